@@ -1,0 +1,190 @@
+/* libsubreg_hip — C ABI of the MI355X-native (gfx950) incremental-episode hot path of
+ * feyzaakyurek/subspace-reg.
+ *
+ * The reference has NO native/FFI interface: its seam is "a torch.nn.Module + autograd"
+ * (SURVEY.md section 8b).  These entry points are what the host-side mirror
+ * (the Python package subspace-reg_amd/subreg_hip, torch.autograd.Function stubs over ctypes) binds;
+ * each one names the reference call site it replaces (paths relative to the reference
+ * repository root).  INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer is CALLER-OWNED device memory (the host
+ *     side passes torch.Tensor.data_ptr()); the library allocates nothing and keeps no
+ *     mutable global state, so one process per GPU is safe.
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no call
+ *     synchronises, allocates or copies to the host => all of it is hipGraph-capturable.
+ *   - return value: SUBREG_OK (0) or a negative code; nothing throws across the ABI.
+ *     -(1000+e) carries hipError_t e of a failed launch.
+ *   - activations: compact NHWC [B*H*W][C] in the compute dtype (SUBREG_F32 | SUBREG_BF16);
+ *     BN parameters, features, classifier and all loss scalars are fp32.
+ *   - single caller thread per process (the reference loop is single-threaded,
+ *     --num_workers 0).
+ */
+#ifndef SUBREG_HIP_H
+#define SUBREG_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUBREG_ABI_VERSION 1
+
+#define SUBREG_OK 0
+#define SUBREG_EINVAL (-1)       /* bad argument (null pointer, shape not supported by contract) */
+#define SUBREG_EUNSUPPORTED (-2) /* valid request the kernels cannot serve (e.g. image too wide for the LDS patch) */
+#define SUBREG_EHIP (-3)         /* HIP runtime call failed */
+
+#define SUBREG_F32 0  /* exact-f32 MFMA path: the 1e-4 parity gate */
+#define SUBREG_BF16 1 /* bf16 MFMA, fp32 accumulate: the throughput path */
+
+/* flags of subreg_conv_fwd / subreg_bn_apply */
+#define SUBREG_CONV_LRELU 1     /* nn.LeakyReLU(0.1), models/resnet_language.py:251 */
+#define SUBREG_CONV_POOL2 2     /* nn.MaxPool2d(2) floor mode, :256,290 */
+#define SUBREG_CONV_RAW_STATS 4 /* train mode: raw conv output + per-channel (sum,sumsq) partials */
+
+/* flags of subreg_backbone_forward */
+#define SUBREG_FWD_TRAIN 1 /* BN batch statistics + running-stat update + keep masks (net.train(), eval/language_eval.py:211) */
+
+int subreg_abi_version(void);
+const char* subreg_strerror(int code);
+
+/* ---- layout packing ------------------------------------------------------------------------- */
+/* First layer (Cin = 3): x NCHW fp32 [B,3,H,W] -> im2col rows [B*H*W][32], k = 3*(3*ky+kx)+c, zero padded.
+ * Turns models/resnet_language.py:249 (conv1 of layer1.0) and :146 (its 1x1 shortcut) into K=32 GEMMs. */
+int subreg_pack_input(const float* x_nchw, void* col, int B, int H, int W, int dtype, void* stream);
+/* Conv2d.weight OIHW fp32 -> [Cout][k*k][Cin] (mode 0) or the K=32 first-layer layout (mode 1, Cin == 3). */
+int subreg_pack_conv_weight(const float* w_oihw, void* out, int Cout, int Cin, int ksize, int mode, int dtype, void* stream);
+int subreg_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, int dtype, void* stream);
+int subreg_nhwc_to_nchw(const void* x_nhwc, float* y_nchw, int B, int C, int H, int W, int dtype, void* stream);
+
+/* ---- convolution: replaces nn.Conv2d (conv3x3 :402-405, 1x1 shortcut :146-147) + fused epilogue -------- */
+/* y = [pool2]( [lrelu]( conv(x,w)*scale + shift [+ residual] ) ), or with SUBREG_CONV_RAW_STATS: y = conv(x,w) and
+ * stats_partial[rows][Cout][2] (rows = subreg_conv_stats_rows).  Cin, Cout multiples of 32; ksize 1 or 3. */
+int subreg_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* shift, const void* residual,
+                    float* stats_partial, int B, int H, int W, int Cin, int Cout, int ksize, int flags, int dtype,
+                    void* stream);
+int subreg_conv_stats_rows(int dtype, int B, int H, int W, int Cout);
+
+/* ---- BatchNorm2d (:148,250,253,255) -------------------------------------------------------------------- */
+/* eval: scale = weight/sqrt(running_var+eps), shift = bias - running_mean*scale */
+int subreg_bn_fold(const float* weight, const float* bias, const float* running_mean, const float* running_var,
+                   float* scale, float* shift, int C, float eps, void* stream);
+/* train: reduce the partials -> batch scale/shift; running stats updated in place (momentum, unbiased var) */
+int subreg_bn_train_finalize(const float* stats_partial, int rows, int C, long long count, const float* weight,
+                             const float* bias, float* running_mean, float* running_var, float momentum, float eps,
+                             float* scale, float* shift, void* stream);
+/* train second pass: y = keep*mask_scale * [pool2]([lrelu]( x*scale+shift + residual*res_scale+res_shift )) */
+int subreg_bn_apply(const void* x, const float* scale, const float* shift, const void* residual, const float* res_scale,
+                    const float* res_shift, const unsigned char* keep_mask, float mask_scale, void* y, int B, int H, int W,
+                    int C, int flags, int dtype, void* stream);
+/* F.dropout (:299) / DropBlock (:311-325) masks: NCHW {0,1} floats -> NHWC u8 keep mask (invert: keep = 1-mask) */
+int subreg_mask_nchw_to_nhwc(const float* mask_nchw, unsigned char* keep_nhwc, int B, int C, int H, int W, int invert,
+                             void* stream);
+/* counter-based Bernoulli(1-p_drop) keep mask for free-running train forwards; kept_count may be NULL */
+int subreg_random_keep_mask(unsigned char* keep, long long n, unsigned long long seed, float p_drop, unsigned int* kept_count,
+                            void* stream);
+/* AdaptiveAvgPool2d(1) + view (:125,179-181): [B][H*W][C] -> fp32 [B][C] */
+int subreg_avgpool(const void* x, float* feat, int B, int H, int W, int C, int dtype, void* stream);
+
+/* ---- whole backbone: ResNet.forward up to `feat` (:170-182), BasicBlock.forward (:268-301) ------------- */
+typedef struct subreg_conv_desc {
+    const void* w;            /* packed weight in the compute dtype; NULL = absent (identity shortcut) */
+    const float* bn_weight;   /* [cout] */
+    const float* bn_bias;     /* [cout] */
+    float* running_mean;      /* [cout] updated in train mode */
+    float* running_var;       /* [cout] */
+    float* scale;             /* [cout] folded (eval) / batch (train) scale, written by the library */
+    float* shift;             /* [cout] */
+    int cin, cout, ksize;     /* as the kernel sees them (first layer: cin 32, ksize 1 over the im2col rows) */
+} subreg_conv_desc;
+
+typedef struct subreg_block_desc {
+    subreg_conv_desc conv1, conv2, conv3, down;
+    int stride;                     /* 2: MaxPool2d(2); 1: identity */
+    const unsigned char* keep_mask; /* train: NHWC u8 keep mask of the block output, NULL = keep all */
+    float mask_scale;               /* 1/(1-p) for dropout, countM/count_ones for DropBlock */
+} subreg_block_desc;
+
+typedef struct subreg_backbone_desc {
+    int n_blocks;
+    const subreg_block_desc* blocks; /* HOST array */
+    int dtype;
+    void* col;         /* [B*H*W][32] first-layer im2col rows */
+    void* ws[4];       /* activation workspaces, each >= subreg_backbone_ws_bytes(...) */
+    float* stats;      /* train: BN partials, >= subreg_backbone_stats_floats(...) floats */
+    float bn_eps, bn_momentum;
+} subreg_backbone_desc;
+
+long long subreg_backbone_ws_bytes(const subreg_backbone_desc* d, int B, int H, int W);
+long long subreg_backbone_stats_floats(const subreg_backbone_desc* d, int B, int H, int W);
+/* eval: fold every BN's running stats into scale/shift (call after the stats changed) */
+int subreg_backbone_fold(const subreg_backbone_desc* d, void* stream);
+/* x NCHW fp32 [B,3,H,W] -> feat fp32 [B][C_last].  stage_out[i] (optional, may be NULL) receives block i's
+ * output as NCHW fp32 (is_feat=True, :189-190). */
+int subreg_backbone_forward(const subreg_backbone_desc* d, const float* x_nchw, int B, int H, int W, float* feat,
+                            float* const* stage_out, int flags, void* stream);
+
+/* ---- classifier head: nn.Linear (:138-140,187) ----------------------------------------------------------- */
+int subreg_linear_fwd(const float* feat, const float* weight, const float* bias, float* logits, int B, int N, int D,
+                      void* stream);
+/* any of dweight/dbias/dfeat may be NULL */
+int subreg_linear_bwd(const float* dlogits, const float* feat, const float* weight, float* dweight, float* dbias,
+                      float* dfeat, int B, int N, int D, void* stream);
+
+/* ---- subspace regularizer: LangPuller.get_projected_weight (:92-97), loss1 (:89-90) --------------------- */
+/* rows of q = orthonormal basis of span(rows of w_base) (replaces torch.qr of a CONSTANT matrix every epoch);
+ * scratch: n_base*D doubles; *info = number of (numerically) dependent rows */
+int subreg_subspace_basis(const float* w_base, float* q, double* scratch, int n_base, int D, int* info, void* stream);
+/* p[k][D] = w q^T q  (projection of the novel rows onto the base span; also its own backward) */
+int subreg_subspace_project(const float* w, const float* q, float* p, int k, int n_base, int D, void* stream);
+/* loss = scale*sum (a-b)^2; grad_a = gscale*grad_out*(a-b), grad_b = -grad_a  (any output may be NULL) */
+int subreg_sqdiff(const float* a, const float* b, long long n, float scale, float* loss, const float* grad_out,
+                  float gscale, float* grad_a, float* grad_b, void* stream);
+/* ResNet.regloss / reglossnovel (:229-240): loss = lmbd*||a-b||_F, grad_a = grad_out*lmbd*(a-b)/||a-b|| (0 at 0) */
+int subreg_frob(const float* a, const float* b, long long n, float lmbd, float* loss, const float* grad_out,
+                float* grad_a, void* stream);
+
+/* ---- fused fine-tune epoch: eval/language_eval.py:252-318 without a host round trip ---------------------- */
+typedef struct subreg_loop_state { /* device resident, one per session */
+    int epoch;        /* completed fine-tune epochs */
+    int stop;         /* stop rule fired (:305,318): later step launches are no-ops */
+    int stable;       /* consecutive |dloss| < eps epochs (:301-304) */
+    int val_epoch;    /* epoch whose validation has been recorded */
+    float train_loss; /* previous epoch's loss, 15 before the first (:234) */
+} subreg_loop_state;
+
+typedef struct subreg_step_desc {
+    const float* feat;       /* [n_support+n_memory][dim] backbone features: support rows then memory rows */
+    const long long* labels; /* [n_support+n_memory] remapped ids */
+    int n_support, n_memory, n_classes, dim;
+    float* weight;           /* [n_classes][dim] classifier.weight, updated in place */
+    float* momentum_buf;     /* [n_classes][dim] */
+    const float* w_base;     /* [n_base][dim] frozen base rows (:106-107) */
+    const float* w_prev;     /* [n_prev][dim] reserved earlier novel rows (:172-185) or NULL */
+    const float* basis;      /* [n_base][dim] from subreg_subspace_basis or NULL */
+    int n_base, n_prev, n_old; /* rows [n_old, n_classes) are this session's novel rows */
+    float lr, momentum, weight_decay, lmbd_base, lmbd_prev, pull;
+    int use_base_reg, use_prev_reg, use_pull;
+    float* dlogits;          /* scratch [n_support+n_memory][n_classes] */
+    float* rowloss;          /* scratch [n_support+n_memory] */
+    int* rowcorrect;         /* scratch [n_support+n_memory] */
+    float* norms;            /* scratch [2] */
+    float* rowl1;            /* scratch [n_classes] */
+    subreg_loop_state* state;
+    float* losses;           /* [max_epochs] loss of every epoch (what the reference prints / the stop rule reads) */
+    float* train_acc;        /* [max_epochs] support top-1 % */
+    int max_epochs, min_epochs, stable_epochs, stable_mode;
+    float target_loss, convergence_eps;
+} subreg_step_desc;
+
+int subreg_loop_state_init(subreg_loop_state* state, void* stream);
+int subreg_finetune_step(const subreg_step_desc* d, void* stream);
+/* validate (:18-43) / eval_base (:46-69): correct[slot*n_sets_max + set_index] += #(argmax == label), slot =
+ * state->epoch (0 when state == NULL); skipped once the stopped loop's last epoch is recorded; mark_done records it */
+int subreg_validate(const float* feat, const long long* labels, const float* weight, int B, int N, int D,
+                    subreg_loop_state* state, int* correct, int set_index, int n_sets_max, int mark_done, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUBREG_HIP_H */

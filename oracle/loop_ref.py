@@ -1,0 +1,196 @@
+"""NumPy restatement of the incremental-session loop (TEST INFRASTRUCTURE, see oracle/__init__.py).
+
+Follows /root/reference/eval/language_eval.py::few_shot_finetune_incremental_test (:71-454)
+with validate (:18-43), eval_base (:46-69) and the helpers of eval/util.py
+(accuracy :26-40, freeze_backbone_weights :62-69, get_optim :92-102 -> torch SGD).
+Only the `distance2subspace` regularizer and the plain-linear classifier without
+bias are restated (the configuration of scripts/continual/slurm_subspace_reg.sh:33-54).
+
+Semantics that parity depends on, all restated here:
+  * net.train() once per session (:211); validate() switches to eval (:19) and
+    nobody switches back => epoch 1 runs the backbone in TRAIN mode (BN batch
+    stats + running-stat update + dropout/DropBlock), epochs >= 2 in EVAL mode.
+  * loss = CE(support) [+ CE(memory)] + regloss + [reglossnovel] + loss1 (:252-290)
+  * fresh SGD(momentum) per session (:231); only classifier.weight has a gradient.
+  * stop rule (:298-318), per-epoch validation on every past query set (:321-326),
+    memory pick (:353-359), base eval (:363-367), 2-dp rounded bookkeeping (:370-393).
+`reuse_features=True` computes each eval-mode feature matrix once per session (the
+backbone is frozen and in eval mode from epoch 2 on, so the values are identical)
+while still advancing the per-block forward counters that feed DropBlock's gamma.
+Parity pinned by tests/golden/loop_*.npz (tools/make_golden.py).
+"""
+import numpy as np
+
+from . import subspace_ref as sr
+from .resnet_ref import linear
+
+
+def cross_entropy(logits, labels):
+    """nn.CrossEntropyLoss (mean).  Returns (loss, dlogits)."""
+    z = logits.astype(np.float64)
+    z = z - z.max(axis=1, keepdims=True)
+    lse = np.log(np.exp(z).sum(axis=1, keepdims=True))
+    logp = z - lse
+    n = logits.shape[0]
+    loss = -logp[np.arange(n), labels].mean()
+    d = np.exp(logp)
+    d[np.arange(n), labels] -= 1.0
+    return float(np.float32(loss)), d / n
+
+
+def accuracy_top1(logits, labels):
+    """eval/util.py:26-40 with topk=(1,): percentage (float32 like torch)."""
+    pred = np.argmax(logits, axis=1)
+    return float(np.float32((pred == labels).sum() * (100.0 / labels.shape[0]))), pred
+
+
+def memory_indices(pick, n_shots=5):
+    """language_eval.py:354-358 for `inds = np.random.choice(n_shots, memory_replay)` == pick."""
+    inds = np.asarray(pick)
+    margin = 5 * np.arange(5)
+    offset = np.arange(0, 125, 25)
+    inds = np.tile(margin + inds, (5, 1)) + (np.tile(offset, (5, 1))).T
+    return inds.flatten()
+
+
+class _Bump:
+    """Advance BasicBlock.num_batches_tracked as one forward would (feature reuse)."""
+
+    def __init__(self, net):
+        self.net = net
+
+    def __call__(self, times=1):
+        for k in self.net.nbt:
+            self.net.nbt[k] += times
+
+
+def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=None,
+                    masks=None, memory_picks=None, reuse_features=True, n_base=60):
+    """Run `len(sessions)` incremental sessions.  Returns a dict of everything the goldens pin."""
+    f32 = np.float32
+    bump = _Bump(net)
+    W = net.sd["classifier.weight"].astype(f32).copy()          # live classifier.weight
+    base_weight = W.copy()                                      # basenet._get_base_weights(), :106-107
+    base_x, base_y = base_batch
+    out = dict(loss=[], test_acc=[], acc_base=[], weighted_avg=[], epochs=[], novel_acc=[],
+               memory_inds=[], train_acc=[])
+
+    def eval_feats(x):
+        net.eval()
+        return net.features(x)
+
+    # initial base evaluation, :128
+    net.sd["classifier.weight"] = W
+    base_feat = eval_feats(base_x)
+    acc_b, _ = accuracy_top1(linear(base_feat, W), base_y)
+    out["weighted_avg"].append(acc_b)
+
+    query_x, query_ids = [], []
+    mem_x, mem_y = None, None
+    reserve = None
+    for idx, sess in enumerate(sessions):
+        sx, sy, qx, qy = sess["support_xs"], sess["support_ys"], sess["query_xs"], sess["query_ys"]
+        if base_support is not None:
+            sx = np.concatenate([sx, base_support[0]], 0)                      # :149-150
+        n_old = n_base + idx * opt.n_ways                                      # len(vocab_base) in the loop
+        if idx == 1:                                                           # :172-185
+            reserve = W[-opt.n_ways:].copy()
+        elif idx > 1:
+            reserve = np.concatenate([reserve, W[-opt.n_ways:].copy()], 0)
+        novel_ids = np.sort(np.unique(qy))
+        orig2id = {int(c): n_base + r + idx * opt.n_ways for r, c in enumerate(novel_ids)}   # :193-194
+        qid = np.array([orig2id[int(y)] for y in qy], np.int64)
+        sid = np.array([orig2id[int(y)] for y in sy], np.int64)
+        query_x.append(qx)
+        query_ids.append(qid)
+        if base_support is not None:
+            sid = np.concatenate([sid, np.asarray(base_support[1], np.int64)])  # :207-209
+        net.train()                                                             # :211
+        W = np.concatenate([W, np.asarray(novel_inits[idx], f32)], 0)           # augment_base_classifier_, :214
+        net.sd["classifier.weight"] = W
+        buf = None                                                              # fresh SGD, :231
+        train_loss, epoch, stable, go = 15, 1, 0, True
+        losses, feat_cache = [], {}
+        while go:
+            # ---- support (+ memory) forward in the CURRENT mode
+            if net.training or not reuse_features:
+                feat_s = net.features(sx, masks)
+                feat_m = net.features(mem_x, masks) if mem_x is not None else None
+            else:
+                if "s" not in feat_cache:
+                    feat_cache["s"] = net.features(sx)
+                    feat_cache["m"] = net.features(mem_x) if mem_x is not None else None
+                else:
+                    bump(1 if mem_x is None else 2)
+                feat_s, feat_m = feat_cache["s"], feat_cache["m"]
+            logits = linear(feat_s, W)
+            loss, dlog = cross_entropy(logits, sid)                              # :252-253
+            grad = dlog.T @ feat_s.astype(np.float64)
+            loss = f32(loss)
+            if feat_m is not None:                                               # :256-258
+                l2, d2 = cross_entropy(linear(feat_m, W), mem_y)
+                loss = f32(loss + f32(l2))
+                grad += d2.T @ feat_m.astype(np.float64)
+            if opt.lmbd_reg_transform_w is not None:                             # :261-265
+                l, g = sr.frob_reg_and_grad(opt.lmbd_reg_transform_w, W[:n_base], base_weight)
+                loss = f32(loss + f32(l))
+                grad[:n_base] += g
+            if opt.lmbd_reg_novel is not None and idx > 0:                       # :268-274
+                k = reserve.shape[0]
+                l, g = sr.frob_reg_and_grad(opt.lmbd_reg_novel, W[n_base:n_base + k], reserve)
+                loss = f32(loss + f32(l))
+                grad[n_base:n_base + k] += g
+            if opt.label_pull is not None:                                       # :277-290
+                l, g = sr.loss1_and_grad(opt.label_pull, base_weight, W[n_old:])
+                loss = f32(loss + f32(l))
+                grad[n_old:] += g
+            # ---- SGD step (torch.optim.SGD: wd added to grad, momentum buffer), :293-295
+            g32 = grad.astype(f32) + f32(opt.weight_decay) * W
+            buf = g32.copy() if buf is None else f32(opt.momentum) * buf + g32
+            W = (W - f32(opt.learning_rate) * buf).astype(f32)
+            net.sd["classifier.weight"] = W
+            # ---- stop rule, :298-318
+            lv = float(loss)
+            if opt.target_train_loss == 0:
+                stable = stable + 1 if abs(lv - train_loss) < opt.convergence_epsilon else 0
+                if stable == opt.stable_epochs:
+                    go = False
+            tr_acc, _ = accuracy_top1(logits, sid)
+            train_loss = lv
+            losses.append(lv)
+            if epoch >= opt.max_novel_epochs or (train_loss <= opt.target_train_loss
+                                                 and epoch >= opt.min_novel_epochs + 1):
+                go = False
+            # ---- validation on every query set so far (eval mode from here on), :321-326
+            net.eval()
+            test_acc = []
+            for j, (xq, yq) in enumerate(zip(query_x, query_ids)):
+                key = ("q", j)
+                if reuse_features and key in feat_cache:
+                    bump()
+                else:
+                    feat_cache[key] = net.features(xq)
+                a, _ = accuracy_top1(linear(feat_cache[key], W), yq)
+                test_acc.append(a)
+            epoch += 1
+        # ---- memory pick, :353-359
+        if opt.memory_replay:
+            inds = memory_indices(memory_picks[idx], opt.n_shots)
+            out["memory_inds"].append(inds)
+            mem_x = sx[inds] if mem_x is None else np.concatenate([mem_x, sx[inds]], 0)
+            mem_y = sid[inds] if mem_y is None else np.concatenate([mem_y, sid[inds]], 0)
+        # ---- base eval with the updated net, :363-367 (eval mode; BN stats may have moved)
+        base_feat = net.features(base_x)
+        acc_b, _ = accuracy_top1(linear(base_feat, W), base_y)
+        test_acc = [round(a, 2) for a in test_acc]                               # :372
+        ta = float(np.array(test_acc).mean())
+        w1, w2 = 60, n_old + opt.n_ways - 60                                     # :383-386
+        out["loss"].append(losses)
+        out["train_acc"].append(tr_acc)
+        out["test_acc"].append(test_acc)
+        out["novel_acc"].append(round(ta, 2))
+        out["acc_base"].append(round(acc_b, 2))
+        out["weighted_avg"].append(round((w1 * acc_b + w2 * ta) / (w1 + w2), 2))
+        out["epochs"].append(epoch - 1)
+    out["classifier_weight"] = W
+    return out

@@ -1,0 +1,155 @@
+// Whole-backbone forward as ONE C-ABI call: the launch sequence of ResNet.forward
+// (models/resnet_language.py:170-182) over BasicBlock.forward (:268-301), eval and train
+// mode, on caller-owned workspaces.  Keeping the per-layer orchestration native removes
+// ~25 Python->ctypes round trips per forward and makes the whole forward capturable into
+// one hipGraph by the host side.
+#include <string.h>
+
+#include "subreg_common.h"
+
+namespace {
+
+struct Shape { int h, w; };
+
+inline size_t elem_size(int dtype) { return dtype == SUBREG_BF16 ? 2 : 4; }
+
+// first block consumes the K=32 im2col rows
+inline bool packed_first(const subreg_backbone_desc* d) { return d->blocks[0].conv1.ksize == 1 && d->blocks[0].conv1.cin == 32; }
+
+int fold_one(const subreg_conv_desc& c, float eps, void* stream) {
+    if (!c.w) return SUBREG_OK;
+    return subreg_bn_fold(c.bn_weight, c.bn_bias, c.running_mean, c.running_var, c.scale, c.shift, c.cout, eps, stream);
+}
+
+#define TRY(expr)                        \
+    do {                                 \
+        const int _rc = (expr);          \
+        if (_rc != SUBREG_OK) return _rc; \
+    } while (0)
+
+// train mode: raw conv + partial stats + finalize (scale/shift of THIS batch, running stats updated)
+int conv_train(const subreg_backbone_desc* d, const subreg_conv_desc& c, const void* x, void* raw, int B, int H, int W,
+               void* stream) {
+    TRY(subreg_conv_fwd(x, c.w, raw, nullptr, nullptr, nullptr, d->stats, B, H, W, c.cin, c.cout, c.ksize,
+                        SUBREG_CONV_RAW_STATS, d->dtype, stream));
+    const int rows = subreg_conv_stats_rows(d->dtype, B, H, W, c.cout);
+    return subreg_bn_train_finalize(d->stats, rows, c.cout, (long long)B * H * W, c.bn_weight, c.bn_bias, c.running_mean,
+                                    c.running_var, d->bn_momentum, d->bn_eps, c.scale, c.shift, stream);
+}
+
+}  // namespace
+
+extern "C" int subreg_abi_version(void) { return SUBREG_ABI_VERSION; }
+
+extern "C" const char* subreg_strerror(int code) {
+    switch (code) {
+        case SUBREG_OK: return "ok";
+        case SUBREG_EINVAL: return "invalid argument";
+        case SUBREG_EUNSUPPORTED: return "unsupported shape for the gfx950 kernels";
+        case SUBREG_EHIP: return "HIP runtime call failed";
+        default: return code <= -1000 ? "kernel launch failed (hipError = -(code+1000))" : "unknown error";
+    }
+}
+
+extern "C" long long subreg_backbone_ws_bytes(const subreg_backbone_desc* d, int B, int H, int W) {
+    if (!d || !d->blocks || d->n_blocks <= 0) return SUBREG_EINVAL;
+    long long worst = (long long)B * H * W * 32;          // im2col rows share the size class of layer 1
+    int h = H, w = W;
+    for (int i = 0; i < d->n_blocks; ++i) {
+        const long long e = (long long)B * h * w * d->blocks[i].conv1.cout;
+        if (e > worst) worst = e;
+        if (d->blocks[i].stride == 2) { h /= 2; w /= 2; }
+    }
+    return worst * (long long)elem_size(d->dtype);
+}
+
+extern "C" long long subreg_backbone_stats_floats(const subreg_backbone_desc* d, int B, int H, int W) {
+    if (!d || !d->blocks || d->n_blocks <= 0) return SUBREG_EINVAL;
+    long long worst = 0;
+    int h = H, w = W;
+    for (int i = 0; i < d->n_blocks; ++i) {
+        const int c = d->blocks[i].conv1.cout;
+        const long long e = (long long)subreg_conv_stats_rows(d->dtype, B, h, w, c) * c * 2;
+        if (e > worst) worst = e;
+        if (d->blocks[i].stride == 2) { h /= 2; w /= 2; }
+    }
+    return worst;
+}
+
+extern "C" int subreg_backbone_fold(const subreg_backbone_desc* d, void* stream) {
+    SUBREG_CHECK_ARG(d && d->blocks && d->n_blocks > 0);
+    for (int i = 0; i < d->n_blocks; ++i) {
+        const subreg_block_desc& b = d->blocks[i];
+        TRY(fold_one(b.conv1, d->bn_eps, stream));
+        TRY(fold_one(b.conv2, d->bn_eps, stream));
+        TRY(fold_one(b.conv3, d->bn_eps, stream));
+        TRY(fold_one(b.down, d->bn_eps, stream));
+    }
+    return SUBREG_OK;
+}
+
+extern "C" int subreg_backbone_forward(const subreg_backbone_desc* d, const float* x_nchw, int B, int H, int W, float* feat,
+                                       float* const* stage_out, int flags, void* stream) {
+    SUBREG_CHECK_ARG(d && d->blocks && d->n_blocks > 0 && x_nchw && feat && B > 0 && H > 0 && W > 0);
+    SUBREG_CHECK_ARG(d->col && d->ws[0] && d->ws[1] && d->ws[2] && d->ws[3]);
+    SUBREG_CHECK_ARG(packed_first(d));
+    const bool train = flags & SUBREG_FWD_TRAIN;
+    SUBREG_CHECK_ARG(!train || d->stats);
+    const int dt = d->dtype;
+
+    TRY(subreg_pack_input(x_nchw, d->col, B, H, W, dt, stream));
+    const void* cur = d->col;
+    int cur_slot = -1;                 // workspace slot holding `cur` (-1: the im2col buffer)
+    int h = H, w = W;
+    for (int i = 0; i < d->n_blocks; ++i) {
+        const subreg_block_desc& b = d->blocks[i];
+        const bool pool = b.stride == 2;
+        SUBREG_CHECK_ARG(b.stride == 1 || b.stride == 2);
+        SUBREG_CHECK_ARG(b.down.w || b.conv1.cin == b.conv3.cout);
+        // three free slots besides the one holding `cur`
+        int fs[3], nf = 0;
+        for (int s = 0; s < 4 && nf < 3; ++s) if (s != cur_slot) fs[nf++] = s;
+        void* A = d->ws[fs[0]];
+        void* Bf = d->ws[fs[1]];
+        void* C = d->ws[fs[2]];
+        const int pflag = pool ? SUBREG_CONV_POOL2 : 0;
+        int out_slot;
+        if (!train) {
+            TRY(subreg_conv_fwd(cur, b.conv1.w, A, b.conv1.scale, b.conv1.shift, nullptr, nullptr, B, h, w, b.conv1.cin,
+                                b.conv1.cout, b.conv1.ksize, SUBREG_CONV_LRELU, dt, stream));
+            TRY(subreg_conv_fwd(A, b.conv2.w, Bf, b.conv2.scale, b.conv2.shift, nullptr, nullptr, B, h, w, b.conv2.cin,
+                                b.conv2.cout, b.conv2.ksize, SUBREG_CONV_LRELU, dt, stream));
+            const void* res = cur;
+            if (b.down.w) {
+                TRY(subreg_conv_fwd(cur, b.down.w, C, b.down.scale, b.down.shift, nullptr, nullptr, B, h, w, b.down.cin,
+                                    b.down.cout, b.down.ksize, 0, dt, stream));
+                res = C;
+            }
+            TRY(subreg_conv_fwd(Bf, b.conv3.w, A, b.conv3.scale, b.conv3.shift, res, nullptr, B, h, w, b.conv3.cin,
+                                b.conv3.cout, b.conv3.ksize, SUBREG_CONV_LRELU | pflag, dt, stream));
+            out_slot = fs[0];
+        } else {
+            TRY(conv_train(d, b.conv1, cur, A, B, h, w, stream));
+            TRY(subreg_bn_apply(A, b.conv1.scale, b.conv1.shift, nullptr, nullptr, nullptr, nullptr, 1.f, A, B, h, w,
+                                b.conv1.cout, SUBREG_CONV_LRELU, dt, stream));
+            TRY(conv_train(d, b.conv2, A, Bf, B, h, w, stream));
+            TRY(subreg_bn_apply(Bf, b.conv2.scale, b.conv2.shift, nullptr, nullptr, nullptr, nullptr, 1.f, Bf, B, h, w,
+                                b.conv2.cout, SUBREG_CONV_LRELU, dt, stream));
+            TRY(conv_train(d, b.conv3, Bf, A, B, h, w, stream));
+            const void* res = cur;
+            const float *rsc = nullptr, *rsh = nullptr;
+            if (b.down.w) {
+                TRY(conv_train(d, b.down, cur, C, B, h, w, stream));
+                res = C; rsc = b.down.scale; rsh = b.down.shift;
+            }
+            TRY(subreg_bn_apply(A, b.conv3.scale, b.conv3.shift, res, rsc, rsh, b.keep_mask, b.mask_scale, Bf, B, h, w,
+                                b.conv3.cout, SUBREG_CONV_LRELU | pflag, dt, stream));
+            out_slot = fs[1];
+        }
+        cur = d->ws[out_slot];
+        cur_slot = out_slot;
+        if (pool) { h /= 2; w /= 2; }
+        if (stage_out && stage_out[i]) TRY(subreg_nhwc_to_nchw(cur, stage_out[i], B, b.conv3.cout, h, w, dt, stream));
+    }
+    return subreg_avgpool(cur, feat, B, h, w, d->blocks[d->n_blocks - 1].conv3.cout, dt, stream);
+}

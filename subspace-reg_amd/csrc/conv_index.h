@@ -1,0 +1,101 @@
+// Index arithmetic of the implicit-GEMM convolution, shared by the gfx950 kernel
+// (conv_fwd.hip) and the host-side emulation test (tests/csrc/conv_index_test.cpp).
+//
+// GEMM view of a bias-free stride-1 'same' conv on compact NHWC activations
+// (reference call sites: models/resnet_language.py:402-405 conv3x3, :146-147 1x1):
+//   C[m][n] = sum_{tap,c} X[pix(m) + off(tap)][c] * Wp[n][tap][c]
+//   M rows  = output pixels, N = Cout, K = taps*Cin.
+// Two row orders:
+//   LINEAR  m == compact pixel index p = (b*H + h)*W + w.
+//   POOL    m = 4*window + sub, window = (b*Hp + hp)*Wp + wp, sub = 2*dy + dx,
+//           pixel (b, 2*hp+dy, 2*wp+dx): the four rows of one 2x2 max-pool window
+//           (nn.MaxPool2d(2), :256,290; floor mode => Hp = H/2, Wp = W/2 and the
+//           odd last row/column is never computed) are consecutive, which is
+//           exactly the 4 accumulator registers (reg&3) one lane holds for a
+//           column of a 32x32 MFMA tile => pooling is an in-register max.
+#pragma once
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SUBREG_HD __host__ __device__ __forceinline__
+#else
+#define SUBREG_HD inline
+#endif
+
+namespace subreg {
+
+struct ConvGeom {
+    int B, H, W;        // input == output spatial size (stride 1, same padding)
+    int Hp, Wp;         // pooled size (H/2, W/2) when POOL
+    int npix;           // B*H*W
+    int M;              // GEMM rows: npix (LINEAR) or B*Hp*Wp*4 (POOL)
+    int taps;           // 1 or 9
+};
+
+SUBREG_HD ConvGeom make_geom(int B, int H, int W, int taps, bool pool) {
+    ConvGeom g;
+    g.B = B; g.H = H; g.W = W; g.Hp = H / 2; g.Wp = W / 2;
+    g.npix = B * H * W;
+    g.M = pool ? B * g.Hp * g.Wp * 4 : g.npix;
+    g.taps = taps;
+    return g;
+}
+
+struct Pix { int p, h, w; };   // compact pixel index and its (h, w)
+
+template <bool POOL>
+SUBREG_HD Pix row_to_pixel(const ConvGeom& g, int m) {
+    Pix r;
+    if (!POOL) {
+        const int hw = g.H * g.W;
+        const int rem = m % hw;
+        r.p = m; r.h = rem / g.W; r.w = rem % g.W;
+    } else {
+        const int win = m >> 2, sub = m & 3;
+        const int per = g.Hp * g.Wp;
+        const int b = win / per, rem = win % per;
+        const int hp = rem / g.Wp, wp = rem % g.Wp;
+        r.h = 2 * hp + (sub >> 1);
+        r.w = 2 * wp + (sub & 1);
+        r.p = (b * g.H + r.h) * g.W + r.w;
+    }
+    return r;
+}
+
+// Contiguous range [lo, hi) of compact pixel rows that the rows [m0, m0+tm) of a
+// tile read through every tap (the LDS activation patch).
+template <bool POOL>
+SUBREG_HD void patch_range(const ConvGeom& g, int m0, int tm, int* lo, int* hi) {
+    int m1 = m0 + tm;
+    if (m1 > g.M) m1 = g.M;
+    const int halo = (g.taps == 9) ? g.W + 1 : 0;
+    int pf, pl;
+    if (!POOL) {
+        pf = m0; pl = m1 - 1;
+    } else {
+        pf = row_to_pixel<true>(g, m0).p;             // sub 0 of the first window
+        pl = row_to_pixel<true>(g, (m1 - 1) | 3).p;   // sub 3 of the last window
+    }
+    int l = pf - halo, h = pl + halo + 1;
+    if (l < 0) l = 0;
+    if (h > g.npix) h = g.npix;
+    *lo = l; *hi = h;
+}
+
+// Is tap (dy,dx) in {-1,0,1}^2 of pixel (h,w) inside the image?  (zero padding otherwise)
+SUBREG_HD bool tap_valid(const ConvGeom& g, int h, int w, int dy, int dx) {
+    const int hh = h + dy, ww = w + dx;
+    return hh >= 0 && hh < g.H && ww >= 0 && ww < g.W;
+}
+
+// LDS row swizzle: the 16-byte slot `slot` of patch/weight row `row` lives at physical
+// slot (slot ^ swz(row)); conflict-free for ds_read_b128 by the 16-lane groups of
+// MI355X_MICROARCH.md section LDS (rows r0+{0..3,12..15,20..27} at one logical slot).
+//   SLOTS = 4 (bf16, 64-byte rows):  swz = (row >> 2) & 3
+//   SLOTS = 8 (f32, 128-byte rows):  swz = (row >> 1) & 7
+template <int SLOTS>
+SUBREG_HD int swz(int row) {
+    return SLOTS == 4 ? ((row >> 2) & 3) : ((row >> 1) & 7);
+}
+
+}  // namespace subreg

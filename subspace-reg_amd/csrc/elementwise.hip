@@ -1,0 +1,305 @@
+// HBM-bound helper kernels around the convolution (gfx950): layout packing, BN
+// folding / train-mode statistics, the train-mode normalise+residual+activation+
+// pool+mask pass, average pooling.  Reference call sites in
+// models/resnet_language.py: nn.BatchNorm2d :148,250,253,255; LeakyReLU :251;
+// residual add :288; MaxPool2d :256,290; F.dropout :299; DropBlock :311-325;
+// AdaptiveAvgPool2d(1) :125,179-181.
+#include "subreg_common.h"
+
+namespace subreg {
+
+constexpr int EW_THREADS = 256;
+
+static inline int ew_blocks(size_t n, int per_thread = 1) {
+    size_t b = (n + (size_t)EW_THREADS * per_thread - 1) / ((size_t)EW_THREADS * per_thread);
+    return (int)(b < 1 ? 1 : b);
+}
+
+// ---------------------------------------------------------------- first-layer im2col (Cin = 3 -> K = 32)
+// x NCHW f32 [B,3,H,W] -> col [B*H*W][32] T with k = 3*tap + c (tap = 3*ky+kx), k >= 27 zero.
+template <typename T>
+__global__ void pack_input_kernel(const float* __restrict__ x, T* __restrict__ col, int B, int H, int W) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B * H * W) return;
+    const int hw = H * W, b = p / hw, r = p % hw, h = r / W, w = r % W;
+    const float* xb = x + (size_t)b * 3 * hw;
+    T out[32];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+        const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[3 * t + c] = ElemTraits<T>::from_float(ok ? xb[(size_t)c * hw + hh * W + ww] : 0.f);
+    }
+#pragma unroll
+    for (int k = 27; k < 32; ++k) out[k] = ElemTraits<T>::from_float(0.f);
+    T* dst = col + (size_t)p * 32;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) dst[k] = out[k];
+}
+
+// ---------------------------------------------------------------- weight packing
+// mode 0: OIHW f32 -> [Cout][k*k][Cin] T.
+// mode 1 (Cin == 3): -> [Cout][32] T over the im2col K axis (3x3: k = 3*tap + c; 1x1: centre tap 4).
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int ks, int mode) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int taps = ks * ks;
+    if (mode == 0) {
+        const size_t total = (size_t)Cout * taps * Cin;
+        if (i >= total) return;
+        const int c = i % Cin, t = (i / Cin) % taps, o = i / ((size_t)Cin * taps);
+        out[i] = ElemTraits<T>::from_float(w[((size_t)o * Cin + c) * taps + t]);
+    } else {
+        const size_t total = (size_t)Cout * 32;
+        if (i >= total) return;
+        const int k = i % 32, o = i / 32;
+        float v = 0.f;
+        if (k < 27) {
+            const int t = k / 3, c = k % 3;
+            if (ks == 3) v = w[((size_t)o * 3 + c) * 9 + t];
+            else if (t == 4) v = w[(size_t)o * 3 + c];
+        }
+        out[i] = ElemTraits<T>::from_float(v);
+    }
+}
+
+// ---------------------------------------------------------------- layout conversion
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C, int HW) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over NHWC output
+    if (i >= (size_t)B * C * HW) return;
+    const int c = i % C;
+    const size_t pb = i / C;
+    const int p = pb % HW, b = pb / HW;
+    y[i] = ElemTraits<T>::from_float(x[((size_t)b * C + c) * HW + p]);
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int B, int C, int HW) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over NCHW output
+    if (i >= (size_t)B * C * HW) return;
+    const int p = i % HW;
+    const size_t cb = i / HW;
+    const int c = cb % C, b = cb / C;
+    y[i] = ElemTraits<T>::to_float(x[((size_t)b * HW + p) * C + c]);
+}
+
+// ---------------------------------------------------------------- BN folding (eval mode)
+__global__ void bn_fold_kernel(const float* __restrict__ weight, const float* __restrict__ bias,
+                               const float* __restrict__ rm, const float* __restrict__ rv, float* __restrict__ scale,
+                               float* __restrict__ shift, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s = weight[c] / sqrtf(rv[c] + eps);
+    scale[c] = s;
+    shift[c] = bias[c] - rm[c] * s;
+}
+
+// ---------------------------------------------------------------- BN train-mode statistics
+// partial [rows][C][2] (sum, sumsq) -> batch mean / biased var -> scale/shift for this batch, and the
+// running-stat update (momentum, unbiased variance) in place.  One thread per channel, fixed summation
+// order in double => bitwise reproducible.
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
+                                   const float* __restrict__ weight, const float* __restrict__ bias,
+                                   float* __restrict__ rm, float* __restrict__ rv, float momentum, float eps,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        s1 += (double)partial[((size_t)r * C + c) * 2];
+        s2 += (double)partial[((size_t)r * C + c) * 2 + 1];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double inv = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)weight[c] * inv;
+    scale[c] = (float)sc;
+    shift[c] = (float)((double)bias[c] - mean * sc);
+    const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * mean);
+    rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * unbiased);
+}
+
+// ---------------------------------------------------------------- train-mode apply pass
+// y = mask * mask_scale * pool( act( x*scale+shift + (res*rscale+rshift | res) ) ), all NHWC.
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                const T* __restrict__ res, const float* __restrict__ rscale,
+                                const float* __restrict__ rshift, const unsigned char* __restrict__ keep,
+                                float mask_scale, T* __restrict__ y, int B, int H, int W, int C, int act, int pool) {
+    const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * Ho * Wo * C) return;
+    const int c = i % C;
+    const size_t po = i / C;
+    const int wo = po % Wo, ho = (po / Wo) % Ho, b = po / ((size_t)Wo * Ho);
+    const float sc = scale[c], sh = shift[c];
+    const float rsc = rscale ? rscale[c] : 1.f, rsh = rshift ? rshift[c] : 0.f;
+    float best = -3.0e38f;
+    const int n = pool ? 2 : 1;
+    for (int dy = 0; dy < n; ++dy)
+        for (int dx = 0; dx < n; ++dx) {
+            const size_t p = ((size_t)b * H + (pool ? 2 * ho + dy : ho)) * W + (pool ? 2 * wo + dx : wo);
+            float v = ElemTraits<T>::to_float(x[p * C + c]) * sc + sh;
+            if (res) v += ElemTraits<T>::to_float(res[p * C + c]) * rsc + rsh;
+            best = fmaxf(best, v);
+        }
+    if (act) best = lrelu(best);
+    if (keep) best = keep[i] ? best * mask_scale : 0.f;
+    y[i] = ElemTraits<T>::from_float(best);
+}
+
+// ---------------------------------------------------------------- keep-mask helpers
+// NCHW f32 {0,1} -> NHWC u8 (masks are drawn in the reference's NCHW order).
+__global__ void mask_nchw_to_nhwc_kernel(const float* __restrict__ m, unsigned char* __restrict__ out, int B, int C, int HW,
+                                         int invert) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * C * HW) return;
+    const int c = i % C;
+    const size_t pb = i / C;
+    const int p = pb % HW, b = pb / HW;
+    const bool one = m[((size_t)b * C + c) * HW + p] != 0.f;
+    out[i] = (one != (invert != 0)) ? 1 : 0;
+}
+
+// counter-based Bernoulli keep mask for free-running (non-injected) train-mode forwards
+__device__ __forceinline__ unsigned mix32(unsigned long long z) {
+    z ^= z >> 33; z *= 0xff51afd7ed558ccdULL; z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ULL; z ^= z >> 33;
+    return (unsigned)(z >> 11);
+}
+__global__ void random_keep_kernel(unsigned char* __restrict__ out, size_t n, unsigned long long seed, float p_drop,
+                                   unsigned int* __restrict__ kept_count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned k = 0;
+    if (i < n) {
+        const float u = (mix32(seed * 0x9E3779B97F4A7C15ULL + i) & 0xFFFFFF) * (1.0f / 16777216.0f);
+        k = u >= p_drop ? 1u : 0u;
+        out[i] = (unsigned char)k;
+    }
+    if (kept_count) {
+        const unsigned long long b = __ballot(k);
+        if ((threadIdx.x & 63) == 0) atomicAdd(kept_count, (unsigned)__popcll(b));
+    }
+}
+
+// ---------------------------------------------------------------- AdaptiveAvgPool2d(1) + view
+template <typename T>
+__global__ void avgpool_kernel(const T* __restrict__ x, float* __restrict__ feat, int B, int HW, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [B][C]
+    if (i >= (size_t)B * C) return;
+    const int c = i % C, b = i / C;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += ElemTraits<T>::to_float(x[((size_t)b * HW + p) * C + c]);
+    feat[i] = s / (float)HW;
+}
+
+}  // namespace subreg
+
+using namespace subreg;
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16)      \
+    if ((dtype) == SUBREG_F32) { CALL_F32; }        \
+    else if ((dtype) == SUBREG_BF16) { CALL_BF16; } \
+    else return SUBREG_EINVAL;
+
+extern "C" int subreg_pack_input(const float* x_nchw, void* col, int B, int H, int W, int dtype, void* stream) {
+    SUBREG_CHECK_ARG(x_nchw && col && B > 0 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int n = B * H * W;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_input_kernel<float>, ew_blocks(n), EW_THREADS, 0, s, x_nchw, (float*)col, B, H, W),
+               hipLaunchKernelGGL(pack_input_kernel<__bf16>, ew_blocks(n), EW_THREADS, 0, s, x_nchw, (__bf16*)col, B, H, W));
+    return launch_status();
+}
+
+extern "C" int subreg_pack_conv_weight(const float* w_oihw, void* out, int Cout, int Cin, int ksize, int mode, int dtype,
+                                       void* stream) {
+    SUBREG_CHECK_ARG(w_oihw && out && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3));
+    SUBREG_CHECK_ARG(mode == 0 || (mode == 1 && Cin == 3));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = mode == 0 ? (size_t)Cout * ksize * ksize * Cin : (size_t)Cout * 32;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(pack_weight_kernel<float>, ew_blocks(n), EW_THREADS, 0, s, w_oihw, (float*)out, Cout, Cin, ksize, mode),
+               hipLaunchKernelGGL(pack_weight_kernel<__bf16>, ew_blocks(n), EW_THREADS, 0, s, w_oihw, (__bf16*)out, Cout, Cin, ksize, mode));
+    return launch_status();
+}
+
+extern "C" int subreg_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int dtype, void* stream) {
+    SUBREG_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * C * H * W;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, ew_blocks(n), EW_THREADS, 0, s, x, (float*)y, B, C, H * W),
+               hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, ew_blocks(n), EW_THREADS, 0, s, x, (__bf16*)y, B, C, H * W));
+    return launch_status();
+}
+
+extern "C" int subreg_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int dtype, void* stream) {
+    SUBREG_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * C * H * W;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, ew_blocks(n), EW_THREADS, 0, s, (const float*)x, y, B, C, H * W),
+               hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, ew_blocks(n), EW_THREADS, 0, s, (const __bf16*)x, y, B, C, H * W));
+    return launch_status();
+}
+
+extern "C" int subreg_bn_fold(const float* weight, const float* bias, const float* running_mean, const float* running_var,
+                              float* scale, float* shift, int C, float eps, void* stream) {
+    SUBREG_CHECK_ARG(weight && bias && running_mean && running_var && scale && shift && C > 0);
+    hipLaunchKernelGGL(bn_fold_kernel, ew_blocks(C), EW_THREADS, 0, (hipStream_t)stream, weight, bias, running_mean,
+                       running_var, scale, shift, C, eps);
+    return launch_status();
+}
+
+extern "C" int subreg_bn_train_finalize(const float* stats_partial, int rows, int C, long long count, const float* weight,
+                                        const float* bias, float* running_mean, float* running_var, float momentum,
+                                        float eps, float* scale, float* shift, void* stream) {
+    SUBREG_CHECK_ARG(stats_partial && weight && bias && running_mean && running_var && scale && shift);
+    SUBREG_CHECK_ARG(rows > 0 && C > 0 && count > 0);
+    hipLaunchKernelGGL(bn_finalize_kernel, ew_blocks(C), EW_THREADS, 0, (hipStream_t)stream, stats_partial, rows, C,
+                       (double)count, weight, bias, running_mean, running_var, momentum, eps, scale, shift);
+    return launch_status();
+}
+
+extern "C" int subreg_bn_apply(const void* x, const float* scale, const float* shift, const void* residual,
+                               const float* res_scale, const float* res_shift, const unsigned char* keep_mask,
+                               float mask_scale, void* y, int B, int H, int W, int C, int flags, int dtype, void* stream) {
+    SUBREG_CHECK_ARG(x && scale && shift && y && B > 0 && H > 0 && W > 0 && C > 0);
+    const int act = (flags & SUBREG_CONV_LRELU) ? 1 : 0, pool = (flags & SUBREG_CONV_POOL2) ? 1 : 0;
+    SUBREG_CHECK_ARG(!pool || (H >= 2 && W >= 2));
+    const size_t n = (size_t)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * C;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(bn_apply_kernel<float>, ew_blocks(n), EW_THREADS, 0, s, (const float*)x, scale, shift,
+                                  (const float*)residual, res_scale, res_shift, keep_mask, mask_scale, (float*)y, B, H, W, C, act, pool),
+               hipLaunchKernelGGL(bn_apply_kernel<__bf16>, ew_blocks(n), EW_THREADS, 0, s, (const __bf16*)x, scale, shift,
+                                  (const __bf16*)residual, res_scale, res_shift, keep_mask, mask_scale, (__bf16*)y, B, H, W, C, act, pool));
+    return launch_status();
+}
+
+extern "C" int subreg_mask_nchw_to_nhwc(const float* mask_nchw, unsigned char* keep_nhwc, int B, int C, int H, int W,
+                                        int invert, void* stream) {
+    SUBREG_CHECK_ARG(mask_nchw && keep_nhwc && B > 0 && C > 0 && H > 0 && W > 0);
+    const size_t n = (size_t)B * C * H * W;
+    hipLaunchKernelGGL(mask_nchw_to_nhwc_kernel, ew_blocks(n), EW_THREADS, 0, (hipStream_t)stream, mask_nchw, keep_nhwc,
+                       B, C, H * W, invert);
+    return launch_status();
+}
+
+extern "C" int subreg_random_keep_mask(unsigned char* keep, long long n, unsigned long long seed, float p_drop,
+                                       unsigned int* kept_count, void* stream) {
+    SUBREG_CHECK_ARG(keep && n > 0 && p_drop >= 0.f && p_drop < 1.f);
+    hipLaunchKernelGGL(random_keep_kernel, ew_blocks((size_t)n), EW_THREADS, 0, (hipStream_t)stream, keep, (size_t)n, seed,
+                       p_drop, kept_count);
+    return launch_status();
+}
+
+extern "C" int subreg_avgpool(const void* x, float* feat, int B, int H, int W, int C, int dtype, void* stream) {
+    SUBREG_CHECK_ARG(x && feat && B > 0 && H > 0 && W > 0 && C > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * C;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(avgpool_kernel<float>, ew_blocks(n), EW_THREADS, 0, s, (const float*)x, feat, B, H * W, C),
+               hipLaunchKernelGGL(avgpool_kernel<__bf16>, ew_blocks(n), EW_THREADS, 0, s, (const __bf16*)x, feat, B, H * W, C));
+    return launch_status();
+}

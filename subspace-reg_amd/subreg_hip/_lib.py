@@ -1,0 +1,142 @@
+"""ctypes binding of libsubreg_hip.so (include/subreg_hip.h).
+
+The library is built in-tree (subspace-reg_amd/Makefile, hipcc --offload-arch=gfx950) and
+loaded lazily.  There is NO fallback: if the .so is missing or a call returns a negative
+code, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsubreg_hip.so")
+
+F32, BF16 = 0, 1
+CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
+FWD_TRAIN = 1
+ABI_VERSION = 1
+
+c_void_p, c_int, c_float, c_longlong = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("w", c_void_p), ("bn_weight", c_void_p), ("bn_bias", c_void_p), ("running_mean", c_void_p),
+                ("running_var", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+                ("cin", c_int), ("cout", c_int), ("ksize", c_int)]
+
+
+class BlockDesc(C.Structure):
+    _fields_ = [("conv1", ConvDesc), ("conv2", ConvDesc), ("conv3", ConvDesc), ("down", ConvDesc),
+                ("stride", c_int), ("keep_mask", c_void_p), ("mask_scale", c_float)]
+
+
+class BackboneDesc(C.Structure):
+    _fields_ = [("n_blocks", c_int), ("blocks", C.POINTER(BlockDesc)), ("dtype", c_int), ("col", c_void_p),
+                ("ws", c_void_p * 4), ("stats", c_void_p), ("bn_eps", c_float), ("bn_momentum", c_float)]
+
+
+class LoopState(C.Structure):
+    _fields_ = [("epoch", c_int), ("stop", c_int), ("stable", c_int), ("val_epoch", c_int), ("train_loss", c_float)]
+
+
+class StepDesc(C.Structure):
+    _fields_ = [("feat", c_void_p), ("labels", c_void_p),
+                ("n_support", c_int), ("n_memory", c_int), ("n_classes", c_int), ("dim", c_int),
+                ("weight", c_void_p), ("momentum_buf", c_void_p), ("w_base", c_void_p), ("w_prev", c_void_p),
+                ("basis", c_void_p), ("n_base", c_int), ("n_prev", c_int), ("n_old", c_int),
+                ("lr", c_float), ("momentum", c_float), ("weight_decay", c_float), ("lmbd_base", c_float),
+                ("lmbd_prev", c_float), ("pull", c_float),
+                ("use_base_reg", c_int), ("use_prev_reg", c_int), ("use_pull", c_int),
+                ("dlogits", c_void_p), ("rowloss", c_void_p), ("rowcorrect", c_void_p), ("norms", c_void_p),
+                ("rowl1", c_void_p), ("state", c_void_p), ("losses", c_void_p), ("train_acc", c_void_p),
+                ("max_epochs", c_int), ("min_epochs", c_int), ("stable_epochs", c_int), ("stable_mode", c_int),
+                ("target_loss", c_float), ("convergence_eps", c_float)]
+
+
+# name -> (restype, argtypes); every symbol include/subreg_hip.h declares
+_P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
+SIGNATURES = {
+    "subreg_abi_version": (_I, []),
+    "subreg_strerror": (C.c_char_p, [_I]),
+    "subreg_pack_input": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "subreg_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "subreg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "subreg_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "subreg_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "subreg_conv_stats_rows": (_I, [_I, _I, _I, _I, _I]),
+    "subreg_bn_fold": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _P]),
+    "subreg_bn_train_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P]),
+    "subreg_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "subreg_mask_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "subreg_random_keep_mask": (_I, [_P, _L, C.c_ulonglong, _F, _P, _P]),
+    "subreg_avgpool": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "subreg_backbone_ws_bytes": (_L, [C.POINTER(BackboneDesc), _I, _I, _I]),
+    "subreg_backbone_stats_floats": (_L, [C.POINTER(BackboneDesc), _I, _I, _I]),
+    "subreg_backbone_fold": (_I, [C.POINTER(BackboneDesc), _P]),
+    "subreg_backbone_forward": (_I, [C.POINTER(BackboneDesc), _P, _I, _I, _I, _P, C.POINTER(_P), _I, _P]),
+    "subreg_linear_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "subreg_linear_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "subreg_subspace_basis": (_I, [_P, _P, _P, _I, _I, _P, _P]),
+    "subreg_subspace_project": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "subreg_sqdiff": (_I, [_P, _P, _L, _F, _P, _P, _F, _P, _P, _P]),
+    "subreg_frob": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
+    "subreg_loop_state_init": (_I, [_P, _P]),
+    "subreg_finetune_step": (_I, [C.POINTER(StepDesc), _P]),
+    "subreg_validate": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into libsubreg_hip.so (hipcc cross-compiles without a GPU)."""
+    root = os.path.dirname(_HERE)
+    r = subprocess.run(["make", "-C", root, "-j4"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise RuntimeError("building libsubreg_hip.so failed")
+    return LIB_PATH
+
+
+def load():
+    """Load the HIP library (once).  Raises if it is missing: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libsubreg_hip.so not found at %s - run `make -C subspace-reg_amd` "
+                           "(or __graft_entry__.build()); the HIP path has no fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.subreg_abi_version() != ABI_VERSION:
+        raise RuntimeError("libsubreg_hip.so ABI %d != binding %d" % (lib.subreg_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().subreg_strerror(int(rc)).decode()
+        raise RuntimeError("libsubreg_hip %s failed: %s (code %d)" % (what, msg, rc))
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def dtype_code(name):
+    if name in (F32, "f32", "fp32", "float32"):
+        return F32
+    if name in (BF16, "bf16", "bfloat16"):
+        return BF16
+    raise ValueError("dtype must be 'f32' or 'bf16', got %r" % (name,))

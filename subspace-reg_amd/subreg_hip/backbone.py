@@ -1,0 +1,213 @@
+"""Host-side owner of one backbone on one GPU: packed weights, folded BN, workspaces.
+
+Drives `subreg_backbone_forward` (csrc/backbone.hip), i.e. ResNet.forward up to `feat`
+(/root/reference/models/resnet_language.py:170-182) over BasicBlock.forward (:268-301).
+All tensors are torch CUDA tensors used as plain device memory; torch does no math here.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .synthetic import backbone_blocks
+
+DROP_RATE = 0.1     # models/util.py:15-18
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def dropblock_gamma(num_batches_tracked, feat_size, block_size, drop_rate=DROP_RATE):
+    """BasicBlock.forward :294-296."""
+    keep_rate = max(1.0 - drop_rate / (20 * 2000) * num_batches_tracked, 1.0 - drop_rate)
+    return (1 - keep_rate) / block_size ** 2 * feat_size ** 2 / (feat_size - block_size + 1) ** 2
+
+
+def dropblock_block_mask_host(sample_nchw, block_size):
+    """DropBlock._compute_block_mask (:327-357) for block_size > 1, on the host (mask preparation only;
+    every script of the reference passes --no_dropblock => block_size 1, which never comes here).
+    Restates the reference's repeat/tile pairing: seed i % n meets offset i % bs^2."""
+    bs = block_size
+    lp, rp = int((bs - 1) / 2), int(bs / 2)
+    padded = np.pad(sample_nchw, ((0, 0), (0, 0), (lp, rp), (lp, rp))).astype(np.float32)
+    nz = np.argwhere(sample_nchw != 0)
+    n = nz.shape[0]
+    if n:
+        i = np.arange(bs * bs * n)
+        s, o = nz[i % n], i % (bs * bs)
+        padded[s[:, 0], s[:, 1], s[:, 2] + o // bs, s[:, 3] + o % bs] = 1.0
+    return 1.0 - padded
+
+
+class HipBackbone:
+    """params: dict with the reference's state_dict key names -> LIVE fp32 CUDA tensors (conv weights, BN
+    weight/bias/running_mean/running_var).  BN running stats are updated in place by train-mode forwards."""
+
+    MAX_EVAL_CHUNK = 256
+
+    def __init__(self, params, n_blocks=(1, 1, 2, 2), dtype="bf16", block_size=1):
+        self.lib = _lib.load()
+        self.params = params
+        self.dtype = _lib.dtype_code(dtype)
+        self.tdtype = torch.bfloat16 if self.dtype == _lib.BF16 else torch.float32
+        self.block_size = block_size
+        self.blocks = backbone_blocks(n_blocks)
+        self.device = params[self.blocks[0][0] + ".conv1.weight"].device
+        assert self.device.type == "cuda", "HipBackbone needs CUDA (HIP) tensors"
+        self.nbt = [0] * len(self.blocks)          # BasicBlock.num_batches_tracked (:260,269): counts EVERY forward
+        self.out_dim = self.blocks[-1][2]
+        self._packed, self._scale, self._shift = {}, {}, {}
+        self._versions = None
+        self._fold_versions = None
+        self._cap = (0, 0, 0)
+        self._keep = []
+        self._blk = (_lib.BlockDesc * len(self.blocks))()
+        self._desc = _lib.BackboneDesc()
+        self._desc.n_blocks = len(self.blocks)
+        self._desc.blocks = C.cast(self._blk, C.POINTER(_lib.BlockDesc))
+        self._desc.dtype = self.dtype
+        self._desc.bn_eps, self._desc.bn_momentum = BN_EPS, BN_MOMENTUM
+        self._alloc_static()
+        self.refresh(force=True)
+
+    # ------------------------------------------------------------------ descriptors
+    def _convs(self):
+        for bi, (name, cin, cout, _stride, ds, _db) in enumerate(self.blocks):
+            first = bi == 0 and cin == 3
+            yield bi, "conv1", name + ".conv1", name + ".bn1", cin, cout, 3, first
+            yield bi, "conv2", name + ".conv2", name + ".bn2", cout, cout, 3, False
+            yield bi, "conv3", name + ".conv3", name + ".bn3", cout, cout, 3, False
+            if ds:
+                yield bi, "down", name + ".downsample.0", name + ".downsample.1", cin, cout, 1, first
+
+    def _alloc_static(self):
+        dev = self.device
+        for bi, slot, cname, bname, cin, cout, k, first in self._convs():
+            kin, kk = (32, 1) if first else (cin, k)
+            self._packed[cname] = torch.empty(cout * kk * kk * kin, dtype=self.tdtype, device=dev)
+            self._scale[cname] = torch.empty(cout, dtype=torch.float32, device=dev)
+            self._shift[cname] = torch.empty(cout, dtype=torch.float32, device=dev)
+            cd = getattr(self._blk[bi], slot)
+            cd.cin, cd.cout, cd.ksize = kin, cout, kk
+        for bi, (name, _cin, _cout, stride, _ds, _db) in enumerate(self.blocks):
+            self._blk[bi].stride = stride
+            self._blk[bi].keep_mask = None
+            self._blk[bi].mask_scale = 1.0
+
+    def _bind_pointers(self):
+        p = self.params
+        for bi, slot, cname, bname, cin, cout, k, first in self._convs():
+            cd = getattr(self._blk[bi], slot)
+            cd.w = self._packed[cname].data_ptr()
+            cd.bn_weight, cd.bn_bias = p[bname + ".weight"].data_ptr(), p[bname + ".bias"].data_ptr()
+            cd.running_mean, cd.running_var = p[bname + ".running_mean"].data_ptr(), p[bname + ".running_var"].data_ptr()
+            cd.scale, cd.shift = self._scale[cname].data_ptr(), self._shift[cname].data_ptr()
+
+    def refresh(self, force=False):
+        """Re-pack conv weights / re-fold BN if the module's tensors changed (tensor._version / data_ptr)."""
+        p = self.params
+        wv = tuple((p[c + ".weight"].data_ptr(), p[c + ".weight"]._version) for _, _, c, *_ in self._convs())
+        bv = tuple((p[b + s].data_ptr(), p[b + s]._version) for _, _, _, b, *_ in self._convs()
+                   for s in (".weight", ".bias", ".running_mean", ".running_var"))
+        s = _lib.stream_ptr()
+        if force or wv != self._versions:
+            for bi, slot, cname, bname, cin, cout, k, first in self._convs():
+                w = p[cname + ".weight"]
+                assert w.dtype == torch.float32 and w.is_contiguous()
+                _lib.check(self.lib.subreg_pack_conv_weight(_lib.ptr(w), _lib.ptr(self._packed[cname]), cout, cin, k,
+                                                            1 if first else 0, self.dtype, s), "pack_conv_weight")
+            self._versions = wv
+        if force or bv != self._fold_versions:
+            self._bind_pointers()
+            _lib.check(self.lib.subreg_backbone_fold(C.byref(self._desc), s), "backbone_fold")
+            self._fold_versions = bv
+
+    def _ensure_workspace(self, B, H, W):
+        cb, ch, cw = self._cap
+        if B <= cb and H == ch and W == cw:
+            return
+        dev = self.device
+        nbytes = self.lib.subreg_backbone_ws_bytes(C.byref(self._desc), B, H, W)
+        nstats = self.lib.subreg_backbone_stats_floats(C.byref(self._desc), B, H, W)
+        assert nbytes > 0 and nstats > 0
+        self._ws = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(4)]
+        self._col = torch.empty(B * H * W * 32, dtype=self.tdtype, device=dev)
+        self._stats = torch.empty(nstats, dtype=torch.float32, device=dev)
+        for i in range(4):
+            self._desc.ws[i] = self._ws[i].data_ptr()
+        self._desc.col = self._col.data_ptr()
+        self._desc.stats = self._stats.data_ptr()
+        self._cap = (B, H, W)
+
+    # ------------------------------------------------------------------ train-mode masks
+    def _prepare_masks(self, B, H, W, masks):
+        """Keep masks of every block output (dropout :299 / DropBlock :311-325), uploaded as NHWC u8."""
+        self._keep = []
+        s = _lib.stream_ptr()
+        h, w = H, W
+        for bi, (name, _cin, cout, stride, _ds, db) in enumerate(self.blocks):
+            h, w = h // stride, w // stride
+            n = B * cout * h * w
+            keep = torch.empty(n, dtype=torch.uint8, device=self.device)
+            if not db:
+                scale = float(np.float32(1.0) / np.float32(1.0 - DROP_RATE))
+                if masks is None:
+                    _lib.check(self.lib.subreg_random_keep_mask(_lib.ptr(keep), n, int(torch.randint(0, 2 ** 62, (1,))),
+                                                                DROP_RATE, None, s), "random_keep_mask")
+                else:
+                    m = torch.from_numpy(masks.dropout_keep((B, cout, h, w), DROP_RATE)).to(self.device)
+                    _lib.check(self.lib.subreg_mask_nchw_to_nhwc(_lib.ptr(m), _lib.ptr(keep), B, cout, h, w, 0, s), "mask")
+            else:
+                bs = self.block_size
+                gamma = dropblock_gamma(self.nbt[bi], h, bs)
+                shape = (B, cout, h - (bs - 1), w - (bs - 1))
+                if masks is None and bs == 1:
+                    cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
+                    _lib.check(self.lib.subreg_random_keep_mask(_lib.ptr(keep), n, int(torch.randint(0, 2 ** 62, (1,))),
+                                                                float(gamma), _lib.ptr(cnt), s), "random_keep_mask")
+                    scale = n / max(int(cnt.item()), 1)
+                else:
+                    sample = (masks.bernoulli(shape, gamma) if masks is not None
+                              else (np.random.random_sample(shape) < gamma).astype(np.float32))
+                    bm = 1.0 - sample if bs == 1 else dropblock_block_mask_host(sample, bs)
+                    scale = bm.size / bm.sum()
+                    m = torch.from_numpy(np.ascontiguousarray(bm, dtype=np.float32)).to(self.device)
+                    _lib.check(self.lib.subreg_mask_nchw_to_nhwc(_lib.ptr(m), _lib.ptr(keep), B, cout, h, w, 0, s), "mask")
+            self._keep.append(keep)
+            self._blk[bi].keep_mask = keep.data_ptr()
+            self._blk[bi].mask_scale = float(scale)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, train=False, masks=None, return_stages=False, out=None):
+        """x: [B,3,H,W] fp32 CUDA (NCHW like the reference) -> feat [B,out_dim] fp32."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        self.refresh()
+        for i in range(len(self.nbt)):
+            self.nbt[i] += 1
+        feat = out if out is not None else torch.empty(B, self.out_dim, dtype=torch.float32, device=self.device)
+        stages, stage_ptrs = None, None
+        if return_stages:
+            stages, h, w = [], H, W
+            for (_n, _ci, cout, stride, _ds, _db) in self.blocks:
+                h, w = h // stride, w // stride
+                stages.append(torch.empty(B, cout, h, w, dtype=torch.float32, device=self.device))
+        chunk = B if (train or return_stages) else min(B, self.MAX_EVAL_CHUNK)
+        self._ensure_workspace(chunk, H, W)
+        s = _lib.stream_ptr()
+        if train:
+            self._prepare_masks(B, H, W, masks)
+        for b0 in range(0, B, chunk):
+            nb = min(chunk, B - b0)
+            if stages is not None:
+                stage_ptrs = (C.c_void_p * len(stages))(*[t.data_ptr() for t in stages])
+            _lib.check(self.lib.subreg_backbone_forward(C.byref(self._desc), _lib.ptr(x[b0:b0 + nb]), nb, H, W,
+                                                        _lib.ptr(feat[b0:b0 + nb]), stage_ptrs,
+                                                        _lib.FWD_TRAIN if train else 0, s), "backbone_forward")
+        if train:
+            self._fold_versions = None      # running stats moved: re-fold before the next eval forward
+            for bi in range(len(self.blocks)):
+                self._blk[bi].keep_mask = None
+        if return_stages:
+            return feat, stages
+        return feat

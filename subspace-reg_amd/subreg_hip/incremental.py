@@ -1,0 +1,249 @@
+"""MI355X-native counterpart of eval/language_eval.py::few_shot_finetune_incremental_test (:71-454).
+
+Same signature, same loaders, same printed result lines, same session semantics (label remap,
+reserved rows, train-mode epoch 1 / eval-mode epochs >= 2, memory replay, stop rule, 2-dp
+bookkeeping) - but one epoch is: ONE batched backbone launch sequence over support+memory+all
+query sets (eval-mode images are independent, so batching them is results-identical), the
+three-launch fused fine-tune step and one validation launch per query set, with the stop rule
+evaluated on the device so that `epochs_per_sync` epochs are queued without a host round trip.
+Every epoch still recomputes the frozen backbone like the reference does (no feature caching)
+unless `reuse_features=True` is passed explicitly.
+"""
+import ctypes as C
+import itertools
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import functional as HF
+
+
+def _drop_a_dim(data):
+    """eval/util.py:131-138."""
+    support_xs, support_ys, query_xs, query_ys = data
+    _, _, height, width, channel = support_xs.size()
+    support_xs = support_xs.view(-1, height, width, channel)
+    query_xs = query_xs.view(-1, height, width, channel)
+    return support_xs, support_ys.view(-1).detach().cpu().numpy(), query_xs, query_ys.view(-1).detach().cpu().numpy()
+
+
+def _vocabs(base_loader, novel_loader, query_ys):
+    """eval/util.py:112-129."""
+    vocab_base = [n for n in base_loader.dataset.label2human if n != ""]
+    novel_ids = np.sort(np.unique(query_ys))
+    l2h = novel_loader.dataset.label2human
+    vocab_novel = [l2h[i] for i in novel_ids]
+    orig2id = dict(zip(novel_ids, len(vocab_base) + np.arange(len(novel_ids))))
+    return vocab_base, vocab_novel, orig2id
+
+
+def _acc(correct, n):
+    """eval/util.py:26-40: float32 count * float32(100/n)."""
+    return float(np.float32(correct) * np.float32(100.0 / n))
+
+
+class _Session:
+    """Device buffers of one session's fused loop."""
+
+    def __init__(self, dev, n_rows, n_cls, dim, max_epochs, n_sets):
+        f32, i32 = torch.float32, torch.int32
+        self.state = torch.zeros(5, dtype=i32, device=dev)            # subreg_loop_state (4 ints + 1 float)
+        self.dlogits = torch.empty(n_rows * n_cls, dtype=f32, device=dev)
+        self.rowloss = torch.empty(n_rows, dtype=f32, device=dev)
+        self.rowcorrect = torch.empty(n_rows, dtype=i32, device=dev)
+        self.norms = torch.zeros(2, dtype=f32, device=dev)
+        self.rowl1 = torch.zeros(n_cls, dtype=f32, device=dev)
+        self.losses = torch.zeros(max_epochs, dtype=f32, device=dev)
+        self.train_acc = torch.zeros(max_epochs, dtype=f32, device=dev)
+        self.correct = torch.zeros((max_epochs + 1) * n_sets, dtype=i32, device=dev)
+        self.mom = torch.zeros(n_cls * dim, dtype=f32, device=dev)
+
+
+def few_shot_finetune_incremental_test(net, ckpt, criterion, meta_valloader, base_val_loader, opt, vis=False,
+                                       base_support_loader=None, *, novel_inits=None, memory_picks=None,
+                                       epochs_per_sync=8, reuse_features=False, verbose=True):
+    """Drop-in for the reference function.  Extra keyword-only arguments (all optional):
+      novel_inits     list of [n_ways, 640] init rows passed to augment_base_classifier_(novel_weight=...)
+      memory_picks    list of np.random.choice(n_shots, memory_replay) results (else drawn from np.random)
+      epochs_per_sync epochs queued per host synchronisation
+      reuse_features  opt-in: compute the (constant) eval-mode features once per session
+    Returns (acc_novel.avg, acc_base.avg) like the reference; details are left in net.last_run."""
+    if vis or getattr(opt, "track_weights", False) or getattr(opt, "save_preds_0", False):
+        raise NotImplementedError("visualisation / CSV tracking are outside the hot path (SURVEY.md section 8)")
+    if getattr(opt, "label_pull", None) is not None and getattr(opt, "attraction_override", None) != "distance2subspace":
+        raise NotImplementedError("fused loop implements the distance2subspace regularizer "
+                                  "(scripts/continual/slurm_subspace_reg.sh); use the module surface for the others")
+    if net.classifier.bias is not None:
+        raise NotImplementedError("fused loop assumes --no_linear_bias backbones (slurm_run_backbone.sh:39)")
+    if getattr(opt, "adam", False):
+        raise NotImplementedError("fused step implements SGD(momentum) (eval/util.py:98-101)")
+    lib = _lib.load()
+    dev = net.classifier.weight.device
+    p = (lambda *a, **k: print(*a, **k)) if verbose else (lambda *a, **k: None)
+    torch.manual_seed(opt.set_seed)                                          # :101-102
+    np.random.seed(opt.set_seed)
+    hb = net.hip_backbone()
+    D = net.classifier.weight.shape[1]
+    base_weight = net.classifier.weight.detach().clone()                     # :106-107
+    n_base = base_weight.shape[0]
+    basis, basis_info = (HF.subspace_basis(base_weight) if opt.label_pull is not None else (None, None))
+    base_it = itertools.cycle(iter(base_val_loader))
+    meta_it = itertools.cycle(iter(meta_valloader))
+    base_support_xs = base_support_ys = None
+    if base_support_loader is not None:                                      # :112-116
+        base_support_xs, base_support_ys, *_ = _drop_a_dim(next(itertools.cycle(iter(base_support_loader))))
+    base_batch = next(base_it)                                               # :121
+    base_x = base_batch[0].squeeze(0).to(dev, torch.float32)
+    base_y = base_batch[1].squeeze(0).to(dev, torch.int64)
+    s = _lib.stream_ptr
+
+    def eval_base():                                                         # :46-69
+        net.eval()
+        feat = hb.forward(base_x)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        W = net.classifier.weight.detach()
+        _lib.check(lib.subreg_validate(_lib.ptr(feat), _lib.ptr(base_y), _lib.ptr(W), feat.shape[0], W.shape[0], D,
+                                       None, _lib.ptr(cnt), 0, 1, 0, s()), "validate(base)")
+        return _acc(int(cnt.item()), feat.shape[0])
+
+    acc_novel_list, acc_base_list, weighted_avg_l = [], [], []
+    novel_vals, base_vals = [], []                                           # AverageMeter contents (:379-380)
+    weighted_avg_l.append(eval_base())                                       # :128-129
+    iter_num = 8 if getattr(opt, "continual", False) else opt.neval_episodes # :132-136
+    query_x, query_id = [], []
+    mem_x = mem_y = None
+    reserve = None
+    run = dict(loss=[], test_acc=[], epochs=[], train_acc=[], memory_inds=[])
+    vocab_base = vocab_novel = None
+    for idx in range(iter_num):
+        p("\n**** Iteration {}/{} ****\n".format(idx + 1, opt.neval_episodes))
+        support_xs, support_ys, qx, qy = _drop_a_dim(next(meta_it))
+        if base_support_xs is not None:
+            support_xs = torch.cat([support_xs, base_support_xs], 0)          # :149-150
+        prev_vb, prev_vn = vocab_base, vocab_novel
+        vocab_base, vocab_novel, orig2id = _vocabs(base_val_loader, meta_valloader, qy)
+        n_vb = len(vocab_base)
+        if idx > 0:
+            vocab_base = prev_vb + prev_vn                                     # :166-167
+        n_old = len(vocab_base)
+        W = net.classifier.weight.detach()
+        if idx == 1:                                                           # :172-185
+            reserve = W[-opt.n_ways:].clone()
+        elif idx > 1:
+            reserve = torch.cat((reserve, W[-opt.n_ways:].clone()), 0)
+        novel_labels = np.sort(np.unique(qy))
+        orig2id = {k: v + idx * opt.n_ways for k, v in orig2id.items()}        # :193-194
+        qid = torch.tensor([orig2id[y] for y in qy], dtype=torch.int64)
+        sid = torch.tensor([orig2id[y] for y in support_ys], dtype=torch.int64)
+        if base_support_ys is not None:
+            sid = torch.cat([sid, torch.from_numpy(np.asarray(base_support_ys)).long()])   # :207-209
+        query_x.append(qx.to(dev, torch.float32))
+        query_id.append(qid.to(dev))
+        net.train()                                                            # :211
+        net.augment_base_classifier_(len(novel_labels),
+                                     novel_weight=None if novel_inits is None else torch.as_tensor(novel_inits[idx]))
+        W = net.classifier.weight.data                                         # live [N, D], updated in place by the step
+        N = W.shape[0]
+        sx = support_xs.to(dev, torch.float32)
+        sid = sid.to(dev)
+        Bs, Bm = sx.shape[0], (0 if mem_x is None else mem_x.shape[0])
+        n_sets = len(query_x)
+        max_e = int(opt.max_novel_epochs)
+        ses = _Session(dev, Bs + Bm, N, D, max_e, n_sets)
+        _lib.check(lib.subreg_loop_state_init(_lib.ptr(ses.state), s()), "loop_state_init")
+        labels = sid if mem_x is None else torch.cat([sid, mem_y])
+        all_x = torch.cat([sx] + ([mem_x] if mem_x is not None else []) + query_x, 0)
+        feats = torch.empty(all_x.shape[0], D, dtype=torch.float32, device=dev)
+        q_off = [Bs + Bm + sum(q.shape[0] for q in query_x[:j]) for j in range(n_sets)]
+        d = _lib.StepDesc()
+        d.feat, d.labels = feats.data_ptr(), labels.data_ptr()
+        d.n_support, d.n_memory, d.n_classes, d.dim = Bs, Bm, N, D
+        d.weight, d.momentum_buf = W.data_ptr(), ses.mom.data_ptr()
+        d.w_base = base_weight.data_ptr()
+        use_prev = opt.lmbd_reg_novel is not None and idx > 0
+        d.w_prev = reserve.data_ptr() if use_prev else None
+        d.basis = basis.data_ptr() if basis is not None else None
+        d.n_base, d.n_prev, d.n_old = n_base, (reserve.shape[0] if use_prev else 0), n_old
+        d.lr, d.momentum, d.weight_decay = opt.learning_rate, opt.momentum, opt.weight_decay
+        d.lmbd_base = opt.lmbd_reg_transform_w or 0.0
+        d.lmbd_prev = opt.lmbd_reg_novel or 0.0
+        d.pull = opt.label_pull or 0.0
+        d.use_base_reg = int(opt.lmbd_reg_transform_w is not None)
+        d.use_prev_reg, d.use_pull = int(use_prev), int(opt.label_pull is not None)
+        d.dlogits, d.rowloss, d.rowcorrect = ses.dlogits.data_ptr(), ses.rowloss.data_ptr(), ses.rowcorrect.data_ptr()
+        d.norms, d.rowl1, d.state = ses.norms.data_ptr(), ses.rowl1.data_ptr(), ses.state.data_ptr()
+        d.losses, d.train_acc = ses.losses.data_ptr(), ses.train_acc.data_ptr()
+        opt.stable = True if opt.target_train_loss == 0 else False            # :238
+        d.max_epochs, d.min_epochs, d.stable_epochs = max_e, int(opt.min_novel_epochs), int(opt.stable_epochs)
+        d.stable_mode, d.target_loss, d.convergence_eps = int(opt.stable), opt.target_train_loss, opt.convergence_epsilon
+        fwd_per_epoch = 1 + (1 if Bm else 0) + n_sets     # forwards the reference makes per epoch (feeds DropBlock's gamma)
+
+        def step_and_validate():
+            _lib.check(lib.subreg_finetune_step(C.byref(d), s()), "finetune_step")
+            for j in range(n_sets):
+                _lib.check(lib.subreg_validate(_lib.ptr(feats[q_off[j]:]), _lib.ptr(query_id[j]), _lib.ptr(W),
+                                               query_x[j].shape[0], N, D, _lib.ptr(ses.state), _lib.ptr(ses.correct), j,
+                                               n_sets, int(j == n_sets - 1), s()), "validate")
+
+        # ---- epoch 1: TRAIN-mode support (+memory) forward (BN batch stats, running-stat update, masks), :252-258
+        hb.forward(sx, train=True, masks=net.mask_source, out=feats[:Bs])
+        if Bm:
+            hb.forward(mem_x, train=True, masks=net.mask_source, out=feats[Bs:Bs + Bm])
+        for m in net._bns:
+            m.num_batches_tracked += 1 + (1 if Bm else 0)
+        net.eval()                                                             # validate() flips the mode for good, :19
+        hb.forward(all_x[Bs + Bm:], out=feats[Bs + Bm:])
+        for i in range(len(hb.nbt)):
+            hb.nbt[i] += n_sets - 1
+        step_and_validate()
+        done, stop = 1, False
+        # ---- epochs >= 2: eval mode, one batched forward per epoch
+        while True:
+            st = ses.state.cpu()
+            done, stop = int(st[0]), bool(st[1])
+            if stop:
+                break
+            k = min(int(epochs_per_sync), max_e - done)
+            for e in range(k):
+                if not reuse_features or (done == 1 and e == 0):
+                    hb.forward(all_x, out=feats)
+                step_and_validate()
+            st = ses.state.cpu()
+            ran = int(st[0]) - done                 # epochs that really advanced the loop
+            for i in range(len(hb.nbt)):            # count forwards like the reference (wasted ones do not exist there)
+                hb.nbt[i] += ran * fwd_per_epoch - (k if not reuse_features else (1 if done == 1 else 0))
+        epochs = done
+        losses = ses.losses[:epochs].cpu().numpy().astype(np.float64)
+        correct = ses.correct.view(-1, n_sets)[epochs].cpu().numpy()
+        test_acc = [round(_acc(int(c), query_x[j].shape[0]), 2) for j, c in enumerate(correct)]   # :372
+        if opt.memory_replay:                                                  # :353-359
+            pick = memory_picks[idx] if memory_picks is not None else np.random.choice(opt.n_shots, opt.memory_replay)
+            inds = np.tile(5 * np.arange(5) + np.asarray(pick), (5, 1)) + (np.tile(np.arange(0, 125, 25), (5, 1))).T
+            inds = torch.from_numpy(inds.flatten()).to(dev)
+            run["memory_inds"].append(inds.cpu().numpy())
+            mem_x = sx[inds] if mem_x is None else torch.cat((mem_x, sx[inds]), 0)
+            mem_y = sid[inds] if mem_y is None else torch.cat((mem_y, sid[inds]), 0)
+        acc_base_ = eval_base()                                                # :363-367
+        p("Novel session accuracies: ", test_acc)
+        ta = float(np.array(test_acc).mean())
+        w1 = 60 if opt.dataset == "miniImageNet" else 200                      # :383
+        w2 = len(vocab_base) + len(vocab_novel) - 60
+        weighted_avg = (w1 * acc_base_ + w2 * ta) / (w1 + w2)
+        weighted_avg_l.append(round(weighted_avg, 2))
+        acc_novel_list.append(round(ta, 2))
+        acc_base_list.append(round(acc_base_, 2))
+        novel_vals.append(ta)
+        base_vals.append(acc_base_)
+        p("***Running weighted avg: {}".format(weighted_avg))
+        run["loss"].append(losses)
+        run["test_acc"].append(test_acc)
+        run["epochs"].append(epochs)
+        run["train_acc"].append(ses.train_acc[:epochs].cpu().numpy())
+    run.update(weighted_avg=weighted_avg_l, novel_acc=acc_novel_list, acc_base=acc_base_list,
+               classifier_weight=net.classifier.weight.detach().cpu().numpy(), basis_info=basis_info)
+    net.last_run = run
+    p("Overall continual accuracies: ", weighted_avg_l)
+    p("Novel only incremental: ", acc_novel_list)
+    p("Base only incremental: ", acc_base_list)
+    return float(np.mean(novel_vals)), float(np.mean(base_vals))

@@ -1,0 +1,275 @@
+"""GPU parity tests: the hand-written gfx950 kernels, called THROUGH THE C ABI, against the CPU oracle
+(same seeded inputs) and against the golden vectors produced by the reference itself.
+
+Tolerances (written here on purpose):
+  f32 path  (v_mfma_f32_32x32x2_f32, the parity mode): 2e-4 abs+rel on activations/features, the
+            north_star's 1e-4 on classifier weights and accuracies.
+  bf16 path (throughput mode): operands are rounded to 8 bits of mantissa => 3e-2 relative to the tensor's
+            max; it is gated on argmax/accuracy level elsewhere.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import resnet_ref as rr                       # noqa: E402  (the checker)
+from oracle import subspace_ref as sr                     # noqa: E402
+from subreg_hip import _lib, synthetic as syn             # noqa: E402
+
+from conftest import GOLDEN                               # noqa: E402
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def _t(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(_dev(), dtype)
+
+
+def _cmp(name, got, want, atol, rtol):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    err = np.abs(got - want)
+    bad = err > atol + rtol * np.abs(want)
+    if bad.any():
+        i = np.unravel_index(np.argmax(err), err.shape)
+        raise AssertionError("%s: %d/%d bad, max err %.4g at %s (got %.6g want %.6g), ref max %.4g" %
+                             (name, bad.sum(), bad.size, err.max(), i, got[i], want[i], np.abs(want).max()))
+
+
+def _tol(dtype, scale=1.0, bf16=1e-2):
+    """(atol, rtol): f32 2e-4; bf16 `bf16` of the tensor's magnitude (1e-2 one conv, 3e-2 whole backbone)."""
+    return (2e-4 * max(scale, 1.0), 2e-4) if dtype == "f32" else (bf16 * scale, bf16)
+
+
+def _nhwc_dev(x_nchw, dtype):
+    """NCHW fp32 numpy -> device NHWC tensor in the compute dtype through the library's own kernel."""
+    lib = _lib.load()
+    B, Cc, H, W = x_nchw.shape
+    src = _t(x_nchw)
+    dst = torch.empty(B * H * W * Cc, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32, device=_dev())
+    _lib.check(lib.subreg_nchw_to_nhwc(_lib.ptr(src), _lib.ptr(dst), B, Cc, H, W, _lib.dtype_code(dtype), _lib.stream_ptr()))
+    return dst
+
+
+def _nchw_host(t, B, Cc, H, W, dtype):
+    lib = _lib.load()
+    out = torch.empty(B, Cc, H, W, dtype=torch.float32, device=_dev())
+    _lib.check(lib.subreg_nhwc_to_nchw(_lib.ptr(t), _lib.ptr(out), B, Cc, H, W, _lib.dtype_code(dtype), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _pack_w(w_oihw, dtype):
+    lib = _lib.load()
+    O, I, k, _ = w_oihw.shape
+    out = torch.empty(O * k * k * I, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32, device=_dev())
+    _lib.check(lib.subreg_pack_conv_weight(_lib.ptr(_t(w_oihw)), _lib.ptr(out), O, I, k, 0, _lib.dtype_code(dtype),
+                                           _lib.stream_ptr()))
+    return out
+
+
+def _round_bf16(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, pool, residual      (shapes of the 14 unique convs, SURVEY.md 8a-3, + ragged/edge ones)
+    (2, 84, 84, 64, 64, 3, False, False),
+    (1, 84, 84, 64, 64, 3, True, True),
+    (2, 42, 42, 64, 160, 3, False, False),
+    (2, 42, 42, 160, 160, 3, True, True),
+    (2, 42, 42, 64, 160, 1, False, False),
+    (3, 21, 21, 160, 320, 3, False, False),
+    (3, 21, 21, 320, 320, 3, True, True),          # 21 -> 10 floor pooling drops the last row/col
+    (2, 21, 21, 160, 320, 1, False, False),
+    (5, 10, 10, 320, 320, 3, False, True),         # identity shortcut, no pool (layer3.1)
+    (5, 10, 10, 320, 640, 3, False, False),
+    (5, 10, 10, 640, 640, 3, True, True),
+    (4, 10, 10, 320, 640, 1, False, False),
+    (7, 5, 5, 640, 640, 3, False, True),
+    (1, 5, 7, 32, 96, 3, False, False),            # non-square, Cout not a multiple of 64/160 (N tail), tiny M
+    (1, 6, 6, 32, 32, 3, True, False),
+    (3, 9, 4, 64, 64, 1, True, True),
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "B%d_%dx%d_%d-%d_k%d_p%d_r%d" % tuple(int(v) for v in c))
+def test_conv_fwd_epilogue(case, dtype):
+    B, H, W, Cin, Cout, k, pool, use_res = case
+    lib = _lib.load()
+    rs = np.random.RandomState(hash(case) % (2 ** 31))
+    x = rs.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rs.standard_normal((Cout, Cin, k, k)) * (1.4 / np.sqrt(Cin * k * k))).astype(np.float32)
+    scale = rs.uniform(0.5, 1.5, Cout).astype(np.float32) * rs.choice([-1, 1], Cout).astype(np.float32)
+    shift = (rs.standard_normal(Cout) * 0.3).astype(np.float32)
+    res = rs.standard_normal((B, Cout, H, W)).astype(np.float32) if use_res else None
+    if dtype == "bf16":            # the oracle sees the same rounded operands; accumulation stays wide on both sides
+        x, w = _round_bf16(x), _round_bf16(w)
+        res = _round_bf16(res) if use_res else None
+    want = rr.conv_nhwc(rr._nhwc(x).astype(np.float64), w.astype(np.float64)) * scale + shift
+    if use_res:
+        want = want + rr._nhwc(res)
+    want = rr.maxpool_nhwc(rr.leaky_relu(want), 2 if pool else 1)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.full((B * Ho * Wo * Cout,), float("nan"), dtype=torch.bfloat16 if dtype == "bf16" else torch.float32, device=_dev())
+    flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0)
+    rd = _nhwc_dev(res, dtype) if use_res else None
+    _lib.check(lib.subreg_conv_fwd(_lib.ptr(_nhwc_dev(x, dtype)), _lib.ptr(_pack_w(w, dtype)), _lib.ptr(y), _lib.ptr(_t(scale)),
+                                   _lib.ptr(_t(shift)), _lib.ptr(rd), None, B, H, W, Cin, Cout, k, flags,
+                                   _lib.dtype_code(dtype), _lib.stream_ptr()), "conv_fwd")
+    got = _nchw_host(y, B, Cout, Ho, Wo, dtype)
+    a, r = _tol(dtype, np.abs(want).max())
+    _cmp("conv", got, rr._nchw(want), a, r)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(3, 21, 21, 160, 320, 3), (2, 42, 42, 64, 160, 1), (5, 5, 5, 640, 640, 3)])
+def test_conv_raw_stats_and_bn_train(shape, dtype):
+    """Train-mode path: raw conv + partial sums -> finalize -> batch scale/shift and running-stat update."""
+    B, H, W, Cin, Cout, k = shape
+    lib = _lib.load()
+    rs = np.random.RandomState(7)
+    x = rs.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rs.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    if dtype == "bf16":
+        x, w = _round_bf16(x), _round_bf16(w)
+    gw, gb = rs.uniform(0.5, 1.5, Cout).astype(np.float32), (rs.standard_normal(Cout) * 0.1).astype(np.float32)
+    rm, rv = (rs.standard_normal(Cout) * 0.1).astype(np.float32), rs.uniform(0.5, 1.5, Cout).astype(np.float32)
+    raw = rr.conv_nhwc(rr._nhwc(x).astype(np.float64), w.astype(np.float64))
+    want, wrm, wrv = rr.bn_train_nhwc(raw, gw, gb, rm, rv)
+    want = rr.leaky_relu(want)
+    dt = _lib.dtype_code(dtype)
+    rows = lib.subreg_conv_stats_rows(dt, B, H, W, Cout)
+    stats = torch.zeros(rows * Cout * 2, dtype=torch.float32, device=_dev())
+    y = torch.empty(B * H * W * Cout, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32, device=_dev())
+    _lib.check(lib.subreg_conv_fwd(_lib.ptr(_nhwc_dev(x, dtype)), _lib.ptr(_pack_w(w, dtype)), _lib.ptr(y), None, None, None,
+                                   _lib.ptr(stats), B, H, W, Cin, Cout, k, _lib.CONV_RAW_STATS, dt, _lib.stream_ptr()))
+    drm, drv = _t(rm), _t(rv)
+    sc, sh = torch.empty(Cout, device=_dev()), torch.empty(Cout, device=_dev())
+    _lib.check(lib.subreg_bn_train_finalize(_lib.ptr(stats), rows, Cout, B * H * W, _lib.ptr(_t(gw)), _lib.ptr(_t(gb)),
+                                            _lib.ptr(drm), _lib.ptr(drv), 0.1, 1e-5, _lib.ptr(sc), _lib.ptr(sh),
+                                            _lib.stream_ptr()))
+    _lib.check(lib.subreg_bn_apply(_lib.ptr(y), _lib.ptr(sc), _lib.ptr(sh), None, None, None, None, 1.0, _lib.ptr(y), B, H, W,
+                                   Cout, _lib.CONV_LRELU, dt, _lib.stream_ptr()))
+    got = _nchw_host(y, B, Cout, H, W, dtype)
+    a, r = _tol(dtype, np.abs(want).max())
+    _cmp("bn-train out", got, rr._nchw(want), a, r)
+    _cmp("running_mean", drm.cpu().numpy(), wrm, 1e-5 if dtype == "f32" else 2e-3, 1e-4)
+    _cmp("running_var", drv.cpu().numpy(), wrv, 1e-5 if dtype == "f32" else 2e-3, 1e-4 if dtype == "f32" else 1e-2)
+
+
+# ---------------------------------------------------------------- backbone against the reference's golden vectors
+def _params_from_sd(sd):
+    return {k: _t(v) for k, v in sd.items() if v.dtype != np.int64}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("hw", [32, 84])
+def test_backbone_golden(hw, dtype):
+    from subreg_hip.backbone import HipBackbone
+    g = np.load(os.path.join(GOLDEN, "backbone.npz"))
+    sd = syn.make_state_dict(21)
+    params = _params_from_sd(sd)
+    hb = HipBackbone(params, (1, 1, 2, 2), dtype, block_size=1)
+    x = _t(syn.make_images(31, 4, hw))
+    feat, stages = hb.forward(x, return_stages=True)
+    torch.cuda.synchronize()
+    a, r = _tol(dtype, float(np.abs(g["hw%d.eval_feat" % hw]).max()), bf16=3e-2)
+    _cmp("stage1 img0", stages[0][0].cpu().numpy(), g["hw%d.eval_f0_b0" % hw], a, r)
+    _cmp("feat", feat.cpu().numpy(), g["hw%d.eval_feat" % hw], a, r)
+    logits = feat.cpu().numpy() @ sd["classifier.weight"].T
+    _cmp("logits", logits, g["hw%d.eval_logits" % hw], a, r)
+    # train-mode forward with the same injected masks as the reference run
+    feat_t = hb.forward(x, train=True, masks=rr.MaskSource(41))
+    torch.cuda.synchronize()
+    _cmp("train logits", feat_t.cpu().numpy() @ sd["classifier.weight"].T, g["hw%d.train_logits" % hw],
+         5e-4 if dtype == "f32" else a, 5e-4 if dtype == "f32" else r)
+    for k in ("layer1.0.bn1", "layer2.0.downsample.1", "layer3.1.bn2", "layer4.1.bn3"):
+        _cmp(k + ".running_mean", params[k + ".running_mean"].cpu().numpy(), g["hw%d.%s.running_mean" % (hw, k)],
+             1e-5 if dtype == "f32" else 3e-3, 1e-4 if dtype == "f32" else 1e-2)
+        _cmp(k + ".running_var", params[k + ".running_var"].cpu().numpy(), g["hw%d.%s.running_var" % (hw, k)],
+             1e-5 if dtype == "f32" else 3e-3, 1e-4 if dtype == "f32" else 2e-2)
+    feat2 = hb.forward(x)
+    torch.cuda.synchronize()
+    _cmp("eval after stats moved", feat2.cpu().numpy() @ sd["classifier.weight"].T, g["hw%d.eval2_logits" % hw],
+         5e-4 if dtype == "f32" else a, 5e-4 if dtype == "f32" else r)
+
+
+def test_backbone_matches_oracle_dropblock5():
+    """block_size 5 (no --no_dropblock): host-prepared block masks with the reference's pairing quirk."""
+    from subreg_hip.backbone import HipBackbone
+    sd = syn.make_state_dict(5)
+    ref_sd = rr.copy_state_dict(sd)
+    hb = HipBackbone(_params_from_sd(sd), (1, 1, 2, 2), "f32", block_size=5)
+    onet = rr.ResNetRef(ref_sd, block_size=5)
+    hb.nbt = [39999] * 6
+    for k in onet.nbt:
+        onet.nbt[k] = 39999
+    x = syn.make_images(3, 6, 84)
+    onet.train()
+    want = onet.features(x, rr.MaskSource(9))
+    got = hb.forward(_t(x), train=True, masks=rr.MaskSource(9))
+    torch.cuda.synchronize()
+    _cmp("dropblock5 train feat", got.cpu().numpy(), want, 5e-4, 5e-4)
+
+
+# ---------------------------------------------------------------- classifier / regularizers against the goldens
+@pytest.mark.parametrize("case", ["rand.k5", "rand.k40", "trained.k5", "trained.k40"])
+def test_subspace_kernels_golden(case):
+    from subreg_hip import functional as HF
+    g = np.load(os.path.join(GOLDEN, "reg.npz"))
+    wb, w = _t(g[case + ".w_base"]), _t(g[case + ".w"]).requires_grad_(True)
+    q, info = HF.subspace_basis(wb)
+    assert int(info.item()) == 0
+    qq = q.cpu().numpy().astype(np.float64)
+    _cmp("orthonormal", qq @ qq.T, np.eye(qq.shape[0]), 1e-6, 0)
+    P = HF.SubspaceProjectFn.apply(w, q)
+    _cmp("P", P.detach().cpu().numpy(), g[case + ".P"], 1e-6, 1e-5)
+    loss = HF.SqDiffFn.apply(P, w, 0.7)
+    loss.backward()
+    _cmp("loss1", loss.item(), g[case + ".loss1"], 1e-6, 1e-5)
+    _cmp("grad", w.grad.cpu().numpy(), g[case + ".grad"], 1e-6, 1e-5)
+
+
+def test_frob_kernels_golden():
+    from subreg_hip import functional as HF
+    g = np.load(os.path.join(GOLDEN, "reg.npz"))
+    W = _t(g["frob.W"]).requires_grad_(True)
+    l0 = HF.FrobFn.apply(W[:60], _t(g["frob.base"]), 0.2)
+    l0.backward()
+    assert l0.item() == 0.0 and not W.grad.cpu().numpy().any()          # zero sub-gradient at 0
+    W2 = _t(g["frob.W2"]).requires_grad_(True)
+    l1 = HF.FrobFn.apply(W2[:60], _t(g["frob.base"]), 0.2) + HF.FrobFn.apply(W2[60:70], _t(g["frob.prev"]), 0.1)
+    l1.backward()
+    _cmp("loss", l1.item(), g["frob.loss"], 1e-6, 1e-5)
+    _cmp("grad", W2.grad.cpu().numpy(), g["frob.grad"], 1e-7, 1e-5)
+
+
+def test_linear_fwd_bwd():
+    from subreg_hip import functional as HF
+    rs = np.random.RandomState(3)
+    f, w, b = rs.standard_normal((37, 640)).astype(np.float32), rs.standard_normal((65, 640)).astype(np.float32) * 0.05, \
+        rs.standard_normal(65).astype(np.float32)
+    ft, wt, bt = _t(f).requires_grad_(True), _t(w).requires_grad_(True), _t(b).requires_grad_(True)
+    out = HF.LinearFn.apply(ft, wt, bt)
+    go = rs.standard_normal((37, 65)).astype(np.float32)
+    out.backward(_t(go))
+    _cmp("logits", out.detach().cpu().numpy(), f.astype(np.float64) @ w.T + b, 1e-5, 1e-5)
+    _cmp("dW", wt.grad.cpu().numpy(), go.T.astype(np.float64) @ f, 1e-4, 1e-5)
+    _cmp("db", bt.grad.cpu().numpy(), go.sum(0), 1e-5, 1e-5)
+    _cmp("dfeat", ft.grad.cpu().numpy(), go.astype(np.float64) @ w, 1e-5, 1e-5)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsubreg_hip.so")
+    with pytest.raises(RuntimeError):
+        _lib.load()

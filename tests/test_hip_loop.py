@@ -1,0 +1,167 @@
+"""GPU parity of the whole incremental loop against the goldens produced by the reference loop itself
+(eval/language_eval.py::few_shot_finetune_incremental_test run on CPU by tools/make_golden.py).
+
+f32 mode: per-epoch losses, per-session accuracies, stop epochs and the learned classifier rows must match
+the reference within the north_star's fp32 tolerance (1e-4 on weights; losses ~5 => 2e-4 abs+rel).
+bf16 mode: accuracy-level gate (per-session accuracy within +-1 query image = 0.8 points at these tiny
+query sets; the north_star's +-0.1 % is for the 10-seed average) and 5e-3 on weights.
+The module-surface test drives the REFERENCE's own loop body (net(x), criterion, regloss, LangPuller,
+torch SGD) over the drop-in modules and checks it against the fused loop.
+"""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle.resnet_ref import MaskSource                                  # noqa: E402
+from subreg_hip import synthetic as syn                                   # noqa: E402
+
+from conftest import GOLDEN                                               # noqa: E402
+from test_hip_kernels import _cmp                                         # noqa: E402
+
+
+class _Loader(list):
+    def __init__(self, items, label2human):
+        super().__init__(items)
+        self.dataset = SimpleNamespace(label2human=label2human)
+
+
+def make_opt(**kw):
+    o = SimpleNamespace(no_dropblock=True, linear_bias=False, temperature=1, word_embed_size=500,
+                        word_embed_path="word_embeds", dataset="miniImageNet", use_synonyms=False, glove=False,
+                        track_weights=False, track_label_inspired_weights=False, save_preds_0=False, set_seed=1,
+                        memory_replay=0, neval_episodes=8, continual=False, n_ways=5, n_shots=5, n_queries=25,
+                        label_pull=1.0, pulling="regularize", attraction_override="distance2subspace",
+                        classifier="linear", attention=None, lmbd_reg_transform_w=0.2, lmbd_reg_novel=0.1,
+                        target_train_loss=0.0, convergence_epsilon=1e-4, stable_epochs=10, max_novel_epochs=1000,
+                        min_novel_epochs=20, learning_rate=0.002, momentum=0.9, weight_decay=5e-4, adam=False,
+                        freeze_backbone_at=1, hip_dtype="f32")
+    o.__dict__.update(kw)
+    return o
+
+
+def build_case(g, dtype):
+    """Model + loaders of a loop golden (inputs regenerated from seeds, BN stats / classifier from the fixture)."""
+    from subreg_hip.resnet_language import create_model
+    hw, ns, seed = int(g["hw"]), int(g["n_sessions"]), int(g["seed"])
+    signal, memory = float(g["signal"]), bool(int(g["memory"]))
+    kw = {k[4:]: g[k].item() for k in g.files if k.startswith("opt.")}
+    opt = make_opt(set_seed=seed, neval_episodes=ns, memory_replay=1 if memory else 0, hip_dtype=dtype, **kw)
+    sd = syn.make_state_dict(int(g["sd_seed"]))
+    for k in g.files:
+        if k.startswith("bn0."):
+            sd[k[4:]] = g[k].copy()
+    sd["classifier.weight"] = g["base_classifier"].copy()
+    net = create_model("resnet18", 60, opt)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    net = net.cuda()
+    net.mask_source = MaskSource(int(g["mask_seed"]))
+    sessions = syn.make_sessions(seed, ns, hw, class_signal=signal)
+    bx, by = syn.make_base_batch(seed, int(g["n_base_batch"]), hw, class_signal=signal)
+    names_base = ["b%d" % i for i in range(60)] + [""] * 40
+    names_novel = ["n%d" % i for i in range(100)]
+    base_loader = _Loader([(torch.from_numpy(bx), torch.from_numpy(by), torch.arange(len(by)))], names_base)
+    meta = _Loader([(torch.from_numpy(s["support_xs"])[None], torch.from_numpy(s["support_ys"])[None],
+                     torch.from_numpy(s["query_xs"])[None], torch.from_numpy(s["query_ys"])[None]) for s in sessions],
+                   names_novel)
+    bsl = None
+    if memory:
+        sx, sy = syn.make_base_support(seed, hw, class_signal=signal)
+        bsl = _Loader([(torch.from_numpy(sx)[None], torch.from_numpy(sy)[None], torch.zeros(1, 1, 3, hw, hw),
+                        torch.zeros(1, 1, dtype=torch.long))], names_base)
+    inits = syn.make_novel_inits(seed, ns)
+    picks = [p for p in g["picks"]]
+    return net, opt, meta, base_loader, bsl, inits, picks
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw84_M"])
+def test_fused_loop_against_reference_golden(tag, dtype):
+    from subreg_hip.incremental import few_shot_finetune_incremental_test
+    g = np.load(os.path.join(GOLDEN, "loop_%s.npz" % tag))
+    net, opt, meta, base_loader, bsl, inits, picks = build_case(g, dtype)
+    novel_avg, base_avg = few_shot_finetune_incremental_test(net, {}, None, meta, base_loader, opt, base_support_loader=bsl,
+                                                             novel_inits=inits, memory_picks=picks, epochs_per_sync=4,
+                                                             verbose=False)
+    run = net.last_run
+    ns = int(g["n_sessions"])
+    f32 = dtype == "f32"
+    for s in range(ns):
+        if f32:
+            assert run["epochs"][s] == int(g["s%d.epochs" % s]), (tag, s, run["epochs"], int(g["s%d.epochs" % s]))
+            _cmp("loss s%d" % s, run["loss"][s], g["s%d.loss" % s], 2e-4, 2e-4)
+            _cmp("val acc s%d" % s, run["test_acc"][s], np.round(g["s%d.last_val" % s], 2), 1e-6, 0)
+        else:
+            if run["epochs"][s] == int(g["s%d.epochs" % s]):
+                _cmp("loss s%d" % s, run["loss"][s], g["s%d.loss" % s], 5e-2, 2e-2)
+                _cmp("val acc s%d" % s, run["test_acc"][s], np.round(g["s%d.last_val" % s], 2), 0.81, 0)
+    if f32 or all(run["epochs"][s] == int(g["s%d.epochs" % s]) for s in range(ns)):
+        _cmp("final classifier", run["classifier_weight"], g["final_classifier"], 1e-4 if f32 else 5e-3, 1e-4 if f32 else 5e-3)
+    if f32:
+        _cmp("novel avg", novel_avg, g["novel_avg"], 1e-5, 1e-6)
+        _cmp("base avg", base_avg, g["base_avg"], 1e-5, 1e-6)
+        sd = net.state_dict()
+        for k in ("layer1.0.bn1", "layer4.1.bn3"):
+            _cmp(k + ".running_mean", sd[k + ".running_mean"].cpu().numpy(), g[k + ".running_mean"], 1e-5, 1e-4)
+            _cmp(k + ".running_var", sd[k + ".running_var"].cpu().numpy(), g[k + ".running_var"], 1e-5, 1e-4)
+
+
+def test_feature_reuse_is_results_identical():
+    """The opt-in frozen-feature reuse must not change a single result (it only skips constant recomputation)."""
+    from subreg_hip.incremental import few_shot_finetune_incremental_test
+    g = np.load(os.path.join(GOLDEN, "loop_hw32_M.npz"))
+    outs = []
+    for reuse in (False, True):
+        net, opt, meta, base_loader, bsl, inits, picks = build_case(g, "f32")
+        few_shot_finetune_incremental_test(net, {}, None, meta, base_loader, opt, base_support_loader=bsl, novel_inits=inits,
+                                           memory_picks=picks, reuse_features=reuse, verbose=False)
+        outs.append(net.last_run)
+    assert outs[0]["epochs"] == outs[1]["epochs"] and outs[0]["test_acc"] == outs[1]["test_acc"]
+    assert np.array_equal(outs[0]["classifier_weight"], outs[1]["classifier_weight"])
+
+
+def test_module_surface_runs_reference_loop_body():
+    """The drop-in modules under the reference's own loop statements (language_eval.py:242-326), torch autograd + SGD,
+    give the same numbers as the fused loop: 1 session, 4 epochs."""
+    from subreg_hip.incremental import few_shot_finetune_incremental_test
+    from subreg_hip.resnet_language import LangPuller
+    g = np.load(os.path.join(GOLDEN, "loop_hw32_noM.npz"))
+    net, opt, meta, base_loader, bsl, inits, picks = build_case(g, "f32")
+    criterion = torch.nn.CrossEntropyLoss()
+    base_weight, base_bias = net._get_base_weights()
+    sx, sy, qx, qy = meta[0]
+    support_xs, query_xs = sx[0].cuda(), qx[0].cuda()
+    ids = {int(c): 60 + r for r, c in enumerate(np.sort(np.unique(qy[0].numpy())))}
+    support_ys_id = torch.tensor([ids[int(y)] for y in sy[0]]).cuda()
+    query_ys_id = torch.tensor([ids[int(y)] for y in qy[0]]).cuda()
+    net.eval()
+    with torch.no_grad():
+        net(torch.from_numpy(syn.make_base_batch(int(g["seed"]), int(g["n_base_batch"]), int(g["hw"]),
+                                                 class_signal=float(g["signal"]))[0]).cuda())   # eval_base forward (:128)
+    net.train()
+    net.augment_base_classifier_(5, novel_weight=torch.from_numpy(inits[0]))
+    puller = LangPuller(opt, ["b"] * 60, ["n"] * 5)
+    for name, prm in net.named_parameters():                  # freeze_backbone_weights (eval/util.py:62-69)
+        prm.requires_grad = name.startswith("classifier")
+    optimizer = torch.optim.SGD(net.parameters(), lr=opt.learning_rate, momentum=opt.momentum, weight_decay=opt.weight_decay)
+    losses, accs = [], []
+    for epoch in range(1, 5):
+        output = net(support_xs)
+        loss = criterion(output, support_ys_id)
+        loss = loss + net.regloss(opt.lmbd_reg_transform_w, base_weight, base_bias)
+        pullers = puller.get_projected_weight(base_weight, net.classifier.weight[60:, :])
+        loss = loss + puller.loss1(opt.label_pull, pullers, net.classifier.weight[60:, :])
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        losses.append(loss.item())
+        net.eval()
+        with torch.no_grad():
+            out = net(query_xs)
+            accs.append((out.argmax(1) == query_ys_id).float().sum().item() * (100.0 / len(query_ys_id)))
+    _cmp("module-surface loss", losses, g["s0.loss"], 2e-4, 2e-4)
+    _cmp("module-surface acc", round(accs[-1], 2), np.round(g["s0.last_val"], 2)[0], 1e-6, 0)

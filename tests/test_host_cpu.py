@@ -1,0 +1,108 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/subreg_hip.h declares, the
+ctypes structs match the C layout, the host-side tiling/index logic of the conv kernel is right, and the product
+package never imports the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from subreg_hip import _lib, synthetic as syn
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "subreg_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(subreg_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return ctypes.CDLL(_lib.LIB_PATH)
+
+
+def test_header_symbols_exported_and_bound(built):
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(built, name), "libsubreg_hip.so does not export %s" % name
+    assert sorted(_lib.SIGNATURES) == declared, set(declared) ^ set(_lib.SIGNATURES)
+
+
+def test_abi_version_and_strerror(built):
+    built.subreg_abi_version.restype = ctypes.c_int
+    assert built.subreg_abi_version() == _lib.ABI_VERSION
+    built.subreg_strerror.restype = ctypes.c_char_p
+    assert b"invalid" in built.subreg_strerror(-1)
+
+
+def test_bad_arguments_return_einval_without_gpu(built):
+    # argument validation happens before any HIP call, so it is testable on a CPU-only box
+    built.subreg_conv_fwd.restype = ctypes.c_int
+    rc = built.subreg_conv_fwd(None, None, None, None, None, None, None, 1, 8, 8, 32, 32, 3, 0, 0, None)
+    assert rc == -1
+    built.subreg_subspace_basis.restype = ctypes.c_int
+    assert built.subreg_subspace_basis(None, None, None, 60, 640, None, None) == -1
+
+
+def test_struct_layouts_match_c():
+    # sizes computed by hand from include/subreg_hip.h on LP64
+    assert ctypes.sizeof(_lib.ConvDesc) == 7 * 8 + 3 * 4 + 4
+    assert ctypes.sizeof(_lib.LoopState) == 20
+    assert ctypes.sizeof(_lib.BlockDesc) == 4 * ctypes.sizeof(_lib.ConvDesc) + 8 + 8 + 8
+    assert _lib.StepDesc.weight.offset == 32 and _lib.StepDesc.n_base.offset == 72
+
+
+def test_conv_tiling_index_emulation():
+    exe = os.path.join(REPO, "tests", "csrc", "conv_index_test")
+    subprocess.run(["g++", "-O2", "-std=c++17", exe + ".cpp", "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-2000:]
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(REPO, "subspace-reg_amd", "subreg_hip")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+
+
+def test_compute_entry_points_fail_loudly_without_gpu():
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from subreg_hip.resnet_language import create_model
+    from types import SimpleNamespace
+    net = create_model("resnet18", 60, SimpleNamespace(no_dropblock=True, linear_bias=False))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 84, 84))
+
+
+def test_module_state_dict_keys_match_reference():
+    torch = pytest.importorskip("torch")
+    from subreg_hip.resnet_language import create_model
+    from types import SimpleNamespace
+    net = create_model("resnet18", 60, SimpleNamespace(no_dropblock=True, linear_bias=False))
+    sd = syn.make_state_dict(1)
+    assert sorted(net.state_dict().keys()) == sorted(sd.keys()) and len(sd) == 133
+    for k, v in net.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    net.augment_base_classifier_(5)
+    assert net.classifier.weight.shape == (65, 640) and net.num_classes == 60
+    names = [n for n, _ in net.named_parameters() if n.startswith("classifier")]
+    assert names == ["classifier.weight"]
+
+
+def test_synthetic_episode_layout():
+    sy, qy = syn.session_labels(2)
+    assert sy.shape == (125,) and qy.shape == (125,) and set(sy) == set(range(70, 75))
+    assert list(sy[:10]) == [70] * 5 + [71] * 5 and list(qy[:26]) == [70] * 25 + [71]
+    from oracle.resnet_ref import conv_flops_per_image
+    assert abs(conv_flops_per_image(84) / 8.1219e9 - 1) < 1e-3

@@ -1,0 +1,178 @@
+"""Pin the CPU oracle against the golden vectors produced by the reference itself.
+
+The fixtures under tests/golden/ were written by tools/make_golden.py, which
+imports /root/reference (PyTorch CPU) in the build container.  These tests run
+without a GPU and without the reference.
+Tolerance: the path is fp32; north_star asks for 1e-4 on weights/accuracies.  The
+oracle differs from torch only in summation order, so block outputs (|x| ~ 1..10)
+are held to 2e-4 absolute+relative and the regularizer/loop scalars tighter.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import loop_ref, subspace_ref as sr
+from oracle.resnet_ref import MaskSource, ResNetRef, _nchw, _nhwc, block_specs, copy_state_dict
+from subreg_hip import synthetic as syn
+
+from conftest import GOLDEN
+
+ATOL = RTOL = 2e-4
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def _close(a, b, atol=ATOL, rtol=RTOL, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err = np.abs(a - b) - (atol + rtol * np.abs(b))
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert err.max() <= 0, "%s: max abs diff %.3e (ref max %.3e)" % (what, np.abs(a - b).max(), np.abs(b).max())
+
+
+# ---------------------------------------------------------------- G1 blocks
+@pytest.mark.parametrize("spec", block_specs(), ids=lambda s: s["name"])
+def test_block_eval_and_train(spec):
+    g = _load("blocks.npz")
+    name = spec["name"]
+    li = [s["name"] for s in block_specs()].index(name)
+    for bs_name, bs in (("bs1", 1), ("bs5", 5)):
+        key = "%s.%s" % (name, bs_name)
+        if key + ".in_shape" not in g:
+            continue
+        x = np.random.RandomState(int(g[key + ".in_seed"])).standard_normal(tuple(g[key + ".in_shape"])).astype(np.float32)
+        sd = syn.make_state_dict(11)
+        net = ResNetRef(sd, block_size=bs)
+        if bs_name == "bs1":
+            net.eval()
+            y = _nchw(net.block_forward(_nhwc(x), spec))
+            _close(y, g[key + ".eval_out"], what=key + " eval")
+        net.train()
+        net.nbt[name] = 39999
+        y = _nchw(net.block_forward(_nhwc(x), spec, MaskSource(int(g[key + ".mask_seed"]))))
+        _close(y, g[key + ".train_out"], what=key + " train")
+        for bn in ("bn1", "bn2", "bn3") + (("downsample.1",) if spec["downsample"] else ()):
+            _close(sd["%s.%s.running_mean" % (name, bn)], g["%s.%s.running_mean" % (key, bn)], 1e-5, 1e-5, key + bn)
+            _close(sd["%s.%s.running_var" % (name, bn)], g["%s.%s.running_var" % (key, bn)], 1e-5, 1e-5, key + bn)
+
+
+def test_dropblock_mask_matches_reference_semantics():
+    # one seed blanks a bs x bs block anchored at the seed index (resnet_language.py:327-357) ...
+    from oracle.resnet_ref import dropblock_block_mask
+    s = np.zeros((1, 1, 6, 6), np.float32)
+    s[0, 0, 2, 3] = 1
+    bm = dropblock_block_mask(s, 5)
+    assert bm.shape == (1, 1, 10, 10)
+    assert bm[0, 0, 2:7, 3:8].sum() == 0 and bm.sum() == 100 - 25
+    # ... but with gcd(n, bs^2) = 5 the reference's repeat/tile pairing gives each seed only 5 of 25 offsets
+    s = np.zeros((5, 1, 1, 1), np.float32)
+    s[:, 0, 0, 0] = 1
+    bm = dropblock_block_mask(s, 5)
+    assert bm.shape == (5, 1, 5, 5)
+    for r in range(5):
+        dropped = {(int(i), int(j)) for i, j in np.argwhere(bm[r, 0] == 0)}
+        # column r from the paired offsets + the seed itself, which F.pad leaves at the padded centre (2,2)
+        assert dropped == {(i, r) for i in range(5)} | {(2, 2)}
+
+
+# ---------------------------------------------------------------- G2 backbone
+@pytest.mark.parametrize("hw", [32, 84])
+def test_backbone(hw):
+    g = _load("backbone.npz")
+    sd = syn.make_state_dict(21)
+    net = ResNetRef(sd)
+    x = syn.make_images(31, 4, hw)
+    net.eval()
+    feat, stages = net.features(x, return_stages=True)
+    _close(_nchw(stages[0])[0], g["hw%d.eval_f0_b0" % hw], what="stage1")
+    _close(feat, g["hw%d.eval_feat" % hw], what="feat")
+    from oracle.resnet_ref import linear
+    _close(linear(feat, sd["classifier.weight"]), g["hw%d.eval_logits" % hw], what="logits")
+    net.train()
+    _close(net.forward(x, MaskSource(41)), g["hw%d.train_logits" % hw], 5e-4, 5e-4, what="train logits")
+    for k in ("layer1.0.bn1", "layer2.0.downsample.1", "layer3.1.bn2", "layer4.1.bn3"):
+        _close(sd[k + ".running_mean"], g["hw%d.%s.running_mean" % (hw, k)], 1e-5, 1e-4, k)
+        _close(sd[k + ".running_var"], g["hw%d.%s.running_var" % (hw, k)], 1e-5, 1e-4, k)
+    net.eval()
+    _close(net.forward(x), g["hw%d.eval2_logits" % hw], 5e-4, 5e-4, what="eval after stats moved")
+
+
+# ---------------------------------------------------------------- G3 regularizers
+@pytest.mark.parametrize("case", ["rand.k5", "rand.k40", "trained.k5", "trained.k40"])
+def test_subspace_projection_loss_grad(case):
+    g = _load("reg.npz")
+    wb, w = g[case + ".w_base"], g[case + ".w"]
+    _close(sr.get_projected_weight(wb, w), g[case + ".P"], 1e-6, 1e-5, "P")
+    loss, grad = sr.loss1_and_grad(0.7, wb, w)
+    _close(loss, g[case + ".loss1"], 1e-6, 1e-5, "loss1")
+    _close(grad, g[case + ".grad"], 1e-6, 1e-5, "grad")
+    # closed form of SURVEY.md section 0 item 4: grad = 2*gamma*(w - w Q Q^T)
+    q = sr.orthonormal_basis(wb)
+    _close(2 * 0.7 * (w - w @ q @ q.T), g[case + ".grad"], 1e-6, 1e-5, "closed form")
+
+
+def test_frobenius_regs_and_zero_subgradient():
+    g = _load("reg.npz")
+    l0, g0 = sr.frob_reg_and_grad(0.2, g["frob.W"][:60], g["frob.base"])
+    assert l0 == 0.0 and float(g["frob.regloss_zero"]) == 0.0
+    assert not g0.any() and not g["frob.regloss_zero_grad"].any()
+    l1, g1 = sr.frob_reg_and_grad(0.2, g["frob.W2"][:60], g["frob.base"])
+    l2, g2 = sr.frob_reg_and_grad(0.1, g["frob.W2"][60:70], g["frob.prev"])
+    _close(l1 + l2, g["frob.loss"], 1e-6, 1e-5, "loss")
+    full = np.zeros((70, 640))
+    full[:60] += g1
+    full[60:70] += g2
+    _close(full, g["frob.grad"], 1e-7, 1e-5, "grad")
+
+
+# ---------------------------------------------------------------- G4 loop
+def _loop_setup(g):
+    hw, ns, seed = int(g["hw"]), int(g["n_sessions"]), int(g["seed"])
+    signal, memory = float(g["signal"]), bool(int(g["memory"]))
+    sd = syn.make_state_dict(int(g["sd_seed"]))
+    for k in g.files:
+        if k.startswith("bn0."):
+            sd[k[4:]] = g[k].copy()
+    sd["classifier.weight"] = g["base_classifier"].copy()
+    from types import SimpleNamespace
+    opt = SimpleNamespace(n_ways=5, n_shots=5, learning_rate=0.002, momentum=0.9, weight_decay=5e-4,
+                          lmbd_reg_transform_w=0.2, lmbd_reg_novel=0.1, label_pull=1.0, max_novel_epochs=1000,
+                          min_novel_epochs=20, target_train_loss=0.0, convergence_epsilon=1e-4, stable_epochs=10,
+                          memory_replay=1 if memory else 0)
+    for k in g.files:
+        if k.startswith("opt."):
+            setattr(opt, k[4:], g[k].item())
+    sessions = syn.make_sessions(seed, ns, hw, class_signal=signal)
+    base = syn.make_base_batch(seed, int(g["n_base_batch"]), hw, class_signal=signal)
+    bsup = syn.make_base_support(seed, hw, class_signal=signal) if memory else None
+    inits = syn.make_novel_inits(seed, ns)
+    return sd, opt, sessions, base, bsup, inits, int(g["mask_seed"]), [p for p in g["picks"]]
+
+
+@pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop"])
+def test_loop_against_reference(tag):
+    g = _load("loop_%s.npz" % tag)
+    sd, opt, sessions, base, bsup, inits, mseed, picks = _loop_setup(g)
+    net = ResNetRef(sd)
+    out = loop_ref.run_incremental(net, sessions, base, opt, inits, base_support=bsup,
+                                   masks=MaskSource(mseed), memory_picks=picks)
+    for s in range(len(sessions)):
+        assert out["epochs"][s] == int(g["s%d.epochs" % s]), (s, out["epochs"], g["s%d.epochs" % s])
+        _close(out["loss"][s], g["s%d.loss" % s], 2e-4, 2e-4, "loss s%d" % s)
+        _close(out["test_acc"][s], np.round(g["s%d.last_val" % s], 2), 1e-6, 0, "val acc s%d" % s)
+    _close(out["classifier_weight"], g["final_classifier"], 1e-4, 1e-4, "final classifier")
+    _close(np.mean(out["novel_acc"]), g["novel_avg"], 1e-6, 1e-6, "novel avg")
+    _close(np.mean(out["acc_base"]), np.round(float(g["base_avg"]), 2), 0.02, 0, "base avg")
+    for k in ("layer1.0.bn1", "layer4.1.bn3"):
+        _close(sd[k + ".running_mean"], g[k + ".running_mean"], 1e-5, 1e-4, k)
+        _close(sd[k + ".running_var"], g[k + ".running_var"], 1e-5, 1e-4, k)
+
+
+def test_memory_index_formula():
+    # language_eval.py:354-358: one shot index per class, its 5 augmented copies
+    inds = loop_ref.memory_indices([2])
+    sy, _ = syn.session_labels(0)
+    assert len(inds) == 25 and len(set(inds)) == 25
+    assert sorted(np.bincount(sy[inds] - 60)) == [5] * 5

@@ -1,0 +1,372 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference; CPU, torch 2.10).  The
+reference's Python never travels to the GPU box: only the .npz outputs of this
+script (data: inputs-as-seeds + expected outputs) are committed.
+
+Shims: Tensor.cuda / Module.cuda -> identity,
+torch.cuda.is_available -> True, cwd=/root/reference for the word-embedding pickle
+that LangPuller.__init__ loads even in distance2subspace mode.  The two RNG
+streams of the train-mode forward (F.dropout, Bernoulli) are replaced by
+oracle.resnet_ref.MaskSource so that masks are reproducible anywhere, and
+augment_base_classifier_ receives explicit `novel_weight` rows (its own API).
+
+Usage:  python tools/make_golden.py [blocks backbone reg loop32 loop84 ...]
+"""
+import os
+import sys
+import time
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "subspace-reg_amd"))
+sys.path.insert(0, REF)
+
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+torch.cuda.is_available = lambda: True
+os.chdir(REF)
+
+import models.resnet_language as rl          # noqa: E402  (the reference)
+import eval.language_eval as le              # noqa: E402  (the reference)
+
+from oracle.resnet_ref import MaskSource     # noqa: E402
+from subreg_hip import synthetic as syn      # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+torch.set_num_threads(8)
+
+
+# ------------------------------------------------------------------ RNG shims for the reference
+class _MaskedF:
+    """Stand-in for `F` inside models.resnet_language: dropout from the MaskSource."""
+
+    def __init__(self):
+        self.masks = None
+        self.pad = torch.nn.functional.pad
+
+    def dropout(self, x, p=0.5, training=True, inplace=False):
+        if not training:
+            return x
+        keep = torch.from_numpy(self.masks.dropout_keep(tuple(x.shape), p))
+        return x.mul_(keep * (1.0 / (1.0 - p))) if inplace else x * keep * (1.0 / (1.0 - p))
+
+
+_F = _MaskedF()
+rl.F = _F
+
+
+class _Bern:
+    def __init__(self, gamma):
+        self.gamma = gamma
+
+    def sample(self, shape):
+        return torch.from_numpy(_F.masks.bernoulli(tuple(shape), self.gamma))
+
+
+rl.Bernoulli = _Bern
+
+
+def set_masks(seed):
+    _F.masks = MaskSource(seed)
+
+
+def ref_opt(**kw):
+    """Flag values of scripts/continual/slurm_subspace_reg.sh:33-54 + configs.py defaults."""
+    o = SimpleNamespace(
+        no_dropblock=True, linear_bias=False, temperature=1, word_embed_size=500,
+        word_embed_path="word_embeds", dataset="miniImageNet", use_synonyms=False, glove=False,
+        track_weights=False, track_label_inspired_weights=False, save_preds_0=False, set_seed=1,
+        memory_replay=0, neval_episodes=8, continual=False, n_ways=5, n_shots=5, n_queries=25,
+        label_pull=1.0, pulling="regularize", attraction_override="distance2subspace",
+        classifier="linear", attention=None, lmbd_reg_transform_w=0.2, lmbd_reg_novel=0.1,
+        target_train_loss=0.0, convergence_epsilon=1e-4, stable_epochs=10, max_novel_epochs=1000,
+        min_novel_epochs=20, learning_rate=0.002, momentum=0.9, weight_decay=5e-4, adam=False,
+        freeze_backbone_at=1, eval_mode="few-shot-incremental-fine-tune", verbose=False)
+    o.__dict__.update(kw)
+    return o
+
+
+def ref_net(sd, opt, n_cls=60):
+    net = rl.resnet18(avg_pool=True, drop_rate=0.1, dropblock_size=5, num_classes=n_cls, vocab=None, opt=opt)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    return net
+
+
+def t2n(t):
+    return t.detach().cpu().numpy().copy()
+
+
+# ------------------------------------------------------------------ G1: block level
+def gen_blocks():
+    opt = ref_opt()
+    sd = syn.make_state_dict(11)
+    out = {}
+    hw_in = {"layer1.0": 84, "layer2.0": 42, "layer3.0": 21, "layer3.1": 10, "layer4.0": 10, "layer4.1": 5}
+    for bs_name, no_db in (("bs1", True), ("bs5", False)):
+        opt.no_dropblock = no_db
+        net = ref_net(sd, opt)
+        for li, (name, cin, cout, stride, ds, db) in enumerate(syn.backbone_blocks()):
+            if bs_name == "bs5" and not db:
+                continue                      # block_size only matters for the DropBlock blocks
+            blk = dict(net.named_modules())[name]
+            B = 1 if name in ("layer1.0", "layer2.0") else 2
+            hw = hw_in[name]
+            x = np.random.RandomState(100 + li).standard_normal((B, cin, hw, hw)).astype(np.float32)
+            key = "%s.%s" % (name, bs_name)
+            out[key + ".in_seed"] = np.array(100 + li)
+            out[key + ".in_shape"] = np.array(x.shape)
+            if bs_name == "bs1":
+                blk.eval()
+                with torch.no_grad():
+                    out[key + ".eval_out"] = t2n(blk(torch.from_numpy(x)))
+            # train mode with injected masks; force a large forward counter so DropBlock's gamma is at its cap
+            blk.train()
+            blk.num_batches_tracked = 39999
+            set_masks(200 + li)
+            with torch.no_grad():
+                out[key + ".train_out"] = t2n(blk(torch.from_numpy(x)))
+            out[key + ".mask_seed"] = np.array(200 + li)
+            for bn in ("bn1", "bn2", "bn3") + (("downsample.1",) if ds else ()):
+                m = dict(blk.named_modules())[bn]
+                out["%s.%s.running_mean" % (key, bn)] = t2n(m.running_mean)
+                out["%s.%s.running_var" % (key, bn)] = t2n(m.running_var)
+            # restore the buffers for the next variant
+            net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    np.savez_compressed(os.path.join(GOLD, "blocks.npz"), **out)
+    print("blocks.npz", sum(v.nbytes for v in out.values()) / 1e6, "MB")
+
+
+# ------------------------------------------------------------------ G2: backbone
+def gen_backbone():
+    opt = ref_opt()
+    out = {}
+    for hw in (84, 32):
+        sd = syn.make_state_dict(21)
+        net = ref_net(sd, opt)
+        x = syn.make_images(31, 4, hw)
+        net.eval()
+        with torch.no_grad():
+            feats, logits = net(torch.from_numpy(x), is_feat=True)
+        out["hw%d.eval_feat" % hw] = t2n(feats[-1])
+        out["hw%d.eval_logits" % hw] = t2n(logits)
+        out["hw%d.eval_f0_b0" % hw] = t2n(feats[0][0])         # stage-1 output of image 0 (localises a mismatch)
+        net.train()
+        set_masks(41)
+        with torch.no_grad():
+            logits = net(torch.from_numpy(x))
+        out["hw%d.train_logits" % hw] = t2n(logits)
+        for k in ("layer1.0.bn1", "layer2.0.downsample.1", "layer3.1.bn2", "layer4.1.bn3"):
+            m = dict(net.named_modules())[k]
+            out["hw%d.%s.running_mean" % (hw, k)] = t2n(m.running_mean)
+            out["hw%d.%s.running_var" % (hw, k)] = t2n(m.running_var)
+        net.eval()
+        with torch.no_grad():
+            out["hw%d.eval2_logits" % hw] = t2n(net(torch.from_numpy(x)))   # eval AFTER the stats moved
+    np.savez_compressed(os.path.join(GOLD, "backbone.npz"), **out)
+    print("backbone.npz", sum(v.nbytes for v in out.values()) / 1e6, "MB")
+
+
+# ------------------------------------------------------------------ G3: regularizers
+def gen_reg():
+    opt = ref_opt()
+    rs = np.random.RandomState(51)
+    out = {}
+    puller = rl.LangPuller(opt, ["a"], ["b"])
+    net = ref_net(syn.make_state_dict(21), opt)
+    for case in ("rand", "trained"):
+        wb = (rs.standard_normal((60, 640)) * 0.05).astype(np.float32)
+        if case == "trained":
+            wb += (rs.standard_normal((60, 1)) * rs.standard_normal((1, 640)) * 0.05).astype(np.float32)
+        for k in (5, 40):
+            w = torch.from_numpy((rs.standard_normal((k, 640)) * 0.04).astype(np.float32)).requires_grad_(True)
+            p = puller.get_projected_weight(torch.from_numpy(wb), w)
+            loss = puller.loss1(0.7, p, w)
+            loss.backward()
+            key = "%s.k%d" % (case, k)
+            out[key + ".w_base"], out[key + ".w"] = wb, t2n(w)
+            out[key + ".P"], out[key + ".loss1"], out[key + ".grad"] = t2n(p), t2n(loss), t2n(w.grad)
+    # regloss / reglossnovel incl. the exact-zero case
+    base_w, _ = net._get_base_weights()
+    net.augment_base_classifier_(10, novel_weight=torch.from_numpy((rs.standard_normal((10, 640)) * 0.03).astype(np.float32)))
+    out["frob.W"] = t2n(net.classifier.weight)
+    out["frob.base"] = t2n(base_w)
+    l0 = net.regloss(0.2, base_w)
+    l0.backward()
+    out["frob.regloss_zero"], out["frob.regloss_zero_grad"] = t2n(l0), t2n(net.classifier.weight.grad)
+    net.classifier.weight.grad = None
+    with torch.no_grad():
+        net.classifier.weight += torch.from_numpy((rs.standard_normal((70, 640)) * 0.01).astype(np.float32))
+    out["frob.W2"] = t2n(net.classifier.weight)
+    prev = torch.from_numpy((rs.standard_normal((10, 640)) * 0.03).astype(np.float32))
+    out["frob.prev"] = t2n(prev)
+    l1 = net.regloss(0.2, base_w) + net.reglossnovel(0.1, prev)
+    l1.backward()
+    out["frob.loss"], out["frob.grad"] = t2n(l1), t2n(net.classifier.weight.grad)
+    np.savez_compressed(os.path.join(GOLD, "reg.npz"), **out)
+    print("reg.npz", sum(v.nbytes for v in out.values()) / 1e6, "MB")
+
+
+# ------------------------------------------------------------------ G4: the loop
+class _Loader(list):
+    def __init__(self, items, label2human):
+        super().__init__(items)
+        self.dataset = SimpleNamespace(label2human=label2human)
+
+
+def calibrate_bn(net, hw, signal):
+    """One train-mode pass (momentum 1.0, no dropping) so the running stats match the synthetic data."""
+    from oracle.resnet_ref import OnesMaskSource
+    x, _ = syn.make_base_batch(99, 64, hw, class_signal=signal)
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    for m in bns:
+        m.momentum = 1.0
+    net.train()
+    _F.masks = OnesMaskSource()
+    with torch.no_grad():
+        net(torch.from_numpy(x))
+    for m in bns:
+        m.momentum = 0.1
+        m.num_batches_tracked.zero_()
+    for blk in net.modules():
+        if isinstance(blk, rl.BasicBlock):
+            blk.num_batches_tracked = 0
+    net.eval()
+
+
+def ncm_classifier(net, hw, signal, per_class=8):
+    """Base classifier rows = nearest-class-mean directions of noisy class samples, centred and made
+    orthogonal to the global mean feature (there is no bias), scaled to norm 0.5."""
+    ys = np.repeat(np.arange(60), per_class)
+    xs = syn.make_images(4242, len(ys), hw)
+    for c in range(60):
+        xs[ys == c] += signal * np.random.RandomState(777000 + c).standard_normal((3, hw, hw)).astype(np.float32)
+    net.eval()
+    with torch.no_grad():
+        f, _ = net(torch.from_numpy(xs), is_feat=True)
+    f = t2n(f[-1]).astype(np.float64)
+    g = f.mean(0)
+    w = np.stack([f[ys == c].mean(0) for c in range(60)]) - g
+    gh = g / np.linalg.norm(g)
+    w = w - (w @ gh)[:, None] * gh[None, :]
+    w = 0.5 * w / np.linalg.norm(w, axis=1, keepdims=True)
+    # the centred class means sum to zero (rank 59); a real base classifier has full rank and torch.qr has no
+    # rank handling (its last basis vector would be rounding noise), so add a small seeded full-rank component
+    w = w + 0.004 * np.random.RandomState(31337).standard_normal(w.shape)
+    for blk in net.modules():
+        if isinstance(blk, rl.BasicBlock):
+            blk.num_batches_tracked = 0
+    return w.astype(np.float32)
+
+
+def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, **optkw):
+    opt = ref_opt(set_seed=seed, neval_episodes=n_sessions, memory_replay=1 if memory else 0, **optkw)
+    signal = 3.0
+    sd = syn.make_state_dict(21 + seed)
+    net = ref_net(sd, opt)
+    calibrate_bn(net, hw, signal)
+    wcls = ncm_classifier(net, hw, signal)
+    bn0 = {k: t2n(v) for k, v in net.state_dict().items() if "running_" in k}
+    with torch.no_grad():
+        net.classifier.weight.copy_(torch.from_numpy(wcls))
+    sessions = syn.make_sessions(seed, n_sessions, hw, class_signal=signal)
+    base_x, base_y = syn.make_base_batch(seed, n_base_batch, hw, class_signal=signal)
+    inits = syn.make_novel_inits(seed, n_sessions)
+    names_base = ["b%d" % i for i in range(60)] + [""] * 40
+    names_novel = ["n%d" % i for i in range(100)]
+    base_loader = _Loader([(torch.from_numpy(base_x), torch.from_numpy(base_y), torch.arange(len(base_y)))], names_base)
+    meta = _Loader([(torch.from_numpy(s["support_xs"])[None], torch.from_numpy(s["support_ys"])[None],
+                     torch.from_numpy(s["query_xs"])[None], torch.from_numpy(s["query_ys"])[None]) for s in sessions],
+                   names_novel)
+    bsl = None
+    if memory:
+        bx, by = syn.make_base_support(seed, hw, class_signal=signal)
+        bsl = _Loader([(torch.from_numpy(bx)[None], torch.from_numpy(by)[None],
+                        torch.zeros(1, 1, 3, hw, hw), torch.zeros(1, 1, dtype=torch.long))], names_base)
+    # explicit init rows through the reference's own novel_weight= argument; one call == one session start
+    rec = dict(loss=[], val=[], picks=[])
+    counter = {"i": 0}
+    orig_aug = net.augment_base_classifier_
+
+    def aug(n, novel_weight=None, novel_bias=None):
+        r = orig_aug(n, novel_weight=torch.from_numpy(inits[counter["i"]]))
+        counter["i"] += 1
+        rec["loss"].append([])
+        rec["val"].append([])
+        return r
+    net.augment_base_classifier_ = aug
+    # record per-epoch losses (at loss.backward()), per-epoch validation accuracies, memory picks
+    orig_validate, orig_choice, orig_backward = le.validate, np.random.choice, torch.Tensor.backward
+
+    def validate(query_xs, query_ys_id, net_, criterion, opt_, epoch):
+        r = orig_validate(query_xs, query_ys_id, net_, criterion, opt_, epoch)
+        if isinstance(query_xs, list):
+            rec["val"][-1].append([float(a) for a in r[0]])
+        return r
+
+    def choice(a, size=None, *args, **kw):
+        r = orig_choice(a, size, *args, **kw)
+        rec["picks"].append(np.array(r))
+        return r
+
+    def backward(self, *a, **k):
+        rec["loss"][-1].append(float(self.item()))
+        return orig_backward(self, *a, **k)
+    le.validate, np.random.choice, torch.Tensor.backward = validate, choice, backward
+    crit = torch.nn.CrossEntropyLoss()
+    set_masks(61 + seed)
+    t0 = time.time()
+    try:
+        novel_avg, base_avg = le.few_shot_finetune_incremental_test(net, {}, crit, meta, base_loader, opt,
+                                                                    vis=False, base_support_loader=bsl)
+    finally:
+        le.validate, np.random.choice, torch.Tensor.backward = orig_validate, orig_choice, orig_backward
+    print(tag, "reference loop took %.1f s" % (time.time() - t0))
+    out = dict(hw=np.array(hw), n_sessions=np.array(n_sessions), memory=np.array(int(memory)), seed=np.array(seed),
+               n_base_batch=np.array(n_base_batch), signal=np.array(signal), sd_seed=np.array(21 + seed),
+               mask_seed=np.array(61 + seed), base_classifier=wcls,
+               final_classifier=t2n(net.classifier.weight), novel_avg=np.array(novel_avg), base_avg=np.array(base_avg),
+               picks=np.array([p.reshape(-1) for p in rec["picks"]]) if rec["picks"] else np.zeros((0, 1), np.int64))
+    for k, v in optkw.items():
+        out["opt." + k] = np.array(v)
+    for k, v in bn0.items():
+        out["bn0." + k] = v
+    for s in range(n_sessions):
+        out["s%d.loss" % s] = np.array(rec["loss"][s], np.float64)
+        out["s%d.last_val" % s] = np.array(rec["val"][s][-1], np.float64)
+        out["s%d.epochs" % s] = np.array(len(rec["loss"][s]))
+    for k in ("layer1.0.bn1", "layer4.1.bn3"):
+        m = dict(net.named_modules())[k]
+        out[k + ".running_mean"], out[k + ".running_var"] = t2n(m.running_mean), t2n(m.running_var)
+    np.savez_compressed(os.path.join(GOLD, "loop_%s.npz" % tag), **out)
+    print("loop_%s.npz" % tag, {k: v for k, v in out.items() if k.endswith("epochs")})
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    what = sys.argv[1:] or ["blocks", "backbone", "reg", "loop32", "loop84"]
+    if "blocks" in what:
+        gen_blocks()
+    if "backbone" in what:
+        gen_backbone()
+    if "reg" in what:
+        gen_reg()
+    if "loop32" in what:
+        gen_loop("hw32_noM", 32, 2, False, 40, seed=1, max_novel_epochs=4)
+        gen_loop("hw32_M", 32, 3, True, 40, seed=2, max_novel_epochs=3)
+        # data-dependent stop: loose epsilon + short stable window so the stable rule fires before the cap
+        gen_loop("hw32_stop", 32, 2, True, 40, seed=3, max_novel_epochs=40, stable_epochs=3,
+                 convergence_epsilon=2e-2)
+    if "loop84" in what:
+        gen_loop("hw84_M", 84, 3, True, 40, seed=4, max_novel_epochs=4)
+
+
+if __name__ == "__main__":
+    main()
