@@ -73,7 +73,7 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
     base_weight = W.copy()                                      # basenet._get_base_weights(), :106-107
     base_x, base_y = base_batch
     out = dict(loss=[], test_acc=[], acc_base=[], weighted_avg=[], epochs=[], novel_acc=[],
-               memory_inds=[], train_acc=[])
+               memory_inds=[], train_acc=[], novel_vals=[], base_vals=[])
 
     def eval_feats(x):
         net.eval()
@@ -188,6 +188,8 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
         out["loss"].append(losses)
         out["train_acc"].append(tr_acc)
         out["test_acc"].append(test_acc)
+        out["novel_vals"].append(ta)          # AverageMeter contents, :379-380 (un-rounded)
+        out["base_vals"].append(acc_b)
         out["novel_acc"].append(round(ta, 2))
         out["acc_base"].append(round(acc_b, 2))
         out["weighted_avg"].append(round((w1 * acc_b + w2 * ta) / (w1 + w2), 2))

@@ -43,7 +43,7 @@ def _acc(correct, n):
     return float(np.float32(correct) * np.float32(100.0 / n))
 
 
-class _Session:
+class _SessionBuffers:
     """Device buffers of one session's fused loop."""
 
     def __init__(self, dev, n_rows, n_cls, dim, max_epochs, n_sets):
@@ -60,97 +60,125 @@ class _Session:
         self.mom = torch.zeros(n_cls * dim, dtype=f32, device=dev)
 
 
-def few_shot_finetune_incremental_test(net, ckpt, criterion, meta_valloader, base_val_loader, opt, vis=False,
-                                       base_support_loader=None, *, novel_inits=None, memory_picks=None,
-                                       epochs_per_sync=8, reuse_features=False, verbose=True):
-    """Drop-in for the reference function.  Extra keyword-only arguments (all optional):
-      novel_inits     list of [n_ways, 640] init rows passed to augment_base_classifier_(novel_weight=...)
-      memory_picks    list of np.random.choice(n_shots, memory_replay) results (else drawn from np.random)
-      epochs_per_sync epochs queued per host synchronisation
-      reuse_features  opt-in: compute the (constant) eval-mode features once per session
-    Returns (acc_novel.avg, acc_base.avg) like the reference; details are left in net.last_run."""
-    if vis or getattr(opt, "track_weights", False) or getattr(opt, "save_preds_0", False):
-        raise NotImplementedError("visualisation / CSV tracking are outside the hot path (SURVEY.md section 8)")
-    if getattr(opt, "label_pull", None) is not None and getattr(opt, "attraction_override", None) != "distance2subspace":
-        raise NotImplementedError("fused loop implements the distance2subspace regularizer "
-                                  "(scripts/continual/slurm_subspace_reg.sh); use the module surface for the others")
-    if net.classifier.bias is not None:
-        raise NotImplementedError("fused loop assumes --no_linear_bias backbones (slurm_run_backbone.sh:39)")
-    if getattr(opt, "adam", False):
-        raise NotImplementedError("fused step implements SGD(momentum) (eval/util.py:98-101)")
-    lib = _lib.load()
-    dev = net.classifier.weight.device
-    p = (lambda *a, **k: print(*a, **k)) if verbose else (lambda *a, **k: None)
-    torch.manual_seed(opt.set_seed)                                          # :101-102
-    np.random.seed(opt.set_seed)
-    hb = net.hip_backbone()
-    D = net.classifier.weight.shape[1]
-    base_weight = net.classifier.weight.detach().clone()                     # :106-107
-    n_base = base_weight.shape[0]
-    basis, basis_info = (HF.subspace_basis(base_weight) if opt.label_pull is not None else (None, None))
-    base_it = itertools.cycle(iter(base_val_loader))
-    meta_it = itertools.cycle(iter(meta_valloader))
-    base_support_xs = base_support_ys = None
-    if base_support_loader is not None:                                      # :112-116
-        base_support_xs, base_support_ys, *_ = _drop_a_dim(next(itertools.cycle(iter(base_support_loader))))
-    base_batch = next(base_it)                                               # :121
-    base_x = base_batch[0].squeeze(0).to(dev, torch.float32)
-    base_y = base_batch[1].squeeze(0).to(dev, torch.int64)
-    s = _lib.stream_ptr
+class IncrementalRunner:
+    """State carried across the sessions of one run (classifier rows, BN stats, memory, reserved rows, query sets).
 
-    def eval_base():                                                         # :46-69
-        net.eval()
-        feat = hb.forward(base_x)
-        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-        W = net.classifier.weight.detach()
-        _lib.check(lib.subreg_validate(_lib.ptr(feat), _lib.ptr(base_y), _lib.ptr(W), feat.shape[0], W.shape[0], D,
-                                       None, _lib.ptr(cnt), 0, 1, 0, s()), "validate(base)")
+    start() = everything before the session loop (:100-142); run_session(idx) = the loop body (:145-395), i.e. one
+    incremental EPISODE, the unit of BASELINE.json's metric; finish() = the final report (:451-454)."""
+
+    def __init__(self, net, meta_valloader, base_val_loader, opt, base_support_loader=None, novel_inits=None,
+                 memory_picks=None, epochs_per_sync=8, reuse_features=False, verbose=True, profile=False):
+        if getattr(opt, "track_weights", False) or getattr(opt, "save_preds_0", False):
+            raise NotImplementedError("CSV tracking is outside the hot path (SURVEY.md section 8)")
+        if getattr(opt, "label_pull", None) is not None and getattr(opt, "attraction_override", None) != "distance2subspace":
+            raise NotImplementedError("fused loop implements the distance2subspace regularizer "
+                                      "(scripts/continual/slurm_subspace_reg.sh); use the module surface for the others")
+        if net.classifier.bias is not None:
+            raise NotImplementedError("fused loop assumes --no_linear_bias backbones (slurm_run_backbone.sh:39)")
+        if getattr(opt, "adam", False):
+            raise NotImplementedError("fused step implements SGD(momentum) (eval/util.py:98-101)")
+        self.lib = _lib.load()
+        self.net, self.opt = net, opt
+        self.meta_valloader, self.base_val_loader, self.base_support_loader = meta_valloader, base_val_loader, base_support_loader
+        self.novel_inits, self.memory_picks = novel_inits, memory_picks
+        self.epochs_per_sync, self.reuse_features = int(epochs_per_sync), reuse_features
+        self.p = (lambda *a, **k: print(*a, **k)) if verbose else (lambda *a, **k: None)
+        self.profile = profile
+        self.fwd_events = []          # (start, end, n_images) of every backbone forward when profile=True
+        self.images_forwarded = 0
+
+    # ------------------------------------------------------------------ helpers
+    def _forward(self, x, train=False, out=None):
+        net = self.net
+        if self.profile:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        r = self.hb.forward(x, train=train, masks=net.mask_source if train else None, out=out)
+        if self.profile:
+            e1.record()
+            self.fwd_events.append((e0, e1, x.shape[0]))
+        self.images_forwarded += x.shape[0]
+        return r
+
+    def _eval_base(self):                                                        # :46-69
+        self.net.eval()
+        feat = self._forward(self.base_x)
+        cnt = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        W = self.net.classifier.weight.detach()
+        _lib.check(self.lib.subreg_validate(_lib.ptr(feat), _lib.ptr(self.base_y), _lib.ptr(W), feat.shape[0], W.shape[0],
+                                            self.D, None, _lib.ptr(cnt), 0, 1, 0, _lib.stream_ptr()), "validate(base)")
         return _acc(int(cnt.item()), feat.shape[0])
 
-    acc_novel_list, acc_base_list, weighted_avg_l = [], [], []
-    novel_vals, base_vals = [], []                                           # AverageMeter contents (:379-380)
-    weighted_avg_l.append(eval_base())                                       # :128-129
-    iter_num = 8 if getattr(opt, "continual", False) else opt.neval_episodes # :132-136
-    query_x, query_id = [], []
-    mem_x = mem_y = None
-    reserve = None
-    run = dict(loss=[], test_acc=[], epochs=[], train_acc=[], memory_inds=[])
-    vocab_base = vocab_novel = None
-    for idx in range(iter_num):
+    # ------------------------------------------------------------------ :100-142
+    def start(self):
+        net, opt = self.net, self.opt
+        self.dev = net.classifier.weight.device
+        torch.manual_seed(opt.set_seed)                                          # :101-102
+        np.random.seed(opt.set_seed)
+        self.hb = net.hip_backbone()
+        self.D = net.classifier.weight.shape[1]
+        self.base_weight = net.classifier.weight.detach().clone()                # :106-107
+        self.n_base = self.base_weight.shape[0]
+        self.basis, self.basis_info = (HF.subspace_basis(self.base_weight) if opt.label_pull is not None else (None, None))
+        self.meta_it = itertools.cycle(iter(self.meta_valloader))
+        self.base_support_xs = self.base_support_ys = None
+        if self.base_support_loader is not None:                                 # :112-116
+            self.base_support_xs, self.base_support_ys, *_ = _drop_a_dim(next(itertools.cycle(iter(self.base_support_loader))))
+        base_batch = next(itertools.cycle(iter(self.base_val_loader)))           # :121
+        self.base_x = base_batch[0].squeeze(0).to(self.dev, torch.float32)
+        self.base_y = base_batch[1].squeeze(0).to(self.dev, torch.int64)
+        self.acc_novel_list, self.acc_base_list, self.weighted_avg_l = [], [], []
+        self.novel_vals, self.base_vals = [], []                                 # AverageMeter contents (:379-380)
+        self.weighted_avg_l.append(self._eval_base())                            # :128-129
+        self.iter_num = 8 if getattr(opt, "continual", False) else opt.neval_episodes   # :132-136
+        self.query_x, self.query_id = [], []
+        self.mem_x = self.mem_y = None
+        self.reserve = None
+        self.run = dict(loss=[], test_acc=[], epochs=[], train_acc=[], memory_inds=[])
+        self.vocab_base = self.vocab_novel = None
+        return self
+
+    # ------------------------------------------------------------------ :145-395, one episode
+    def run_session(self, idx):
+        net, opt, lib, dev, D, p = self.net, self.opt, self.lib, self.dev, self.D, self.p
+        hb, s = self.hb, _lib.stream_ptr
         p("\n**** Iteration {}/{} ****\n".format(idx + 1, opt.neval_episodes))
-        support_xs, support_ys, qx, qy = _drop_a_dim(next(meta_it))
-        if base_support_xs is not None:
-            support_xs = torch.cat([support_xs, base_support_xs], 0)          # :149-150
-        prev_vb, prev_vn = vocab_base, vocab_novel
-        vocab_base, vocab_novel, orig2id = _vocabs(base_val_loader, meta_valloader, qy)
-        n_vb = len(vocab_base)
+        support_xs, support_ys, qx, qy = _drop_a_dim(next(self.meta_it))
+        if self.base_support_xs is not None:
+            support_xs = torch.cat([support_xs.to(self.base_support_xs.device), self.base_support_xs], 0)   # :149-150
+        prev_vb, prev_vn = self.vocab_base, self.vocab_novel
+        vocab_base, vocab_novel, orig2id = _vocabs(self.base_val_loader, self.meta_valloader, qy)
         if idx > 0:
             vocab_base = prev_vb + prev_vn                                     # :166-167
+        self.vocab_base, self.vocab_novel = vocab_base, vocab_novel
         n_old = len(vocab_base)
         W = net.classifier.weight.detach()
         if idx == 1:                                                           # :172-185
-            reserve = W[-opt.n_ways:].clone()
+            self.reserve = W[-opt.n_ways:].clone()
         elif idx > 1:
-            reserve = torch.cat((reserve, W[-opt.n_ways:].clone()), 0)
+            self.reserve = torch.cat((self.reserve, W[-opt.n_ways:].clone()), 0)
+        reserve = self.reserve
         novel_labels = np.sort(np.unique(qy))
         orig2id = {k: v + idx * opt.n_ways for k, v in orig2id.items()}        # :193-194
         qid = torch.tensor([orig2id[y] for y in qy], dtype=torch.int64)
         sid = torch.tensor([orig2id[y] for y in support_ys], dtype=torch.int64)
-        if base_support_ys is not None:
-            sid = torch.cat([sid, torch.from_numpy(np.asarray(base_support_ys)).long()])   # :207-209
-        query_x.append(qx.to(dev, torch.float32))
-        query_id.append(qid.to(dev))
+        if self.base_support_ys is not None:
+            sid = torch.cat([sid, torch.from_numpy(np.asarray(self.base_support_ys)).long()])   # :207-209
+        self.query_x.append(qx.to(dev, torch.float32))
+        self.query_id.append(qid.to(dev))
+        query_x, query_id = self.query_x, self.query_id
         net.train()                                                            # :211
-        net.augment_base_classifier_(len(novel_labels),
-                                     novel_weight=None if novel_inits is None else torch.as_tensor(novel_inits[idx]))
+        net.augment_base_classifier_(len(novel_labels), novel_weight=None if self.novel_inits is None
+                                     else torch.as_tensor(self.novel_inits[idx]))
         W = net.classifier.weight.data                                         # live [N, D], updated in place by the step
         N = W.shape[0]
         sx = support_xs.to(dev, torch.float32)
         sid = sid.to(dev)
+        mem_x, mem_y = self.mem_x, self.mem_y
         Bs, Bm = sx.shape[0], (0 if mem_x is None else mem_x.shape[0])
         n_sets = len(query_x)
         max_e = int(opt.max_novel_epochs)
-        ses = _Session(dev, Bs + Bm, N, D, max_e, n_sets)
+        ses = _SessionBuffers(dev, Bs + Bm, N, D, max_e, n_sets)
         _lib.check(lib.subreg_loop_state_init(_lib.ptr(ses.state), s()), "loop_state_init")
         labels = sid if mem_x is None else torch.cat([sid, mem_y])
         all_x = torch.cat([sx] + ([mem_x] if mem_x is not None else []) + query_x, 0)
@@ -160,11 +188,11 @@ def few_shot_finetune_incremental_test(net, ckpt, criterion, meta_valloader, bas
         d.feat, d.labels = feats.data_ptr(), labels.data_ptr()
         d.n_support, d.n_memory, d.n_classes, d.dim = Bs, Bm, N, D
         d.weight, d.momentum_buf = W.data_ptr(), ses.mom.data_ptr()
-        d.w_base = base_weight.data_ptr()
+        d.w_base = self.base_weight.data_ptr()
         use_prev = opt.lmbd_reg_novel is not None and idx > 0
         d.w_prev = reserve.data_ptr() if use_prev else None
-        d.basis = basis.data_ptr() if basis is not None else None
-        d.n_base, d.n_prev, d.n_old = n_base, (reserve.shape[0] if use_prev else 0), n_old
+        d.basis = self.basis.data_ptr() if self.basis is not None else None
+        d.n_base, d.n_prev, d.n_old = self.n_base, (reserve.shape[0] if use_prev else 0), n_old
         d.lr, d.momentum, d.weight_decay = opt.learning_rate, opt.momentum, opt.weight_decay
         d.lmbd_base = opt.lmbd_reg_transform_w or 0.0
         d.lmbd_prev = opt.lmbd_reg_novel or 0.0
@@ -187,63 +215,89 @@ def few_shot_finetune_incremental_test(net, ckpt, criterion, meta_valloader, bas
                                                n_sets, int(j == n_sets - 1), s()), "validate")
 
         # ---- epoch 1: TRAIN-mode support (+memory) forward (BN batch stats, running-stat update, masks), :252-258
-        hb.forward(sx, train=True, masks=net.mask_source, out=feats[:Bs])
+        self._forward(sx, train=True, out=feats[:Bs])
         if Bm:
-            hb.forward(mem_x, train=True, masks=net.mask_source, out=feats[Bs:Bs + Bm])
+            self._forward(mem_x, train=True, out=feats[Bs:Bs + Bm])
         for m in net._bns:
             m.num_batches_tracked += 1 + (1 if Bm else 0)
         net.eval()                                                             # validate() flips the mode for good, :19
-        hb.forward(all_x[Bs + Bm:], out=feats[Bs + Bm:])
+        self._forward(all_x[Bs + Bm:], out=feats[Bs + Bm:])
         for i in range(len(hb.nbt)):
             hb.nbt[i] += n_sets - 1
         step_and_validate()
-        done, stop = 1, False
         # ---- epochs >= 2: eval mode, one batched forward per epoch
         while True:
             st = ses.state.cpu()
             done, stop = int(st[0]), bool(st[1])
             if stop:
                 break
-            k = min(int(epochs_per_sync), max_e - done)
+            k = min(self.epochs_per_sync, max_e - done)
+            executed = 0
             for e in range(k):
-                if not reuse_features or (done == 1 and e == 0):
-                    hb.forward(all_x, out=feats)
+                if not self.reuse_features or (done == 1 and e == 0):
+                    self._forward(all_x, out=feats)
+                    executed += 1
                 step_and_validate()
-            st = ses.state.cpu()
-            ran = int(st[0]) - done                 # epochs that really advanced the loop
-            for i in range(len(hb.nbt)):            # count forwards like the reference (wasted ones do not exist there)
-                hb.nbt[i] += ran * fwd_per_epoch - (k if not reuse_features else (1 if done == 1 else 0))
+            ran = int(ses.state.cpu()[0]) - done   # epochs that really advanced the loop
+            for i in range(len(hb.nbt)):            # count forwards like the reference (queued-but-stopped ones do not exist there)
+                hb.nbt[i] += ran * fwd_per_epoch - executed
         epochs = done
         losses = ses.losses[:epochs].cpu().numpy().astype(np.float64)
         correct = ses.correct.view(-1, n_sets)[epochs].cpu().numpy()
         test_acc = [round(_acc(int(c), query_x[j].shape[0]), 2) for j, c in enumerate(correct)]   # :372
         if opt.memory_replay:                                                  # :353-359
-            pick = memory_picks[idx] if memory_picks is not None else np.random.choice(opt.n_shots, opt.memory_replay)
+            pick = (self.memory_picks[idx] if self.memory_picks is not None
+                    else np.random.choice(opt.n_shots, opt.memory_replay))
             inds = np.tile(5 * np.arange(5) + np.asarray(pick), (5, 1)) + (np.tile(np.arange(0, 125, 25), (5, 1))).T
             inds = torch.from_numpy(inds.flatten()).to(dev)
-            run["memory_inds"].append(inds.cpu().numpy())
-            mem_x = sx[inds] if mem_x is None else torch.cat((mem_x, sx[inds]), 0)
-            mem_y = sid[inds] if mem_y is None else torch.cat((mem_y, sid[inds]), 0)
-        acc_base_ = eval_base()                                                # :363-367
+            self.run["memory_inds"].append(inds.cpu().numpy())
+            self.mem_x = sx[inds] if mem_x is None else torch.cat((mem_x, sx[inds]), 0)
+            self.mem_y = sid[inds] if mem_y is None else torch.cat((mem_y, sid[inds]), 0)
+        acc_base_ = self._eval_base()                                          # :363-367
         p("Novel session accuracies: ", test_acc)
         ta = float(np.array(test_acc).mean())
         w1 = 60 if opt.dataset == "miniImageNet" else 200                      # :383
         w2 = len(vocab_base) + len(vocab_novel) - 60
         weighted_avg = (w1 * acc_base_ + w2 * ta) / (w1 + w2)
-        weighted_avg_l.append(round(weighted_avg, 2))
-        acc_novel_list.append(round(ta, 2))
-        acc_base_list.append(round(acc_base_, 2))
-        novel_vals.append(ta)
-        base_vals.append(acc_base_)
+        self.weighted_avg_l.append(round(weighted_avg, 2))
+        self.acc_novel_list.append(round(ta, 2))
+        self.acc_base_list.append(round(acc_base_, 2))
+        self.novel_vals.append(ta)
+        self.base_vals.append(acc_base_)
         p("***Running weighted avg: {}".format(weighted_avg))
+        run = self.run
         run["loss"].append(losses)
         run["test_acc"].append(test_acc)
         run["epochs"].append(epochs)
         run["train_acc"].append(ses.train_acc[:epochs].cpu().numpy())
-    run.update(weighted_avg=weighted_avg_l, novel_acc=acc_novel_list, acc_base=acc_base_list,
-               classifier_weight=net.classifier.weight.detach().cpu().numpy(), basis_info=basis_info)
-    net.last_run = run
-    p("Overall continual accuracies: ", weighted_avg_l)
-    p("Novel only incremental: ", acc_novel_list)
-    p("Base only incremental: ", acc_base_list)
-    return float(np.mean(novel_vals)), float(np.mean(base_vals))
+        return epochs
+
+    # ------------------------------------------------------------------ :451-454
+    def finish(self):
+        run, p = self.run, self.p
+        run.update(weighted_avg=self.weighted_avg_l, novel_acc=self.acc_novel_list, acc_base=self.acc_base_list,
+                   classifier_weight=self.net.classifier.weight.detach().cpu().numpy(), basis_info=self.basis_info)
+        self.net.last_run = run
+        p("Overall continual accuracies: ", self.weighted_avg_l)
+        p("Novel only incremental: ", self.acc_novel_list)
+        p("Base only incremental: ", self.acc_base_list)
+        return float(np.mean(self.novel_vals)), float(np.mean(self.base_vals))
+
+
+def few_shot_finetune_incremental_test(net, ckpt, criterion, meta_valloader, base_val_loader, opt, vis=False,
+                                       base_support_loader=None, *, novel_inits=None, memory_picks=None,
+                                       epochs_per_sync=8, reuse_features=False, verbose=True):
+    """Drop-in for the reference function.  Extra keyword-only arguments (all optional):
+      novel_inits     list of [n_ways, 640] init rows passed to augment_base_classifier_(novel_weight=...)
+      memory_picks    list of np.random.choice(n_shots, memory_replay) results (else drawn from np.random)
+      epochs_per_sync epochs queued per host synchronisation
+      reuse_features  opt-in: compute the (constant) eval-mode features once per session
+    `ckpt` and `criterion` are accepted for signature compatibility (CrossEntropyLoss is fused into the step; the
+    non-continual branch never reads ckpt).  Returns (acc_novel.avg, acc_base.avg); details in net.last_run."""
+    if vis:
+        raise NotImplementedError("visualisation is outside the hot path (SURVEY.md section 8)")
+    r = IncrementalRunner(net, meta_valloader, base_val_loader, opt, base_support_loader, novel_inits, memory_picks,
+                          epochs_per_sync, reuse_features, verbose).start()
+    for idx in range(r.iter_num):
+        r.run_session(idx)
+    return r.finish()

@@ -122,9 +122,9 @@ def test_conv_fwd_epilogue(case, dtype):
     y = torch.full((B * Ho * Wo * Cout,), float("nan"), dtype=torch.bfloat16 if dtype == "bf16" else torch.float32, device=_dev())
     flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0)
     rd = _nhwc_dev(res, dtype) if use_res else None
-    _lib.check(lib.subreg_conv_fwd(_lib.ptr(_nhwc_dev(x, dtype)), _lib.ptr(_pack_w(w, dtype)), _lib.ptr(y), _lib.ptr(_t(scale)),
-                                   _lib.ptr(_t(shift)), _lib.ptr(rd), None, B, H, W, Cin, Cout, k, flags,
-                                   _lib.dtype_code(dtype), _lib.stream_ptr()), "conv_fwd")
+    xd, wd, scd, shd = _nhwc_dev(x, dtype), _pack_w(w, dtype), _t(scale), _t(shift)   # keep the device buffers alive
+    _lib.check(lib.subreg_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), _lib.ptr(scd), _lib.ptr(shd), _lib.ptr(rd), None,
+                                   B, H, W, Cin, Cout, k, flags, _lib.dtype_code(dtype), _lib.stream_ptr()), "conv_fwd")
     got = _nchw_host(y, B, Cout, Ho, Wo, dtype)
     a, r = _tol(dtype, np.abs(want).max())
     _cmp("conv", got, rr._nchw(want), a, r)
@@ -150,11 +150,12 @@ def test_conv_raw_stats_and_bn_train(shape, dtype):
     rows = lib.subreg_conv_stats_rows(dt, B, H, W, Cout)
     stats = torch.zeros(rows * Cout * 2, dtype=torch.float32, device=_dev())
     y = torch.empty(B * H * W * Cout, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32, device=_dev())
-    _lib.check(lib.subreg_conv_fwd(_lib.ptr(_nhwc_dev(x, dtype)), _lib.ptr(_pack_w(w, dtype)), _lib.ptr(y), None, None, None,
+    xd, wd = _nhwc_dev(x, dtype), _pack_w(w, dtype)                                   # keep the device buffers alive
+    _lib.check(lib.subreg_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), None, None, None,
                                    _lib.ptr(stats), B, H, W, Cin, Cout, k, _lib.CONV_RAW_STATS, dt, _lib.stream_ptr()))
-    drm, drv = _t(rm), _t(rv)
+    drm, drv, gwd, gbd = _t(rm), _t(rv), _t(gw), _t(gb)
     sc, sh = torch.empty(Cout, device=_dev()), torch.empty(Cout, device=_dev())
-    _lib.check(lib.subreg_bn_train_finalize(_lib.ptr(stats), rows, Cout, B * H * W, _lib.ptr(_t(gw)), _lib.ptr(_t(gb)),
+    _lib.check(lib.subreg_bn_train_finalize(_lib.ptr(stats), rows, Cout, B * H * W, _lib.ptr(gwd), _lib.ptr(gbd),
                                             _lib.ptr(drm), _lib.ptr(drv), 0.1, 1e-5, _lib.ptr(sc), _lib.ptr(sh),
                                             _lib.stream_ptr()))
     _lib.check(lib.subreg_bn_apply(_lib.ptr(y), _lib.ptr(sc), _lib.ptr(sh), None, None, None, None, 1.0, _lib.ptr(y), B, H, W,
