@@ -52,17 +52,24 @@ const char* subreg_strerror(int code);
 /* First layer (Cin = 3): x NCHW fp32 [B,3,H,W] -> im2col rows [B*H*W][32], k = 3*(3*ky+kx)+c, zero padded.
  * Turns models/resnet_language.py:249 (conv1 of layer1.0) and :146 (its 1x1 shortcut) into K=32 GEMMs. */
 int subreg_pack_input(const float* x_nchw, void* col, int B, int H, int W, int dtype, void* stream);
-/* Conv2d.weight OIHW fp32 -> [Cout][k*k][Cin] (mode 0) or the K=32 first-layer layout (mode 1, Cin == 3). */
-int subreg_pack_conv_weight(const float* w_oihw, void* out, int Cout, int Cin, int ksize, int mode, int dtype, void* stream);
+/* Conv2d.weight OIHW fp32 -> [Cout][k*k][Cin] (mode 0) or the K=32 first-layer layout (mode 1, Cin == 3);
+ * fold_scale [Cout] (may be NULL) multiplies output channel o by fold_scale[o] (eval-mode BN scale folded in). */
+int subreg_pack_conv_weight(const float* w_oihw, const float* fold_scale, void* out, int Cout, int Cin, int ksize, int mode,
+                            int dtype, void* stream);
+/* identity weights [C][C] for the identity-shortcut GEMM (layer3.1 / layer4.1, resnet_language.py:271,288) */
+int subreg_pack_identity(void* out, int C, int dtype, void* stream);
+int subreg_vec_add(float* dst, const float* a, const float* b, int n, void* stream);
 int subreg_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, int dtype, void* stream);
 int subreg_nhwc_to_nchw(const void* x_nhwc, float* y_nchw, int B, int C, int H, int W, int dtype, void* stream);
 
 /* ---- convolution: replaces nn.Conv2d (conv3x3 :402-405, 1x1 shortcut :146-147) + fused epilogue -------- */
-/* y = [pool2]( [lrelu]( conv(x,w)*scale + shift [+ residual] ) ), or with SUBREG_CONV_RAW_STATS: y = conv(x,w) and
- * stats_partial[rows][Cout][2] (rows = subreg_conv_stats_rows).  Cin, Cout multiples of 32; ksize 1 or 3. */
+/* y = [pool2]( [lrelu]( (conv(x,w) + x2*w2^T) * scale + shift [+ residual] ) ), or with SUBREG_CONV_RAW_STATS:
+ * y = conv(x,w) and stats_partial[rows][Cout][2] (rows = subreg_conv_stats_rows).  scale == NULL: already folded into
+ * the packed weights.  (x2 [B*H*W][Cin2], w2 [Cout][Cin2]) is the fused shortcut GEMM of BasicBlock.forward :286-288
+ * (1x1 conv+BN, or the identity with w2 = I); x2 == NULL: none.  Cin, Cin2, Cout multiples of 32; ksize 1 or 3. */
 int subreg_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* shift, const void* residual,
-                    float* stats_partial, int B, int H, int W, int Cin, int Cout, int ksize, int flags, int dtype,
-                    void* stream);
+                    float* stats_partial, const void* x2, const void* w2, int Cin2, int B, int H, int W, int Cin, int Cout,
+                    int ksize, int flags, int dtype, void* stream);
 int subreg_conv_stats_rows(int dtype, int B, int H, int W, int Cout);
 
 /* ---- BatchNorm2d (:148,250,253,255) -------------------------------------------------------------------- */
@@ -88,7 +95,9 @@ int subreg_avgpool(const void* x, float* feat, int B, int H, int W, int C, int d
 
 /* ---- whole backbone: ResNet.forward up to `feat` (:170-182), BasicBlock.forward (:268-301) ------------- */
 typedef struct subreg_conv_desc {
-    const void* w;            /* packed weight in the compute dtype; NULL = absent (identity shortcut) */
+    const void* w;            /* packed RAW weight in the compute dtype (train mode); NULL = absent (identity shortcut) */
+    const void* w_folded;     /* packed weight * eval-mode BN scale (eval mode), refreshed by subreg_backbone_fold */
+    const float* w_oihw;      /* the fp32 Conv2d.weight the two packed copies are made from */
     const float* bn_weight;   /* [cout] */
     const float* bn_bias;     /* [cout] */
     float* running_mean;      /* [cout] updated in train mode */
@@ -96,10 +105,13 @@ typedef struct subreg_conv_desc {
     float* scale;             /* [cout] folded (eval) / batch (train) scale, written by the library */
     float* shift;             /* [cout] */
     int cin, cout, ksize;     /* as the kernel sees them (first layer: cin 32, ksize 1 over the im2col rows) */
+    int cin_raw, ksize_raw;   /* Conv2d shape (3 / 3x3 for the first layer) */
 } subreg_conv_desc;
 
 typedef struct subreg_block_desc {
     subreg_conv_desc conv1, conv2, conv3, down;
+    const void* w_identity;         /* [cout][cout] identity (subreg_pack_identity) for an identity shortcut, else NULL */
+    float* shift3;                  /* [cout] conv3 epilogue shift: bn3 shift + shortcut-BN shift, written by the fold */
     int stride;                     /* 2: MaxPool2d(2); 1: identity */
     const unsigned char* keep_mask; /* train: NHWC u8 keep mask of the block output, NULL = keep all */
     float mask_scale;               /* 1/(1-p) for dropout, countM/count_ones for DropBlock */
@@ -117,7 +129,8 @@ typedef struct subreg_backbone_desc {
 
 long long subreg_backbone_ws_bytes(const subreg_backbone_desc* d, int B, int H, int W);
 long long subreg_backbone_stats_floats(const subreg_backbone_desc* d, int B, int H, int W);
-/* eval: fold every BN's running stats into scale/shift (call after the stats changed) */
+/* (re)pack every conv weight: the raw copy, and the copy with the eval-mode BN scale folded in; writes shift[].
+ * Call after the weights or the BN statistics changed. */
 int subreg_backbone_fold(const subreg_backbone_desc* d, void* stream);
 /* x NCHW fp32 [B,3,H,W] -> feat fp32 [B][C_last].  stage_out[i] (optional, may be NULL) receives block i's
  * output as NCHW fp32 (is_feat=True, :189-190). */

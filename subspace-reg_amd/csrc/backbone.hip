@@ -16,21 +16,26 @@ inline size_t elem_size(int dtype) { return dtype == SUBREG_BF16 ? 2 : 4; }
 // first block consumes the K=32 im2col rows
 inline bool packed_first(const subreg_backbone_desc* d) { return d->blocks[0].conv1.ksize == 1 && d->blocks[0].conv1.cin == 32; }
 
-int fold_one(const subreg_conv_desc& c, float eps, void* stream) {
-    if (!c.w) return SUBREG_OK;
-    return subreg_bn_fold(c.bn_weight, c.bn_bias, c.running_mean, c.running_var, c.scale, c.shift, c.cout, eps, stream);
-}
-
 #define TRY(expr)                        \
     do {                                 \
         const int _rc = (expr);          \
         if (_rc != SUBREG_OK) return _rc; \
     } while (0)
 
+// eval-mode scale/shift of one BN, then both packed copies of its conv: raw (train mode) and scale-folded (eval mode)
+int fold_one(const subreg_conv_desc& c, float eps, int dtype, void* stream) {
+    if (!c.w) return SUBREG_OK;
+    TRY(subreg_bn_fold(c.bn_weight, c.bn_bias, c.running_mean, c.running_var, c.scale, c.shift, c.cout, eps, stream));
+    const int mode = (c.cin_raw == 3) ? 1 : 0;
+    TRY(subreg_pack_conv_weight(c.w_oihw, nullptr, const_cast<void*>(c.w), c.cout, c.cin_raw, c.ksize_raw, mode, dtype, stream));
+    return subreg_pack_conv_weight(c.w_oihw, c.scale, const_cast<void*>(c.w_folded), c.cout, c.cin_raw, c.ksize_raw, mode, dtype,
+                                   stream);
+}
+
 // train mode: raw conv + partial stats + finalize (scale/shift of THIS batch, running stats updated)
 int conv_train(const subreg_backbone_desc* d, const subreg_conv_desc& c, const void* x, void* raw, int B, int H, int W,
                void* stream) {
-    TRY(subreg_conv_fwd(x, c.w, raw, nullptr, nullptr, nullptr, d->stats, B, H, W, c.cin, c.cout, c.ksize,
+    TRY(subreg_conv_fwd(x, c.w, raw, nullptr, nullptr, nullptr, d->stats, nullptr, nullptr, 0, B, H, W, c.cin, c.cout, c.ksize,
                         SUBREG_CONV_RAW_STATS, d->dtype, stream));
     const int rows = subreg_conv_stats_rows(d->dtype, B, H, W, c.cout);
     return subreg_bn_train_finalize(d->stats, rows, c.cout, (long long)B * H * W, c.bn_weight, c.bn_bias, c.running_mean,
@@ -80,10 +85,14 @@ extern "C" int subreg_backbone_fold(const subreg_backbone_desc* d, void* stream)
     SUBREG_CHECK_ARG(d && d->blocks && d->n_blocks > 0);
     for (int i = 0; i < d->n_blocks; ++i) {
         const subreg_block_desc& b = d->blocks[i];
-        TRY(fold_one(b.conv1, d->bn_eps, stream));
-        TRY(fold_one(b.conv2, d->bn_eps, stream));
-        TRY(fold_one(b.conv3, d->bn_eps, stream));
-        TRY(fold_one(b.down, d->bn_eps, stream));
+        TRY(fold_one(b.conv1, d->bn_eps, d->dtype, stream));
+        TRY(fold_one(b.conv2, d->bn_eps, d->dtype, stream));
+        TRY(fold_one(b.conv3, d->bn_eps, d->dtype, stream));
+        TRY(fold_one(b.down, d->bn_eps, d->dtype, stream));
+        SUBREG_CHECK_ARG(b.shift3 != nullptr);
+        if (b.down.w) TRY(subreg_vec_add(b.shift3, b.conv3.shift, b.down.shift, b.conv3.cout, stream));   // one epilogue shift
+        else TRY(hipMemcpyAsync(b.shift3, b.conv3.shift, sizeof(float) * b.conv3.cout, hipMemcpyDeviceToDevice,
+                                (hipStream_t)stream) == hipSuccess ? SUBREG_OK : SUBREG_EHIP);
     }
     return SUBREG_OK;
 }
@@ -115,18 +124,18 @@ extern "C" int subreg_backbone_forward(const subreg_backbone_desc* d, const floa
         const int pflag = pool ? SUBREG_CONV_POOL2 : 0;
         int out_slot;
         if (!train) {
-            TRY(subreg_conv_fwd(cur, b.conv1.w, A, b.conv1.scale, b.conv1.shift, nullptr, nullptr, B, h, w, b.conv1.cin,
-                                b.conv1.cout, b.conv1.ksize, SUBREG_CONV_LRELU, dt, stream));
-            TRY(subreg_conv_fwd(A, b.conv2.w, Bf, b.conv2.scale, b.conv2.shift, nullptr, nullptr, B, h, w, b.conv2.cin,
-                                b.conv2.cout, b.conv2.ksize, SUBREG_CONV_LRELU, dt, stream));
-            const void* res = cur;
-            if (b.down.w) {
-                TRY(subreg_conv_fwd(cur, b.down.w, C, b.down.scale, b.down.shift, nullptr, nullptr, B, h, w, b.down.cin,
-                                    b.down.cout, b.down.ksize, 0, dt, stream));
-                res = C;
-            }
-            TRY(subreg_conv_fwd(Bf, b.conv3.w, A, b.conv3.scale, b.conv3.shift, res, nullptr, B, h, w, b.conv3.cin,
-                                b.conv3.cout, b.conv3.ksize, SUBREG_CONV_LRELU | pflag, dt, stream));
+            // BN scale is folded into the packed weights; conv3 accumulates the shortcut branch (1x1 conv+BN, or the
+            // identity) as a second GEMM over the block input, so no separate shortcut tensor is written or re-read
+            TRY(subreg_conv_fwd(cur, b.conv1.w_folded, A, nullptr, b.conv1.shift, nullptr, nullptr, nullptr, nullptr, 0, B, h, w,
+                                b.conv1.cin, b.conv1.cout, b.conv1.ksize, SUBREG_CONV_LRELU, dt, stream));
+            TRY(subreg_conv_fwd(A, b.conv2.w_folded, Bf, nullptr, b.conv2.shift, nullptr, nullptr, nullptr, nullptr, 0, B, h, w,
+                                b.conv2.cin, b.conv2.cout, b.conv2.ksize, SUBREG_CONV_LRELU, dt, stream));
+            const void* w2 = b.down.w ? b.down.w_folded : b.w_identity;
+            const int cin2 = b.down.w ? b.down.cin : b.conv3.cout;
+            SUBREG_CHECK_ARG(w2 != nullptr);
+            TRY(subreg_conv_fwd(Bf, b.conv3.w_folded, A, nullptr, b.shift3, nullptr, nullptr, cur, w2, cin2, B, h, w,
+                                b.conv3.cin, b.conv3.cout, b.conv3.ksize, SUBREG_CONV_LRELU | pflag, dt, stream));
+            (void)C;
             out_slot = fs[0];
         } else {
             TRY(conv_train(d, b.conv1, cur, A, B, h, w, stream));

@@ -2,11 +2,13 @@
 //
 // Replaces the cuDNN calls behind models/resnet_language.py:402-405 (conv3x3),
 // :146-147 (1x1 shortcut conv) and fuses what follows them in
-// BasicBlock.forward (:268-301): eval-mode BatchNorm (:250,253,255 as a folded
-// per-channel scale/shift), the residual add (:288), LeakyReLU(0.1) (:251,289)
-// and MaxPool2d(2) (:256,290).  In train mode (epoch 1 of every session,
+// BasicBlock.forward (:268-301): eval-mode BatchNorm (:250,253,255; the scale is
+// folded into the packed weights, the shift is added in the epilogue), the
+// shortcut branch (:286-288; the 1x1 conv+BN or the identity is a SECOND GEMM
+// accumulated into the same MFMA tiles), LeakyReLU(0.1) (:251,289) and
+// MaxPool2d(2) (:256,290).  In train mode (epoch 1 of every session,
 // eval/language_eval.py:211) it writes the raw convolution and per-channel
-// partial sums for the batch statistics instead (bn_train.hip finishes the job).
+// partial sums for the batch statistics instead (elementwise.hip finishes it).
 //
 // Data layout: activations compact NHWC [B*H*W][C]; weights [Cout][tap][Cin]
 // (tap = 3*ky+kx), both in the compute type T (bf16 or f32).  One workgroup
@@ -16,6 +18,9 @@
 // a tap is a constant row offset, image borders are handled by pointing the
 // lane's LDS address at a zero row.  LDS rows are 32 channels (64 B bf16 / 128 B
 // f32), XOR-swizzled per conv_index.h so that ds_read_b128 is conflict-free.
+// Staging is LDS-DMA (global_load_lds_dwordx4: lane-linear LDS image, the swizzle
+// is applied to the per-lane SOURCE address): the patch is double-buffered one
+// chunk ahead, the per-tap weight tile one step ahead, one barrier per step.
 //   bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate      (throughput mode)
 //   f32 : v_mfma_f32_32x32x2_f32, bitwise an fmaf chain  (parity mode, 1e-4 gate)
 #include "conv_index.h"
@@ -34,13 +39,15 @@ template <> struct KT<float> {
 struct ConvArgs {
     const char* x;       // [npix][Cin] T
     const char* w;       // [Cout][taps][Cin] T
+    const char* x2;      // fused shortcut GEMM: [npix][Cin2] T (centre tap only) or null
+    const char* w2;      // [Cout][Cin2] T
     char* y;             // LINEAR [npix][Cout] T ; POOL [B*Hp*Wp][Cout] T
-    const float* scale;  // [Cout] folded BN scale (null when raw)
+    const float* scale;  // [Cout] or null (scale folded into the weights)
     const float* shift;  // [Cout]
     const char* res;     // [npix][Cout] T residual or null
     float* stats;        // raw: [gridDim.x*WAVES_M][Cout][2] partial (sum, sumsq)
     ConvGeom g;
-    int Cin, Cout;
+    int Cin, Cin2, Cout;
     int act;             // LeakyReLU(0.1) after scale/shift/residual
     int raw;             // write the un-normalised conv + stats partials
 };
@@ -63,19 +70,29 @@ __device__ __forceinline__ void mma_step<float>(const uint4& a, const uint4& b, 
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], acc, 0, 0, 0);
 }
 
+// one 1-KiB LDS-DMA piece: 64 lanes x 16 B, LDS image lane-linear from the wave-uniform `lds_off`
+__device__ __forceinline__ void dma16(const char* src, char* smem, int lds_off) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
+}
+
 // NI x NJ 32x32 accumulator tiles per wave; WAVES_M x WAVES_N waves per workgroup.
 template <typename T, int NI, int NJ, int WAVES_M, int WAVES_N, int TAPS, bool POOL, int AROWS>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2 * WAVES_M * WAVES_N / 4) void conv_fwd_kernel(const ConvArgs a) {
     using K = KT<T>;
-    constexpr int NT = WAVES_M * WAVES_N * 64;
+    constexpr int NW = WAVES_M * WAVES_N;
     constexpr int TM = WAVES_M * NI * 32, TN = WAVES_N * NJ * 32;
     constexpr int SLOTS = K::SLOTS, ROWB = K::ROWB, ELEM = K::ELEM;
-    constexpr int A_BYTES = (AROWS + 1) * ROWB;        // + one zero row for padded taps
+    constexpr int RPP = 1024 / ROWB;                     // rows per 1-KiB DMA piece (16 bf16 / 8 f32)
+    constexpr int ABUF = (AROWS + 1) * ROWB;             // one patch buffer + its zero row
+    constexpr int BBUF = TN * ROWB;
+    constexpr int B_BASE = 2 * ABUF;
+    constexpr int CENTER = TAPS / 2;
+    static_assert(AROWS % RPP == 0 && TN % RPP == 0, "DMA pieces must tile the buffers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const sA = smem;
-    char* const sB = smem + A_BYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wid / WAVES_N, wave_n = wid % WAVES_N;
     const int lr = lane & 31, lh = lane >> 5;
     const ConvGeom g = a.g;
@@ -84,9 +101,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2 * WAVES_M * WAVES_N / 4) v
     int plo, phi;
     patch_range<POOL>(g, m0, TM, &plo, &phi);
     const int prow = phi - plo;
+    const int apieces = (prow + RPP - 1) / RPP;
 
-    // zero row (index AROWS) for taps that fall outside the image / rows beyond M
-    if (tid < ROWB / 16) *reinterpret_cast<uint4*>(sA + AROWS * ROWB + tid * 16) = make_uint4(0, 0, 0, 0);
+    // zero rows (index AROWS of each patch buffer) for taps outside the image / rows beyond M
+    if (tid < 2 * (ROWB / 16)) {
+        const int b = tid / (ROWB / 16), q = tid % (ROWB / 16);
+        *reinterpret_cast<uint4*>(smem + b * ABUF + AROWS * ROWB + q * 16) = make_uint4(0, 0, 0, 0);
+    }
 
     // per-lane LDS addresses of this lane's A rows for every tap (k-step 0; k-step s is addr ^ 32*s)
     int aaddr[NI][TAPS];
@@ -109,7 +130,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2 * WAVES_M * WAVES_N / 4) v
     for (int j = 0; j < NJ; ++j) {
         const int nl = (wave_n * NJ + j) * 32 + lr;
         const int f = swz<SLOTS>(nl);
-        baddr[j] = A_BYTES + nl * ROWB + 32 * (f >> 1) + 16 * (lh ^ (f & 1));
+        baddr[j] = B_BASE + nl * ROWB + 32 * (f >> 1) + 16 * (lh ^ (f & 1));
     }
 
     f32x16 acc[NI][NJ];
@@ -120,46 +141,75 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2 * WAVES_M * WAVES_N / 4) v
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const size_t xrow = (size_t)a.Cin * ELEM;             // bytes per pixel row of x
-    const size_t wrow = (size_t)TAPS * a.Cin * ELEM;      // bytes per output channel of w
-    const int nchunks = a.Cin / 32;
-    for (int c = 0; c < nchunks; ++c) {
-        __syncthreads();   // everyone is done reading the previous chunk's patch / last tap's weights
-        {
-            const char* src = a.x + (size_t)plo * xrow + (size_t)c * 32 * ELEM;
-#pragma unroll 4
-            for (int idx = tid; idx < prow * SLOTS; idx += NT) {
-                const int row = idx / SLOTS, slot = idx % SLOTS;
-                const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)row * xrow + slot * 16);
-                *reinterpret_cast<uint4*>(sA + row * ROWB + ((slot ^ swz<SLOTS>(row)) << 4)) = v;
+    // ---- staging (LDS-DMA).  Lane l of a piece writes LDS row 16q + l/SLOTS, physical slot l%SLOTS, so it must
+    //      FETCH logical slot (l%SLOTS) ^ swz(row): the swizzle lives on the source address (rule 21).
+    const int prl = lane / SLOTS, psl = lane % SLOTS;            // row within a piece, physical slot
+    auto stage_patch = [&](const char* xsrc, int cin, int chunk, int buf) {
+        const size_t xrow = (size_t)cin * ELEM;
+        const char* base = xsrc + (size_t)plo * xrow + (size_t)chunk * 32 * ELEM;
+        for (int q = wid; q < apieces; q += NW) {
+            int row = q * RPP + prl;
+            const int srow = row < prow ? row : prow - 1;            // tail rows of the last piece: any valid source
+            dma16(base + (size_t)srow * xrow + ((psl ^ swz<SLOTS>(row)) << 4), smem, buf * ABUF + q * 1024);
+        }
+    };
+    auto stage_w = [&](const char* wsrc, int cin, int taps, int chunk, int tap, int buf) {
+        const size_t wrow = (size_t)taps * cin * ELEM;
+        const char* base = wsrc + ((size_t)tap * cin + (size_t)chunk * 32) * ELEM;
+#pragma unroll
+        for (int q0 = 0; q0 < TN / RPP; q0 += NW) {
+            const int q = q0 + wid;
+            if (q < TN / RPP) {
+                const int row = q * RPP + prl;
+                int n = n0 + row;
+                n = n < a.Cout ? n : a.Cout - 1;                     // N tail: those output columns are never stored
+                dma16(base + (size_t)n * wrow + ((psl ^ swz<SLOTS>(row)) << 4), smem, B_BASE + buf * BBUF + q * 1024);
             }
         }
+    };
+
+    // ---- step list: phase 0 = the convolution (nch0 chunks x TAPS taps); phase 1 = the fused shortcut GEMM
+    //      (nch1 chunks, centre tap only).  Patch of chunk c lives in buffer c&1, weights of step s in buffer s&1.
+    const int nch0 = a.Cin / 32, nch1 = a.x2 ? a.Cin2 / 32 : 0;
+    const int nchunks = nch0 + nch1;
+    stage_patch(a.x, a.Cin, 0, 0);
+    stage_w(a.w, a.Cin, TAPS, 0, 0, 0);
+    __syncthreads();                                                  // emits vmcnt(0): DMA landed, zero rows visible
+    int step = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const bool ph1 = c >= nch0;
+        if (c + 1 < nchunks) {                                        // next chunk's patch, one whole chunk ahead
+            if (c + 1 < nch0) stage_patch(a.x, a.Cin, c + 1, (c + 1) & 1);
+            else stage_patch(a.x2, a.Cin2, c + 1 - nch0, (c + 1) & 1);
+        }
+        const int aoff = (c & 1) * ABUF;
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
-            if (t > 0) __syncthreads();   // previous tap's weights fully consumed
+            if (ph1 && t != CENTER) continue;
+            // prefetch the NEXT step's weight tile
             {
-                const char* src = a.w + (size_t)t * a.Cin * ELEM + (size_t)c * 32 * ELEM;
-#pragma unroll
-                for (int idx = tid; idx < TN * SLOTS; idx += NT) {
-                    const int row = idx / SLOTS, slot = idx % SLOTS;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (n0 + row < a.Cout) v = *reinterpret_cast<const uint4*>(src + (size_t)(n0 + row) * wrow + slot * 16);
-                    *reinterpret_cast<uint4*>(sB + row * ROWB + ((slot ^ swz<SLOTS>(row)) << 4)) = v;
+                const bool last_tap = ph1 || t == TAPS - 1;
+                const int nc = last_tap ? c + 1 : c;
+                if (nc < nchunks) {
+                    if (nc < nch0) stage_w(a.w, a.Cin, TAPS, nc, last_tap ? 0 : t + 1, (step + 1) & 1);
+                    else stage_w(a.w2, a.Cin2, 1, nc - nch0, 0, (step + 1) & 1);
                 }
             }
-            __syncthreads();
+            const int boff = (step & 1) * BBUF;
 #pragma unroll
             for (int s = 0; s < K::KSTEPS; ++s) {
                 uint4 fa[NI], fb[NJ];
 #pragma unroll
-                for (int i = 0; i < NI; ++i) fa[i] = *reinterpret_cast<const uint4*>(smem + (aaddr[i][t] ^ (32 * s)));
+                for (int i = 0; i < NI; ++i) fa[i] = *reinterpret_cast<const uint4*>(smem + aoff + (aaddr[i][t] ^ (32 * s)));
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const uint4*>(smem + (baddr[j] ^ (32 * s)));
+                for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const uint4*>(smem + boff + (baddr[j] ^ (32 * s)));
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) mma_step<T>(fa[i], fb[j], acc[i][j]);
             }
+            ++step;
+            __syncthreads();          // vmcnt(0) + barrier: next step's tiles landed, this step's reads are done
         }
     }
 
@@ -167,6 +217,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2 * WAVES_M * WAVES_N / 4) v
     // C layout of a 32x32 tile: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     T* const y = reinterpret_cast<T*>(a.y);
     const T* const res = reinterpret_cast<const T*>(a.res);
+    const bool full = m0 + TM <= g.M && n0 + TN <= a.Cout;            // no ragged edge in this tile
     if (a.raw) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -178,9 +229,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2 * WAVES_M * WAVES_N / 4) v
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mb + (r & 3) + 8 * (r >> 2);
-                    if (m < g.M && n < a.Cout) {
+                    if (full || (m < g.M && n < a.Cout)) {
                         const float v = acc[i][j][r];
-                        y[(size_t)m * a.Cout + n] = ElemTraits<T>::from_float(v);
+                        y[(unsigned)(m * a.Cout + n)] = ElemTraits<T>::from_float(v);
                         s1 += v;
                         s2 += v * v;
                     }
@@ -199,40 +250,41 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2 * WAVES_M * WAVES_N / 4) v
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + (wave_n * NJ + j) * 32 + lr;
-        const bool nv = n < a.Cout;
-        const float sc = nv ? a.scale[n] : 0.f, sh = nv ? a.shift[n] : 0.f;
+        const bool nv = full || n < a.Cout;
+        const float sc = (a.scale && nv) ? a.scale[n] : 1.f, sh = nv ? a.shift[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int mb = m0 + (wave_m * NI + i) * 32 + 4 * lh;
             if (!POOL) {
+                const unsigned obase = (unsigned)(mb * a.Cout + n);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    if (m < g.M && nv) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (full || (mb + dr < g.M && nv)) {
                         float v = acc[i][j][r] * sc + sh;
-                        if (res) v += ElemTraits<T>::to_float(res[(size_t)m * a.Cout + n]);
-                        if (a.act) v = lrelu(v);
-                        y[(size_t)m * a.Cout + n] = ElemTraits<T>::from_float(v);
+                        if (res) v += ElemTraits<T>::to_float(res[obase + (unsigned)(dr * a.Cout)]);
+                        if (a.act) v = fmaxf(v, v * 0.1f);            // LeakyReLU(0.1)
+                        y[obase + (unsigned)(dr * a.Cout)] = ElemTraits<T>::from_float(v);
                     }
                 }
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {          // register group q: rows mb + 8q + {0,1,2,3} == one 2x2 window
                     const int m = mb + 8 * q;
-                    if (m < g.M && nv) {
-                        const Pix px = row_to_pixel<true>(g, m);      // top-left pixel of the window
-                        float best = -3.0e38f;
-#pragma unroll
-                        for (int sub = 0; sub < 4; ++sub) {
-                            float v = acc[i][j][4 * q + sub] * sc + sh;
-                            if (res) {
-                                const size_t p = (size_t)px.p + (sub >> 1) * g.W + (sub & 1);
-                                v += ElemTraits<T>::to_float(res[p * a.Cout + n]);
-                            }
-                            best = fmaxf(best, v);
+                    if (full || (m < g.M && nv)) {
+                        float v0 = acc[i][j][4 * q] * sc + sh, v1 = acc[i][j][4 * q + 1] * sc + sh;
+                        float v2 = acc[i][j][4 * q + 2] * sc + sh, v3 = acc[i][j][4 * q + 3] * sc + sh;
+                        if (res) {
+                            const Pix px = row_to_pixel<true>(g, m);  // top-left pixel of the window
+                            const T* rp = res + (size_t)px.p * a.Cout + n;
+                            v0 += ElemTraits<T>::to_float(rp[0]);
+                            v1 += ElemTraits<T>::to_float(rp[a.Cout]);
+                            v2 += ElemTraits<T>::to_float(rp[(size_t)g.W * a.Cout]);
+                            v3 += ElemTraits<T>::to_float(rp[(size_t)(g.W + 1) * a.Cout]);
                         }
-                        if (a.act) best = lrelu(best);     // monotone => lrelu(max) == max(lrelu)
-                        y[(size_t)(m >> 2) * a.Cout + n] = ElemTraits<T>::from_float(best);
+                        float best = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                        if (a.act) best = fmaxf(best, best * 0.1f);  // monotone => lrelu(max) == max(lrelu)
+                        y[(unsigned)((m >> 2) * a.Cout + n)] = ElemTraits<T>::from_float(best);
                     }
                 }
             }
@@ -241,19 +293,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2 * WAVES_M * WAVES_N / 4) v
 }
 
 // ---------------------------------------------------------------------------- host side
+template <bool POOL>
+static int worst_patch_rows(const ConvGeom& g, int TM) {
+    int worst = 0;
+    for (int m0 = 0; m0 < g.M; m0 += TM) {
+        int lo, hi;
+        patch_range<POOL>(g, m0, TM, &lo, &hi);
+        if (hi - lo > worst) worst = hi - lo;
+    }
+    return worst;
+}
+
 template <typename T, int NI, int NJ, int WM, int WN, int TAPS, bool POOL, int AROWS>
 static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     using K = KT<T>;
     constexpr int TM = WM * NI * 32, TN = WN * NJ * 32;
-    // worst-case patch rows over all tiles must fit the LDS patch
-    int worst = 0;
-    for (int m0 = 0; m0 < a.g.M; m0 += TM) {
-        int lo, hi;
-        patch_range<POOL>(a.g, m0, TM, &lo, &hi);
-        if (hi - lo > worst) worst = hi - lo;
-    }
-    if (worst > AROWS) return SUBREG_EUNSUPPORTED;
-    const size_t lds = (size_t)(AROWS + 1) * K::ROWB + (size_t)TN * K::ROWB;
+    const size_t lds = 2 * (size_t)(AROWS + 1) * K::ROWB + 2 * (size_t)TN * K::ROWB;
     auto kern = conv_fwd_kernel<T, NI, NJ, WM, WN, TAPS, POOL, AROWS>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
@@ -267,19 +322,28 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     return launch_status();
 }
 
-template <typename T, int NI, int NJ, int WM, int WN, int AROWS>
+// AR_S / AR_L: small and large LDS patch capacities (rows); the small one keeps two workgroups per CU
+template <typename T, int NI, int NJ, int WM, int WN, int TAPS, bool POOL, int AR_S, int AR_L>
+static int launch_rows(const ConvArgs& a, hipStream_t s) {
+    if ((long long)a.g.M * a.Cout >= (1LL << 31) || (long long)a.g.npix * a.Cout >= (1LL << 31)) return SUBREG_EUNSUPPORTED;
+    const int worst = worst_patch_rows<POOL>(a.g, WM * NI * 32);
+    if (worst <= AR_S) return launch_cfg<T, NI, NJ, WM, WN, TAPS, POOL, AR_S>(a, s);
+    if (worst <= AR_L) return launch_cfg<T, NI, NJ, WM, WN, TAPS, POOL, AR_L>(a, s);
+    return SUBREG_EUNSUPPORTED;      // image too wide for the LDS patch
+}
+
+template <typename T, int NI, int NJ, int WM, int WN, int AR_S, int AR_L>
 static int launch_shape(const ConvArgs& a, bool pool, hipStream_t s) {
     if (a.g.taps == 9) {
-        return pool ? launch_cfg<T, NI, NJ, WM, WN, 9, true, AROWS>(a, s) : launch_cfg<T, NI, NJ, WM, WN, 9, false, AROWS>(a, s);
+        return pool ? launch_rows<T, NI, NJ, WM, WN, 9, true, AR_S, AR_L>(a, s) : launch_rows<T, NI, NJ, WM, WN, 9, false, AR_S, AR_L>(a, s);
     }
-    return pool ? launch_cfg<T, NI, NJ, WM, WN, 1, true, AROWS>(a, s) : launch_cfg<T, NI, NJ, WM, WN, 1, false, AROWS>(a, s);
+    return pool ? launch_rows<T, NI, NJ, WM, WN, 1, true, AR_S, AR_L>(a, s) : launch_rows<T, NI, NJ, WM, WN, 1, false, AR_S, AR_L>(a, s);
 }
 
 // rows of stats partials the raw mode writes for a given problem (caller sizes the buffer with this)
-static int stats_rows_for(int dtype, int Cout, int M) {
+static int stats_rows_for(int dtype, int M) {
     const int wm = dtype == SUBREG_BF16 ? 4 : 2;
     const int tm = wm * 2 * 32;
-    (void)Cout;
     return ((M + tm - 1) / tm) * wm;
 }
 
@@ -288,23 +352,26 @@ static int stats_rows_for(int dtype, int Cout, int M) {
 using namespace subreg;
 
 extern "C" int subreg_conv_stats_rows(int dtype, int B, int H, int W, int Cout) {
-    return stats_rows_for(dtype, Cout, B * H * W);
+    (void)Cout;
+    return stats_rows_for(dtype, B * H * W);
 }
 
 extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* shift,
-                               const void* residual, float* stats_partial, int B, int H, int W, int Cin, int Cout,
-                               int ksize, int flags, int dtype, void* stream) {
+                               const void* residual, float* stats_partial, const void* x2, const void* w2, int Cin2, int B,
+                               int H, int W, int Cin, int Cout, int ksize, int flags, int dtype, void* stream) {
     SUBREG_CHECK_ARG(x && w && y);
     SUBREG_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
     SUBREG_CHECK_ARG(ksize == 1 || ksize == 3);
     SUBREG_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0);
     SUBREG_CHECK_ARG(dtype == SUBREG_F32 || dtype == SUBREG_BF16);
     const bool raw = flags & SUBREG_CONV_RAW_STATS, pool = flags & SUBREG_CONV_POOL2;
-    SUBREG_CHECK_ARG(!(raw && (pool || residual)));
-    SUBREG_CHECK_ARG(raw ? stats_partial != nullptr : (scale && shift));
+    SUBREG_CHECK_ARG(!(raw && (pool || residual || x2)));
+    SUBREG_CHECK_ARG(raw ? stats_partial != nullptr : shift != nullptr);
     SUBREG_CHECK_ARG(!pool || (H >= 2 && W >= 2));
+    SUBREG_CHECK_ARG(!x2 || (w2 && Cin2 > 0 && Cin2 % 32 == 0));
     ConvArgs a;
     a.x = (const char*)x; a.w = (const char*)w; a.y = (char*)y;
+    a.x2 = (const char*)x2; a.w2 = (const char*)w2; a.Cin2 = x2 ? Cin2 : 0;
     a.scale = scale; a.shift = shift; a.res = (const char*)residual; a.stats = stats_partial;
     a.g = make_geom(B, H, W, ksize * ksize, pool);
     a.Cin = Cin; a.Cout = Cout;
@@ -312,8 +379,9 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
     a.raw = raw ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const bool wide = (Cout % 160 == 0);
+    // LDS per block = 2 patch buffers + 2 weight buffers; sized so that two blocks fit a CU (160 KiB)
     if (dtype == SUBREG_BF16) {
-        return wide ? launch_shape<__bf16, 2, 5, 4, 1, 704>(a, pool, s) : launch_shape<__bf16, 2, 2, 4, 1, 704>(a, pool, s);
+        return wide ? launch_shape<__bf16, 2, 5, 4, 1, 432, 560>(a, pool, s) : launch_shape<__bf16, 2, 2, 4, 1, 432, 560>(a, pool, s);
     }
-    return wide ? launch_shape<float, 2, 5, 2, 1, 448>(a, pool, s) : launch_shape<float, 2, 2, 2, 1, 448>(a, pool, s);
+    return wide ? launch_shape<float, 2, 5, 2, 1, 304, 408>(a, pool, s) : launch_shape<float, 2, 2, 2, 1, 304, 408>(a, pool, s);
 }

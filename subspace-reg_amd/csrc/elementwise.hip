@@ -42,14 +42,15 @@ __global__ void pack_input_kernel(const float* __restrict__ x, T* __restrict__ c
 // mode 0: OIHW f32 -> [Cout][k*k][Cin] T.
 // mode 1 (Cin == 3): -> [Cout][32] T over the im2col K axis (3x3: k = 3*tap + c; 1x1: centre tap 4).
 template <typename T>
-__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int ks, int mode) {
+__global__ void pack_weight_kernel(const float* __restrict__ w, const float* __restrict__ fold, T* __restrict__ out, int Cout,
+                                   int Cin, int ks, int mode) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int taps = ks * ks;
     if (mode == 0) {
         const size_t total = (size_t)Cout * taps * Cin;
         if (i >= total) return;
         const int c = i % Cin, t = (i / Cin) % taps, o = i / ((size_t)Cin * taps);
-        out[i] = ElemTraits<T>::from_float(w[((size_t)o * Cin + c) * taps + t]);
+        out[i] = ElemTraits<T>::from_float(w[((size_t)o * Cin + c) * taps + t] * (fold ? fold[o] : 1.f));
     } else {
         const size_t total = (size_t)Cout * 32;
         if (i >= total) return;
@@ -60,8 +61,20 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
             if (ks == 3) v = w[((size_t)o * 3 + c) * 9 + t];
             else if (t == 4) v = w[(size_t)o * 3 + c];
         }
-        out[i] = ElemTraits<T>::from_float(v);
+        out[i] = ElemTraits<T>::from_float(v * (fold ? fold[o] : 1.f));
     }
+}
+
+template <typename T>
+__global__ void pack_identity_kernel(T* __restrict__ out, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)C * C) return;
+    out[i] = ElemTraits<T>::from_float((i / C) == (i % C) ? 1.f : 0.f);
+}
+
+__global__ void vec_add_kernel(float* __restrict__ dst, const float* __restrict__ a, const float* __restrict__ b, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = a[i] + b[i];
 }
 
 // ---------------------------------------------------------------- layout conversion
@@ -98,19 +111,29 @@ __global__ void bn_fold_kernel(const float* __restrict__ weight, const float* __
 
 // ---------------------------------------------------------------- BN train-mode statistics
 // partial [rows][C][2] (sum, sumsq) -> batch mean / biased var -> scale/shift for this batch, and the
-// running-stat update (momentum, unbiased variance) in place.  One thread per channel, fixed summation
-// order in double => bitwise reproducible.
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
-                                   const float* __restrict__ weight, const float* __restrict__ bias,
-                                   float* __restrict__ rm, float* __restrict__ rv, float momentum, float eps,
-                                   float* __restrict__ scale, float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// running-stat update (momentum, unbiased variance) in place.  One 256-thread block per channel; per-thread
+// strided sums and a fixed-shape tree in double => bitwise reproducible.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
+                                                          const float* __restrict__ weight, const float* __restrict__ bias,
+                                                          float* __restrict__ rm, float* __restrict__ rv, float momentum,
+                                                          float eps, float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double r1[256], r2[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < rows; ++r) {
-        s1 += (double)partial[((size_t)r * C + c) * 2];
-        s2 += (double)partial[((size_t)r * C + c) * 2 + 1];
+    for (int r = tid; r < rows; r += 256) {
+        const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)r * C + c) * 2);
+        s1 += (double)v.x;
+        s2 += (double)v.y;
     }
+    r1[tid] = s1;
+    r2[tid] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { r1[tid] += r1[tid + o]; r2[tid] += r2[tid + o]; }
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    s1 = r1[0]; s2 = r2[0];
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -214,15 +237,30 @@ extern "C" int subreg_pack_input(const float* x_nchw, void* col, int B, int H, i
     return launch_status();
 }
 
-extern "C" int subreg_pack_conv_weight(const float* w_oihw, void* out, int Cout, int Cin, int ksize, int mode, int dtype,
-                                       void* stream) {
+extern "C" int subreg_pack_identity(void* out, int Cc, int dtype, void* stream) {
+    SUBREG_CHECK_ARG(out && Cc > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)Cc * Cc;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_identity_kernel<float>, ew_blocks(n), EW_THREADS, 0, s, (float*)out, Cc),
+               hipLaunchKernelGGL(pack_identity_kernel<__bf16>, ew_blocks(n), EW_THREADS, 0, s, (__bf16*)out, Cc));
+    return launch_status();
+}
+
+extern "C" int subreg_vec_add(float* dst, const float* a, const float* b, int n, void* stream) {
+    SUBREG_CHECK_ARG(dst && a && b && n > 0);
+    hipLaunchKernelGGL(vec_add_kernel, ew_blocks(n), EW_THREADS, 0, (hipStream_t)stream, dst, a, b, n);
+    return launch_status();
+}
+
+extern "C" int subreg_pack_conv_weight(const float* w_oihw, const float* fold_scale, void* out, int Cout, int Cin, int ksize,
+                                       int mode, int dtype, void* stream) {
     SUBREG_CHECK_ARG(w_oihw && out && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3));
     SUBREG_CHECK_ARG(mode == 0 || (mode == 1 && Cin == 3));
     hipStream_t s = (hipStream_t)stream;
     const size_t n = mode == 0 ? (size_t)Cout * ksize * ksize * Cin : (size_t)Cout * 32;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(pack_weight_kernel<float>, ew_blocks(n), EW_THREADS, 0, s, w_oihw, (float*)out, Cout, Cin, ksize, mode),
-               hipLaunchKernelGGL(pack_weight_kernel<__bf16>, ew_blocks(n), EW_THREADS, 0, s, w_oihw, (__bf16*)out, Cout, Cin, ksize, mode));
+               hipLaunchKernelGGL(pack_weight_kernel<float>, ew_blocks(n), EW_THREADS, 0, s, w_oihw, fold_scale, (float*)out, Cout, Cin, ksize, mode),
+               hipLaunchKernelGGL(pack_weight_kernel<__bf16>, ew_blocks(n), EW_THREADS, 0, s, w_oihw, fold_scale, (__bf16*)out, Cout, Cin, ksize, mode));
     return launch_status();
 }
 
@@ -257,7 +295,7 @@ extern "C" int subreg_bn_train_finalize(const float* stats_partial, int rows, in
                                         float eps, float* scale, float* shift, void* stream) {
     SUBREG_CHECK_ARG(stats_partial && weight && bias && running_mean && running_var && scale && shift);
     SUBREG_CHECK_ARG(rows > 0 && C > 0 && count > 0);
-    hipLaunchKernelGGL(bn_finalize_kernel, ew_blocks(C), EW_THREADS, 0, (hipStream_t)stream, stats_partial, rows, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, C, 256, 0, (hipStream_t)stream, stats_partial, rows, C,
                        (double)count, weight, bias, running_mean, running_var, momentum, eps, scale, shift);
     return launch_status();
 }

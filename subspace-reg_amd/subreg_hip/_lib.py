@@ -20,14 +20,16 @@ c_void_p, c_int, c_float, c_longlong = C.c_void_p, C.c_int, C.c_float, C.c_longl
 
 
 class ConvDesc(C.Structure):
-    _fields_ = [("w", c_void_p), ("bn_weight", c_void_p), ("bn_bias", c_void_p), ("running_mean", c_void_p),
-                ("running_var", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
-                ("cin", c_int), ("cout", c_int), ("ksize", c_int)]
+    _fields_ = [("w", c_void_p), ("w_folded", c_void_p), ("w_oihw", c_void_p), ("bn_weight", c_void_p),
+                ("bn_bias", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p), ("scale", c_void_p),
+                ("shift", c_void_p), ("cin", c_int), ("cout", c_int), ("ksize", c_int), ("cin_raw", c_int),
+                ("ksize_raw", c_int)]
 
 
 class BlockDesc(C.Structure):
     _fields_ = [("conv1", ConvDesc), ("conv2", ConvDesc), ("conv3", ConvDesc), ("down", ConvDesc),
-                ("stride", c_int), ("keep_mask", c_void_p), ("mask_scale", c_float)]
+                ("w_identity", c_void_p), ("shift3", c_void_p), ("stride", c_int), ("keep_mask", c_void_p),
+                ("mask_scale", c_float)]
 
 
 class BackboneDesc(C.Structure):
@@ -59,10 +61,12 @@ SIGNATURES = {
     "subreg_abi_version": (_I, []),
     "subreg_strerror": (C.c_char_p, [_I]),
     "subreg_pack_input": (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    "subreg_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "subreg_pack_conv_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "subreg_pack_identity": (_I, [_P, _I, _I, _P]),
+    "subreg_vec_add": (_I, [_P, _P, _P, _I, _P]),
     "subreg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "subreg_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "subreg_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "subreg_conv_stats_rows": (_I, [_I, _I, _I, _I, _I]),
     "subreg_bn_fold": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _P]),
     "subreg_bn_train_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P]),

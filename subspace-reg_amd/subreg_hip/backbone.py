@@ -81,45 +81,51 @@ class HipBackbone:
 
     def _alloc_static(self):
         dev = self.device
+        self._folded, self._ident, self._shift3 = {}, {}, []
         for bi, slot, cname, bname, cin, cout, k, first in self._convs():
             kin, kk = (32, 1) if first else (cin, k)
-            self._packed[cname] = torch.empty(cout * kk * kk * kin, dtype=self.tdtype, device=dev)
+            self._packed[cname] = torch.empty(cout * kk * kk * kin, dtype=self.tdtype, device=dev)   # raw (train mode)
+            self._folded[cname] = torch.empty(cout * kk * kk * kin, dtype=self.tdtype, device=dev)   # * BN scale (eval)
             self._scale[cname] = torch.empty(cout, dtype=torch.float32, device=dev)
             self._shift[cname] = torch.empty(cout, dtype=torch.float32, device=dev)
             cd = getattr(self._blk[bi], slot)
-            cd.cin, cd.cout, cd.ksize = kin, cout, kk
-        for bi, (name, _cin, _cout, stride, _ds, _db) in enumerate(self.blocks):
+            cd.cin, cd.cout, cd.ksize, cd.cin_raw, cd.ksize_raw = kin, cout, kk, cin, k
+        s = _lib.stream_ptr()
+        for bi, (name, _cin, cout, stride, ds, _db) in enumerate(self.blocks):
             self._blk[bi].stride = stride
             self._blk[bi].keep_mask = None
             self._blk[bi].mask_scale = 1.0
+            self._shift3.append(torch.empty(cout, dtype=torch.float32, device=dev))
+            self._blk[bi].shift3 = self._shift3[-1].data_ptr()
+            self._blk[bi].w_identity = None
+            if not ds:                         # identity shortcut: accumulated as a GEMM with I (resnet_language.py:271,288)
+                if cout not in self._ident:
+                    self._ident[cout] = torch.empty(cout * cout, dtype=self.tdtype, device=dev)
+                    _lib.check(self.lib.subreg_pack_identity(_lib.ptr(self._ident[cout]), cout, self.dtype, s), "pack_identity")
+                self._blk[bi].w_identity = self._ident[cout].data_ptr()
 
     def _bind_pointers(self):
         p = self.params
         for bi, slot, cname, bname, cin, cout, k, first in self._convs():
             cd = getattr(self._blk[bi], slot)
-            cd.w = self._packed[cname].data_ptr()
+            w = p[cname + ".weight"]
+            assert w.dtype == torch.float32 and w.is_contiguous()
+            cd.w, cd.w_folded, cd.w_oihw = self._packed[cname].data_ptr(), self._folded[cname].data_ptr(), w.data_ptr()
             cd.bn_weight, cd.bn_bias = p[bname + ".weight"].data_ptr(), p[bname + ".bias"].data_ptr()
             cd.running_mean, cd.running_var = p[bname + ".running_mean"].data_ptr(), p[bname + ".running_var"].data_ptr()
             cd.scale, cd.shift = self._scale[cname].data_ptr(), self._shift[cname].data_ptr()
 
     def refresh(self, force=False):
-        """Re-pack conv weights / re-fold BN if the module's tensors changed (tensor._version / data_ptr)."""
+        """Re-pack the conv weights (raw + BN-scale-folded) and re-fold BN if the module's tensors changed
+        (tensor._version / data_ptr)."""
         p = self.params
-        wv = tuple((p[c + ".weight"].data_ptr(), p[c + ".weight"]._version) for _, _, c, *_ in self._convs())
-        bv = tuple((p[b + s].data_ptr(), p[b + s]._version) for _, _, _, b, *_ in self._convs()
-                   for s in (".weight", ".bias", ".running_mean", ".running_var"))
-        s = _lib.stream_ptr()
-        if force or wv != self._versions:
-            for bi, slot, cname, bname, cin, cout, k, first in self._convs():
-                w = p[cname + ".weight"]
-                assert w.dtype == torch.float32 and w.is_contiguous()
-                _lib.check(self.lib.subreg_pack_conv_weight(_lib.ptr(w), _lib.ptr(self._packed[cname]), cout, cin, k,
-                                                            1 if first else 0, self.dtype, s), "pack_conv_weight")
-            self._versions = wv
-        if force or bv != self._fold_versions:
+        ver = tuple((p[c + ".weight"].data_ptr(), p[c + ".weight"]._version) for _, _, c, *_ in self._convs()) + \
+            tuple((p[b + s].data_ptr(), p[b + s]._version) for _, _, _, b, *_ in self._convs()
+                  for s in (".weight", ".bias", ".running_mean", ".running_var"))
+        if force or ver != self._fold_versions:
             self._bind_pointers()
-            _lib.check(self.lib.subreg_backbone_fold(C.byref(self._desc), s), "backbone_fold")
-            self._fold_versions = bv
+            _lib.check(self.lib.subreg_backbone_fold(C.byref(self._desc), _lib.stream_ptr()), "backbone_fold")
+            self._fold_versions = ver
 
     def _ensure_workspace(self, B, H, W):
         cb, ch, cw = self._cap
@@ -177,12 +183,15 @@ class HipBackbone:
             self._blk[bi].mask_scale = float(scale)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, train=False, masks=None, return_stages=False, out=None):
-        """x: [B,3,H,W] fp32 CUDA (NCHW like the reference) -> feat [B,out_dim] fp32."""
+    def forward(self, x, train=False, masks=None, return_stages=False, out=None, check_params=True):
+        """x: [B,3,H,W] fp32 CUDA (NCHW like the reference) -> feat [B,out_dim] fp32.
+        check_params=False skips the (host-side) scan for changed weights/BN tensors when the caller knows
+        nothing changed since the last forward (the fused loop's eval epochs)."""
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3
         x = x.contiguous()
         B, _, H, W = x.shape
-        self.refresh()
+        if check_params or self._fold_versions is None:
+            self.refresh()
         for i in range(len(self.nbt)):
             self.nbt[i] += 1
         feat = out if out is not None else torch.empty(B, self.out_dim, dtype=torch.float32, device=self.device)

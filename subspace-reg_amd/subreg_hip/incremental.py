@@ -88,12 +88,12 @@ class IncrementalRunner:
         self.images_forwarded = 0
 
     # ------------------------------------------------------------------ helpers
-    def _forward(self, x, train=False, out=None):
+    def _forward(self, x, train=False, out=None, check_params=True):
         net = self.net
         if self.profile:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        r = self.hb.forward(x, train=train, masks=net.mask_source if train else None, out=out)
+        r = self.hb.forward(x, train=train, masks=net.mask_source if train else None, out=out, check_params=check_params)
         if self.profile:
             e1.record()
             self.fwd_events.append((e0, e1, x.shape[0]))
@@ -235,7 +235,7 @@ class IncrementalRunner:
             executed = 0
             for e in range(k):
                 if not self.reuse_features or (done == 1 and e == 0):
-                    self._forward(all_x, out=feats)
+                    self._forward(all_x, out=feats, check_params=False)     # frozen backbone, nothing changed
                     executed += 1
                 step_and_validate()
             ran = int(ses.state.cpu()[0]) - done   # epochs that really advanced the loop

@@ -66,12 +66,13 @@ def _nchw_host(t, B, Cc, H, W, dtype):
     return out.cpu().numpy()
 
 
-def _pack_w(w_oihw, dtype):
+def _pack_w(w_oihw, dtype, fold=None):
     lib = _lib.load()
     O, I, k, _ = w_oihw.shape
     out = torch.empty(O * k * k * I, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32, device=_dev())
-    _lib.check(lib.subreg_pack_conv_weight(_lib.ptr(_t(w_oihw)), _lib.ptr(out), O, I, k, 0, _lib.dtype_code(dtype),
-                                           _lib.stream_ptr()))
+    fd = _t(fold) if fold is not None else None
+    _lib.check(lib.subreg_pack_conv_weight(_lib.ptr(_t(w_oihw)), _lib.ptr(fd), _lib.ptr(out), O, I, k, 0,
+                                           _lib.dtype_code(dtype), _lib.stream_ptr()))
     return out
 
 
@@ -124,10 +125,65 @@ def test_conv_fwd_epilogue(case, dtype):
     rd = _nhwc_dev(res, dtype) if use_res else None
     xd, wd, scd, shd = _nhwc_dev(x, dtype), _pack_w(w, dtype), _t(scale), _t(shift)   # keep the device buffers alive
     _lib.check(lib.subreg_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), _lib.ptr(scd), _lib.ptr(shd), _lib.ptr(rd), None,
-                                   B, H, W, Cin, Cout, k, flags, _lib.dtype_code(dtype), _lib.stream_ptr()), "conv_fwd")
+                                   None, None, 0, B, H, W, Cin, Cout, k, flags, _lib.dtype_code(dtype), _lib.stream_ptr()),
+               "conv_fwd")
     got = _nchw_host(y, B, Cout, Ho, Wo, dtype)
     a, r = _tol(dtype, np.abs(want).max())
     _cmp("conv", got, rr._nchw(want), a, r)
+
+
+FUSED_CASES = [
+    # B, H, W, Cin, Cout, Cin2 (0 = identity shortcut), pool      conv3 of every block type with its fused shortcut GEMM
+    (2, 84, 84, 64, 64, 32, True),       # layer1.0: shortcut = 1x1 conv over the K=32 im2col rows
+    (2, 42, 42, 160, 160, 64, True),     # layer2.0
+    (3, 21, 21, 320, 320, 160, True),    # layer3.0 (floor pooling)
+    (5, 10, 10, 320, 320, 0, False),     # layer3.1: identity shortcut as a GEMM with I
+    (5, 10, 10, 640, 640, 320, True),    # layer4.0
+    (7, 5, 5, 640, 640, 0, False),       # layer4.1
+    (2, 7, 9, 64, 96, 32, False),        # ragged N tail + ragged M
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", FUSED_CASES, ids=lambda c: "B%d_%dx%d_%d-%d_sc%d_p%d" % tuple(int(v) for v in c))
+def test_conv_folded_scale_and_fused_shortcut(case, dtype):
+    """Eval-mode conv3 as the backbone runs it: BN scale folded into the packed weights, the shortcut branch
+    accumulated as a second GEMM (x2 * w2^T), one shift, LeakyReLU, optional 2x2 max-pool."""
+    B, H, W, Cin, Cout, Cin2, pool = case
+    lib = _lib.load()
+    rs = np.random.RandomState(hash(case) % (2 ** 31))
+    x = rs.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rs.standard_normal((Cout, Cin, 3, 3)) * (1.4 / np.sqrt(Cin * 9))).astype(np.float32)
+    sc3 = rs.uniform(0.5, 1.5, Cout).astype(np.float32) * rs.choice([-1, 1], Cout).astype(np.float32)
+    shift = (rs.standard_normal(Cout) * 0.3).astype(np.float32)
+    ident = Cin2 == 0
+    c2 = Cout if ident else Cin2
+    x2 = rs.standard_normal((B, c2, H, W)).astype(np.float32)
+    w2 = np.eye(Cout, dtype=np.float32)[:, :, None, None] if ident else \
+        (rs.standard_normal((Cout, c2, 1, 1)) / np.sqrt(c2)).astype(np.float32)
+    sc2 = np.ones(Cout, np.float32) if ident else rs.uniform(0.5, 1.5, Cout).astype(np.float32)
+    wf, w2f = w * sc3[:, None, None, None], w2 * sc2[:, None, None, None]
+    if dtype == "bf16":            # compare against the operands the kernel really sees (fold, then round)
+        x, x2, wf, w2f = _round_bf16(x), _round_bf16(x2), _round_bf16(wf), _round_bf16(w2f)
+    want = rr.conv_nhwc(rr._nhwc(x).astype(np.float64), wf.astype(np.float64)) + \
+        rr.conv_nhwc(rr._nhwc(x2).astype(np.float64), w2f.astype(np.float64)) + shift
+    want = rr.maxpool_nhwc(rr.leaky_relu(want), 2 if pool else 1)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.full((B * Ho * Wo * Cout,), float("nan"), dtype=torch.bfloat16 if dtype == "bf16" else torch.float32, device=_dev())
+    xd, x2d, shd = _nhwc_dev(x, dtype), _nhwc_dev(x2, dtype), _t(shift)
+    wd = _pack_w(w, dtype, fold=sc3)
+    if ident:
+        w2d = torch.empty(Cout * Cout, dtype=y.dtype, device=_dev())
+        _lib.check(lib.subreg_pack_identity(_lib.ptr(w2d), Cout, _lib.dtype_code(dtype), _lib.stream_ptr()))
+    else:
+        w2d = _pack_w(w2, dtype, fold=sc2)
+    flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0)
+    _lib.check(lib.subreg_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), None, _lib.ptr(shd), None, None, _lib.ptr(x2d),
+                                   _lib.ptr(w2d), c2, B, H, W, Cin, Cout, 3, flags, _lib.dtype_code(dtype), _lib.stream_ptr()),
+               "conv_fwd(fused)")
+    got = _nchw_host(y, B, Cout, Ho, Wo, dtype)
+    a, r = _tol(dtype, np.abs(want).max())
+    _cmp("fused conv3", got, rr._nchw(want), a, r)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -151,8 +207,8 @@ def test_conv_raw_stats_and_bn_train(shape, dtype):
     stats = torch.zeros(rows * Cout * 2, dtype=torch.float32, device=_dev())
     y = torch.empty(B * H * W * Cout, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32, device=_dev())
     xd, wd = _nhwc_dev(x, dtype), _pack_w(w, dtype)                                   # keep the device buffers alive
-    _lib.check(lib.subreg_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), None, None, None,
-                                   _lib.ptr(stats), B, H, W, Cin, Cout, k, _lib.CONV_RAW_STATS, dt, _lib.stream_ptr()))
+    _lib.check(lib.subreg_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), None, None, None, _lib.ptr(stats), None, None, 0,
+                                   B, H, W, Cin, Cout, k, _lib.CONV_RAW_STATS, dt, _lib.stream_ptr()))
     drm, drv, gwd, gbd = _t(rm), _t(rv), _t(gw), _t(gb)
     sc, sh = torch.empty(Cout, device=_dev()), torch.empty(Cout, device=_dev())
     _lib.check(lib.subreg_bn_train_finalize(_lib.ptr(stats), rows, Cout, B * H * W, _lib.ptr(gwd), _lib.ptr(gbd),

@@ -44,7 +44,7 @@ def test_abi_version_and_strerror(built):
 def test_bad_arguments_return_einval_without_gpu(built):
     # argument validation happens before any HIP call, so it is testable on a CPU-only box
     built.subreg_conv_fwd.restype = ctypes.c_int
-    rc = built.subreg_conv_fwd(None, None, None, None, None, None, None, 1, 8, 8, 32, 32, 3, 0, 0, None)
+    rc = built.subreg_conv_fwd(None, None, None, None, None, None, None, None, None, 0, 1, 8, 8, 32, 32, 3, 0, 0, None)
     assert rc == -1
     built.subreg_subspace_basis.restype = ctypes.c_int
     assert built.subreg_subspace_basis(None, None, None, 60, 640, None, None) == -1
@@ -52,9 +52,9 @@ def test_bad_arguments_return_einval_without_gpu(built):
 
 def test_struct_layouts_match_c():
     # sizes computed by hand from include/subreg_hip.h on LP64
-    assert ctypes.sizeof(_lib.ConvDesc) == 7 * 8 + 3 * 4 + 4
+    assert ctypes.sizeof(_lib.ConvDesc) == 9 * 8 + 5 * 4 + 4
     assert ctypes.sizeof(_lib.LoopState) == 20
-    assert ctypes.sizeof(_lib.BlockDesc) == 4 * ctypes.sizeof(_lib.ConvDesc) + 8 + 8 + 8
+    assert ctypes.sizeof(_lib.BlockDesc) == 4 * ctypes.sizeof(_lib.ConvDesc) + 8 + 8 + 8 + 8 + 8
     assert _lib.StepDesc.weight.offset == 32 and _lib.StepDesc.n_base.offset == 72
 
 

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace CSV: per kernel (short name) and, for the conv kernels, per launch geometry
+(= per layer shape).  Usage: prof_summary.py <kernel_trace.csv> [--top N] [--conv]"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"^void\s+", "", name)
+    m = re.match(r"_ZN6subreg(\d+)([a-z_0-9]+)", name)
+    if m:
+        n = int(m.group(1))
+        tail = name[len("_ZN6subreg") + len(m.group(1)) + n:]
+        t = re.findall(r"Li(\d+)E|Lb([01])E|(DF16b|f(?=Li))", tail[:60])
+        return m.group(2)[:n] + "<" + ",".join(a or b or c for a, b, c in t) + ">"
+    name = re.sub(r"subreg::", "", name)
+    name = re.sub(r"\(.*", "", name)
+    return name[:70]
+
+
+def main():
+    path = sys.argv[1]
+    top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 25
+    per, geo = defaultdict(lambda: [0, 0.0]), defaultdict(lambda: [0, 0.0])
+    total = 0.0
+    for r in csv.DictReader(open(path)):
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+        n = short(r["Kernel_Name"])
+        per[n][0] += 1
+        per[n][1] += d
+        total += d
+        if "conv_fwd" in n:
+            wg = int(r["Workgroup_Size_X"])
+            k = (n, int(r["Grid_Size_X"]) // wg, int(r["Grid_Size_Y"]), r["VGPR_Count"], r["Accum_VGPR_Count"], r["LDS_Block_Size"])
+            geo[k][0] += 1
+            geo[k][1] += d
+    print("total kernel time %.1f ms" % (total * 1e-3))
+    for n, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:top]:
+        print("%-64s calls %6d  total %9.1f us  avg %9.1f us  %5.1f%%" % (n[:64], c, t, t / c, 100 * t / total))
+    if "--conv" in sys.argv:
+        print("\nconv launches by geometry (grid_m x grid_n, vgpr, agpr, lds):")
+        for k, (c, t) in sorted(geo.items(), key=lambda kv: -kv[1][1])[:40]:
+            print("%-44s grid %5dx%d v%s a%s lds%s calls %5d avg %9.1f us total %9.1f us" % (k[0][:44], k[1], k[2], k[3], k[4], k[5], c, t / c, t))
+
+
+if __name__ == "__main__":
+    main()
