@@ -70,25 +70,40 @@ __device__ __forceinline__ void mma_step<float>(const uint4& a, const uint4& b, 
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], acc, 0, 0, 0);
 }
 
-// one 1-KiB LDS-DMA piece: 64 lanes x 16 B, LDS image lane-linear from the wave-uniform `lds_off`
-__device__ __forceinline__ void dma16(const char* src, char* smem, int lds_off) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
+// one 1-KiB LDS-DMA piece: 64 lanes x 16 B, LDS image lane-linear from the wave-uniform LDS byte address `lds_addr`.
+// Issued from inline asm ON PURPOSE: for the builtin form hipcc (ROCm 7.2) inserts `s_waitcnt vmcnt(0)` in front of
+// the next ds_read of ANY LDS address, which drains the prefetch every step; asm DMAs are invisible to that pass, so
+// the counted `s_waitcnt vmcnt(N)` + `s_barrier` at the end of each step are the only (hand-placed) waits on them.
+// M0 (the DMA's LDS base) is compiler-reserved: save / set / restore inside the one statement.
+__device__ __forceinline__ void dma16(const char* src, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_addr)
+        : "memory");
 }
 
-// NI x NJ 32x32 accumulator tiles per wave; WAVES_M x WAVES_N waves per workgroup.
-template <typename T, int NI, int NJ, int WAVES_M, int WAVES_N, int TAPS, bool POOL, int AROWS>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2 * WAVES_M * WAVES_N / 4) void conv_fwd_kernel(const ConvArgs a) {
+// NI x NJ 32x32 accumulator tiles per wave; WAVES_M x WAVES_N waves per workgroup; TPS taps staged per step
+// (one barrier per step); MINW = minimum waves per SIMD the register allocation must allow.
+template <typename T, int NI, int NJ, int WAVES_M, int WAVES_N, int TAPS, int TPS, bool POOL, int AROWS, int MINW>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(const ConvArgs a) {
     using K = KT<T>;
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int TM = WAVES_M * NI * 32, TN = WAVES_N * NJ * 32;
     constexpr int SLOTS = K::SLOTS, ROWB = K::ROWB, ELEM = K::ELEM;
     constexpr int RPP = 1024 / ROWB;                     // rows per 1-KiB DMA piece (16 bf16 / 8 f32)
     constexpr int ABUF = (AROWS + 1) * ROWB;             // one patch buffer + its zero row
-    constexpr int BBUF = TN * ROWB;
+    constexpr int BTAP = TN * ROWB;                      // one tap's weight tile
+    constexpr int BBUF = TPS * BTAP;
     constexpr int B_BASE = 2 * ABUF;
     constexpr int CENTER = TAPS / 2;
-    static_assert(AROWS % RPP == 0 && TN % RPP == 0, "DMA pieces must tile the buffers");
+    constexpr int NG = TAPS / TPS;                       // tap groups (= steps) per chunk
+    static_assert(AROWS % RPP == 0 && TN % RPP == 0 && TAPS % TPS == 0, "DMA pieces must tile the buffers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -144,72 +159,116 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2 * WAVES_M * WAVES_N / 4) v
     // ---- staging (LDS-DMA).  Lane l of a piece writes LDS row 16q + l/SLOTS, physical slot l%SLOTS, so it must
     //      FETCH logical slot (l%SLOTS) ^ swz(row): the swizzle lives on the source address (rule 21).
     const int prl = lane / SLOTS, psl = lane % SLOTS;            // row within a piece, physical slot
-    auto stage_patch = [&](const char* xsrc, int cin, int chunk, int buf) {
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of smem
+    // piece group `grp` of a patch = pieces grp*NW .. grp*NW+NW-1, one per wave (the last group re-loads the last
+    // piece on the surplus waves so that every wave issues the same number of DMAs: counted vmcnt waits rely on it)
+    auto stage_patch_group = [&](const char* xsrc, int cin, int chunk, int buf, int grp) {
         const size_t xrow = (size_t)cin * ELEM;
         const char* base = xsrc + (size_t)plo * xrow + (size_t)chunk * 32 * ELEM;
-        for (int q = wid; q < apieces; q += NW) {
-            int row = q * RPP + prl;
-            const int srow = row < prow ? row : prow - 1;            // tail rows of the last piece: any valid source
-            dma16(base + (size_t)srow * xrow + ((psl ^ swz<SLOTS>(row)) << 4), smem, buf * ABUF + q * 1024);
-        }
+        int q = grp * NW + wid;
+        q = q < apieces ? q : apieces - 1;
+        const int row = q * RPP + prl;
+        const int srow = row < prow ? row : prow - 1;                // tail rows of the last piece: any valid source
+        dma16(base + (size_t)srow * xrow + ((psl ^ swz<SLOTS>(row)) << 4), lds_base + buf * ABUF + q * 1024);
     };
-    auto stage_w = [&](const char* wsrc, int cin, int taps, int chunk, int tap, int buf) {
+    const int agroups = (apieces + NW - 1) / NW;                     // piece groups of one patch
+    auto stage_patch = [&](const char* xsrc, int cin, int chunk, int buf) {
+        for (int grp = 0; grp < agroups; ++grp) stage_patch_group(xsrc, cin, chunk, buf, grp);
+    };
+    // weight tiles of `ntaps` consecutive taps starting at `tap` into weight buffer `buf`
+    auto stage_w = [&](const char* wsrc, int cin, int taps, int chunk, int tap, int ntaps, int buf) {
         const size_t wrow = (size_t)taps * cin * ELEM;
-        const char* base = wsrc + ((size_t)tap * cin + (size_t)chunk * 32) * ELEM;
+        for (int tt = 0; tt < ntaps; ++tt) {
+            const char* base = wsrc + ((size_t)(tap + tt) * cin + (size_t)chunk * 32) * ELEM;
 #pragma unroll
-        for (int q0 = 0; q0 < TN / RPP; q0 += NW) {
-            const int q = q0 + wid;
-            if (q < TN / RPP) {
-                const int row = q * RPP + prl;
-                int n = n0 + row;
-                n = n < a.Cout ? n : a.Cout - 1;                     // N tail: those output columns are never stored
-                dma16(base + (size_t)n * wrow + ((psl ^ swz<SLOTS>(row)) << 4), smem, B_BASE + buf * BBUF + q * 1024);
+            for (int q0 = 0; q0 < TN / RPP; q0 += NW) {
+                const int q = q0 + wid;
+                if (q < TN / RPP) {
+                    const int row = q * RPP + prl;
+                    int n = n0 + row;
+                    n = n < a.Cout ? n : a.Cout - 1;                 // N tail: those output columns are never stored
+                    dma16(base + (size_t)n * wrow + ((psl ^ swz<SLOTS>(row)) << 4),
+                          lds_base + B_BASE + buf * BBUF + tt * BTAP + q * 1024);
+                }
             }
         }
     };
 
-    // ---- step list: phase 0 = the convolution (nch0 chunks x TAPS taps); phase 1 = the fused shortcut GEMM
+    // ---- step list: phase 0 = the convolution (nch0 chunks x NG tap groups); phase 1 = the fused shortcut GEMM
     //      (nch1 chunks, centre tap only).  Patch of chunk c lives in buffer c&1, weights of step s in buffer s&1.
     const int nch0 = a.Cin / 32, nch1 = a.x2 ? a.Cin2 / 32 : 0;
     const int nchunks = nch0 + nch1;
     stage_patch(a.x, a.Cin, 0, 0);
-    stage_w(a.w, a.Cin, TAPS, 0, 0, 0);
-    __syncthreads();                                                  // emits vmcnt(0): DMA landed, zero rows visible
+    stage_w(a.w, a.Cin, TAPS, 0, 0, TPS, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's DMA landed ...
+    __syncthreads();                                                  // ... everyone's did; zero rows visible
+    // Patch of chunk c+1 is prefetched during chunk c, PA piece groups per step, issued AFTER the step's weight
+    // prefetch: LDS-DMA completes in issue order, so the end-of-step wait `vmcnt(groups issued this step)` covers
+    // the L2-resident weights of the next step but leaves the (HBM) patch pieces in flight for one more step.
+    constexpr int PA = (AROWS / RPP + NW * NG - 1) / (NW * NG);
     int step = 0;
     for (int c = 0; c < nchunks; ++c) {
         const bool ph1 = c >= nch0;
-        if (c + 1 < nchunks) {                                        // next chunk's patch, one whole chunk ahead
-            if (c + 1 < nch0) stage_patch(a.x, a.Cin, c + 1, (c + 1) & 1);
-            else stage_patch(a.x2, a.Cin2, c + 1 - nch0, (c + 1) & 1);
-        }
+        const bool more = c + 1 < nchunks;
+        const char* nx = (c + 1 < nch0) ? a.x : a.x2;
+        const int ncin = (c + 1 < nch0) ? a.Cin : a.Cin2, nck = (c + 1 < nch0) ? c + 1 : c + 1 - nch0;
         const int aoff = (c & 1) * ABUF;
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-            if (ph1 && t != CENTER) continue;
-            // prefetch the NEXT step's weight tile
+        for (int tg = 0; tg < NG; ++tg) {
+            if (ph1 && tg != 0) continue;
+            const bool last_grp = ph1 || tg == NG - 1;
+            // prefetch the NEXT step's weight tiles
             {
-                const bool last_tap = ph1 || t == TAPS - 1;
-                const int nc = last_tap ? c + 1 : c;
+                const int nc = last_grp ? c + 1 : c;
                 if (nc < nchunks) {
-                    if (nc < nch0) stage_w(a.w, a.Cin, TAPS, nc, last_tap ? 0 : t + 1, (step + 1) & 1);
-                    else stage_w(a.w2, a.Cin2, 1, nc - nch0, 0, (step + 1) & 1);
+                    if (nc < nch0) stage_w(a.w, a.Cin, TAPS, nc, last_grp ? 0 : (tg + 1) * TPS, TPS, (step + 1) & 1);
+                    else stage_w(a.w2, a.Cin2, 1, nc - nch0, 0, 1, (step + 1) & 1);
+                }
+            }
+            // ... then this step's share of the next chunk's patch
+            int issued = 0;
+            if (more) {
+                if (ph1) {
+                    for (int grp = 0; grp < agroups; ++grp) stage_patch_group(nx, ncin, nck, (c + 1) & 1, grp);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < PA; ++k) {
+                        const int grp = tg * PA + k;
+                        if (grp < agroups) { stage_patch_group(nx, ncin, nck, (c + 1) & 1, grp); ++issued; }
+                    }
                 }
             }
             const int boff = (step & 1) * BBUF;
 #pragma unroll
-            for (int s = 0; s < K::KSTEPS; ++s) {
-                uint4 fa[NI], fb[NJ];
+            for (int tt = 0; tt < TPS; ++tt) {
+                if (ph1 && tt != 0) continue;
 #pragma unroll
-                for (int i = 0; i < NI; ++i) fa[i] = *reinterpret_cast<const uint4*>(smem + aoff + (aaddr[i][t] ^ (32 * s)));
+                for (int s = 0; s < K::KSTEPS; ++s) {
+                    uint4 fa[NI], fb[NJ];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const uint4*>(smem + boff + (baddr[j] ^ (32 * s)));
+                    for (int i = 0; i < NI; ++i) {
+                        const int ad = ph1 ? aaddr[i][CENTER] : aaddr[i][tg * TPS + tt];
+                        fa[i] = *reinterpret_cast<const uint4*>(smem + aoff + (ad ^ (32 * s)));
+                    }
 #pragma unroll
-                for (int i = 0; i < NI; ++i)
+                    for (int j = 0; j < NJ; ++j)
+                        fb[j] = *reinterpret_cast<const uint4*>(smem + boff + tt * BTAP + (baddr[j] ^ (32 * s)));
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) mma_step<T>(fa[i], fb[j], acc[i][j]);
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) mma_step<T>(fa[i], fb[j], acc[i][j]);
+                }
             }
             ++step;
-            __syncthreads();          // vmcnt(0) + barrier: next step's tiles landed, this step's reads are done
+            // end of step: next step's weights landed (and, at a chunk boundary, the whole next patch); this wave's
+            // LDS reads are complete (their results fed the MFMAs); then the workgroup barrier
+            if (last_grp || issued == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (issued == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if (issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (issued == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -243,6 +302,45 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2 * WAVES_M * WAVES_N / 4) v
                 float* dst = a.stats + ((size_t)(blockIdx.x * WAVES_M + wave_m) * a.Cout + n) * 2;
                 dst[0] = s1;
                 dst[1] = s2;
+            }
+        }
+        return;
+    }
+    constexpr bool SLAB_FITS = NW * 32 * (NJ * 32 * ELEM + 16) <= 2 * ABUF + 2 * BBUF;   // epilogue slabs reuse the staging LDS
+    if constexpr (!POOL && SLAB_FITS) if (full && !res) {
+        // Full linear tile: stage each 32-row slab of this wave's tile through LDS ([row][channel], +16 B row pad) and
+        // write it back as whole 16-byte vectors, consecutive lanes on consecutive addresses of a pixel row.  (The
+        // direct path below needs one 2/4-byte store per accumulator register and dominated short-K layers.)
+        constexpr int TNW = NJ * 32, RS = TNW * ELEM + 16, VPR = TNW * ELEM / 16, NV = 32 * VPR;
+        char* const slab = smem + wid * (32 * RS);               // all waves are past the last step's barrier
+        float shj[NJ], scj[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + (wave_n * NJ + j) * 32 + lr;
+            shj[j] = a.shift[n];
+            scj[j] = a.scale ? a.scale[n] : 1.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] * scj[j] + shj[j];
+                    if (a.act) v = fmaxf(v, v * 0.1f);            // LeakyReLU(0.1)
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    *reinterpret_cast<T*>(slab + row * RS + (j * 32 + lr) * ELEM) = ElemTraits<T>::from_float(v);
+                }
+            const int mrow0 = m0 + (wave_m * NI + i) * 32;
+            char* const ybase = a.y + ((size_t)mrow0 * a.Cout + n0 + wave_n * TNW) * ELEM;
+#pragma unroll
+            for (int v0 = 0; v0 < NV; v0 += 64) {
+                const int v = v0 + lane;
+                if (NV % 64 == 0 || v < NV) {
+                    const int row = v / VPR, c16 = v % VPR;
+                    const uint4 val = *reinterpret_cast<const uint4*>(slab + row * RS + c16 * 16);
+                    *reinterpret_cast<uint4*>(ybase + (size_t)row * a.Cout * ELEM + c16 * 16) = val;
+                }
             }
         }
         return;
@@ -304,12 +402,12 @@ static int worst_patch_rows(const ConvGeom& g, int TM) {
     return worst;
 }
 
-template <typename T, int NI, int NJ, int WM, int WN, int TAPS, bool POOL, int AROWS>
+template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AROWS, int MINW>
 static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     using K = KT<T>;
     constexpr int TM = WM * NI * 32, TN = WN * NJ * 32;
-    const size_t lds = 2 * (size_t)(AROWS + 1) * K::ROWB + 2 * (size_t)TN * K::ROWB;
-    auto kern = conv_fwd_kernel<T, NI, NJ, WM, WN, TAPS, POOL, AROWS>;
+    const size_t lds = 2 * (size_t)(AROWS + 1) * K::ROWB + 2 * (size_t)TPS * TN * K::ROWB;
+    auto kern = conv_fwd_kernel<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AROWS, MINW>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -322,22 +420,27 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     return launch_status();
 }
 
-// AR_S / AR_L: small and large LDS patch capacities (rows); the small one keeps two workgroups per CU
-template <typename T, int NI, int NJ, int WM, int WN, int TAPS, bool POOL, int AR_S, int AR_L>
+// AR_S / AR_L: small and large LDS patch capacities (rows); the small one allows more workgroups per CU
+template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AR_S, int AR_L, int MINW>
 static int launch_rows(const ConvArgs& a, hipStream_t s) {
     if ((long long)a.g.M * a.Cout >= (1LL << 31) || (long long)a.g.npix * a.Cout >= (1LL << 31)) return SUBREG_EUNSUPPORTED;
     const int worst = worst_patch_rows<POOL>(a.g, WM * NI * 32);
-    if (worst <= AR_S) return launch_cfg<T, NI, NJ, WM, WN, TAPS, POOL, AR_S>(a, s);
-    if (worst <= AR_L) return launch_cfg<T, NI, NJ, WM, WN, TAPS, POOL, AR_L>(a, s);
+    if (worst <= AR_S) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_S, MINW>(a, s);
+    if (worst <= AR_L) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_L, MINW>(a, s);
     return SUBREG_EUNSUPPORTED;      // image too wide for the LDS patch
 }
 
-template <typename T, int NI, int NJ, int WM, int WN, int AR_S, int AR_L>
+// TPS3: taps staged per step for the 3x3 case (1x1 convs always stage their single tap)
+template <typename T, int NI, int NJ, int WM, int WN, int TPS3, int AR_S, int AR_L, int MINW>
 static int launch_shape(const ConvArgs& a, bool pool, hipStream_t s) {
     if (a.g.taps == 9) {
-        return pool ? launch_rows<T, NI, NJ, WM, WN, 9, true, AR_S, AR_L>(a, s) : launch_rows<T, NI, NJ, WM, WN, 9, false, AR_S, AR_L>(a, s);
+        return pool ? launch_rows<T, NI, NJ, WM, WN, 9, TPS3, true, AR_S, AR_L, MINW>(a, s)
+                    : launch_rows<T, NI, NJ, WM, WN, 9, TPS3, false, AR_S, AR_L, MINW>(a, s);
     }
-    return pool ? launch_rows<T, NI, NJ, WM, WN, 1, true, AR_S, AR_L>(a, s) : launch_rows<T, NI, NJ, WM, WN, 1, false, AR_S, AR_L>(a, s);
+    // 1x1: the patch is exactly the tile's own rows (no halo) => small patch buffers, more workgroups per CU
+    constexpr int TM = WM * NI * 32;
+    return pool ? launch_rows<T, NI, NJ, WM, WN, 1, 1, true, AR_S, AR_L, MINW>(a, s)
+                : launch_rows<T, NI, NJ, WM, WN, 1, 1, false, TM, AR_L, MINW>(a, s);
 }
 
 // rows of stats partials the raw mode writes for a given problem (caller sizes the buffer with this)
@@ -379,9 +482,21 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
     a.raw = raw ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const bool wide = (Cout % 160 == 0);
-    // LDS per block = 2 patch buffers + 2 weight buffers; sized so that two blocks fit a CU (160 KiB)
+    // LDS per block = 2 patch buffers + 2 weight buffers, sized so that >= 2 workgroups fit a CU (160 KiB).
+    // Tile height by problem size: the chip has 256 CUs x 2 resident workgroups, so small-M layers (10x10, 5x5
+    // feature maps) take 128- or 64-row tiles to fill it.
     if (dtype == SUBREG_BF16) {
-        return wide ? launch_shape<__bf16, 2, 5, 4, 1, 432, 560>(a, pool, s) : launch_shape<__bf16, 2, 2, 4, 1, 432, 560>(a, pool, s);
+        if (!wide) {
+            // Cout = 64 (layer 1): 64x64 wave tiles are barrier-bound at one tap per step => stage 3 taps per step;
+            // the pooled conv3 takes 128-row tiles so that two patch buffers + 3-tap weight buffers still fit twice per CU
+            if (a.g.taps == 1) return launch_shape<__bf16, 2, 2, 4, 1, 1, 432, 560, 2>(a, pool, s);
+            if (!pool || raw) return launch_rows<__bf16, 2, 2, 4, 1, 9, 3, false, 432, 560, 2>(a, s);
+            return launch_rows<__bf16, 1, 2, 4, 1, 9, 3, true, 416, 560, 2>(a, s);
+        }
+        const long long nt = Cout / 160;
+        if (raw || ((a.g.M + 255) / 256) * nt >= 384) return launch_shape<__bf16, 2, 5, 4, 1, 1, 432, 560, 2>(a, pool, s);
+        if (((a.g.M + 127) / 128) * nt >= 384) return launch_shape<__bf16, 1, 5, 4, 1, 1, 192, 432, 2>(a, pool, s);
+        return launch_shape<__bf16, 1, 5, 2, 1, 1, 128, 432, 2>(a, pool, s);
     }
-    return wide ? launch_shape<float, 2, 5, 2, 1, 304, 408>(a, pool, s) : launch_shape<float, 2, 2, 2, 1, 304, 408>(a, pool, s);
+    return wide ? launch_shape<float, 2, 5, 2, 1, 1, 304, 408, 1>(a, pool, s) : launch_shape<float, 2, 2, 2, 1, 1, 304, 408, 1>(a, pool, s);
 }

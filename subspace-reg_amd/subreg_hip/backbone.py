@@ -42,7 +42,7 @@ class HipBackbone:
     """params: dict with the reference's state_dict key names -> LIVE fp32 CUDA tensors (conv weights, BN
     weight/bias/running_mean/running_var).  BN running stats are updated in place by train-mode forwards."""
 
-    MAX_EVAL_CHUNK = 256
+    MAX_EVAL_CHUNK = 512      # images per launch sequence: big enough to fill 256 CUs on the 10x10 / 5x5 layers
 
     def __init__(self, params, n_blocks=(1, 1, 2, 2), dtype="bf16", block_size=1):
         self.lib = _lib.load()
@@ -201,7 +201,11 @@ class HipBackbone:
             for (_n, _ci, cout, stride, _ds, _db) in self.blocks:
                 h, w = h // stride, w // stride
                 stages.append(torch.empty(B, cout, h, w, dtype=torch.float32, device=self.device))
-        chunk = B if (train or return_stages) else min(B, self.MAX_EVAL_CHUNK)
+        if train or return_stages:
+            chunk = B
+        else:                                        # balanced chunks (1125 images -> 3 x 375, not 512 + 512 + 101)
+            n_chunks = -(-B // self.MAX_EVAL_CHUNK)
+            chunk = -(-B // n_chunks)
         self._ensure_workspace(chunk, H, W)
         s = _lib.stream_ptr()
         if train:

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Per-layer micro-benchmark of subreg_conv_fwd as the eval-mode backbone calls it (folded scale, fused shortcut).
+
+  python tools/bench_conv.py [--batch 256] [--dtype bf16] [--iters 20]
+Prints one line per distinct conv of ResNet18 at 84x84: time (HIP events on the launch stream, random data),
+algorithmic TFLOP/s and the fraction of the dense MFMA peak.  GPU only.
+"""
+import argparse
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "subspace-reg_amd"))
+
+import torch  # noqa: E402
+
+from subreg_hip import _lib  # noqa: E402
+
+# (name, H, Cin, Cout, ksize, pool, Cin2 (fused shortcut K; -1 none; 0 identity), count per forward)
+LAYERS = [
+    ("L1.conv1 (K=32 im2col)", 84, 32, 64, 1, False, -1, 1),
+    ("L1.conv2", 84, 64, 64, 3, False, -1, 1),
+    ("L1.conv3+ds+pool", 84, 64, 64, 3, True, 32, 1),
+    ("L2.conv1", 42, 64, 160, 3, False, -1, 1),
+    ("L2.conv2", 42, 160, 160, 3, False, -1, 1),
+    ("L2.conv3+ds+pool", 42, 160, 160, 3, True, 64, 1),
+    ("L3.0.conv1", 21, 160, 320, 3, False, -1, 1),
+    ("L3.0.conv2", 21, 320, 320, 3, False, -1, 1),
+    ("L3.0.conv3+ds+pool", 21, 320, 320, 3, True, 160, 1),
+    ("L3.1.conv1/2", 10, 320, 320, 3, False, -1, 2),
+    ("L3.1.conv3+id", 10, 320, 320, 3, False, 0, 1),
+    ("L4.0.conv1", 10, 320, 640, 3, False, -1, 1),
+    ("L4.0.conv2", 10, 640, 640, 3, False, -1, 1),
+    ("L4.0.conv3+ds+pool", 10, 640, 640, 3, True, 320, 1),
+    ("L4.1.conv1/2", 5, 640, 640, 3, False, -1, 2),
+    ("L4.1.conv3+id", 5, 640, 640, 3, False, 0, 1),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    dt = _lib.dtype_code(a.dtype)
+    td = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    peak = 2500.0 if a.dtype == "bf16" else 157.3
+    B = a.batch
+    tot_t, tot_f = 0.0, 0.0
+    for name, H, Cin, Cout, k, pool, cin2, count in LAYERS:
+        if a.only and a.only not in name:
+            continue
+        npix = B * H * H
+        x = torch.randn(npix, Cin, device=dev).to(td)
+        w = (torch.randn(Cout, k * k, Cin, device=dev) / (Cin * k * k) ** 0.5).to(td)
+        shift = torch.randn(Cout, device=dev)
+        Ho = H // 2 if pool else H
+        y = torch.empty(B * Ho * Ho, Cout, device=dev, dtype=td)
+        x2 = w2 = None
+        c2 = 0
+        if cin2 >= 0:
+            c2 = Cout if cin2 == 0 else cin2
+            x2 = torch.randn(npix, c2, device=dev).to(td)
+            w2 = (torch.eye(Cout, device=dev) if cin2 == 0 else torch.randn(Cout, c2, device=dev) / c2 ** 0.5).to(td).contiguous()
+        flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0)
+
+        def run():
+            _lib.check(lib.subreg_conv_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), None, _lib.ptr(shift), None, None,
+                                           _lib.ptr(x2), _lib.ptr(w2), c2, B, H, H, Cin, Cout, k, flags, dt, _lib.stream_ptr()))
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / a.iters
+        mrows = B * Ho * Ho * 4 if pool else npix                 # rows actually computed (floor pooling skips the odd edge)
+        flops = 2.0 * npix * Cout * Cin * k * k + (2.0 * npix * Cout * c2 if (cin2 > 0) else 0.0)   # algorithmic (identity adds none)
+        tf = flops / us * 1e-6
+        tot_t += us * count
+        tot_f += flops * count
+        print("%-24s M=%8d K=%5d N=%4d  %8.1f us  %7.1f TFLOP/s  %5.1f%% of peak" % (name, mrows, Cin * k * k, Cout, us, tf, 100 * tf / peak))
+    if not a.only:
+        print("conv stack, B=%d: %.1f us, %.1f TFLOP/s algorithmic (%.1f%% of %s peak)" % (B, tot_t, tot_f / tot_t * 1e-6, 100 * tot_f / tot_t * 1e-6 / peak, a.dtype))
+
+
+if __name__ == "__main__":
+    main()
