@@ -144,6 +144,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)       # RCCL; used only for the barrier and the max-over-ranks time
 
+    from subreg_hip import sweep
     from subreg_hip.incremental import IncrementalRunner
     seed = rank + 1                                           # one seed per GPU, like the SLURM array
     net, opt = make_net(args, seed, dev)
@@ -165,8 +166,7 @@ def main():
         r.run_session(i % 8)
     # ---- timed: exactly K episodes
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    sweep.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     runners = []
@@ -176,14 +176,9 @@ def main():
             runners.append(r)
         r.run_session(i % 8)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    sweep.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = sweep.max_over_ranks(time.perf_counter() - t0, dev)
 
     imgs = sum(rr.images_forwarded for rr in runners)
     fwd_ms = sum(e0.elapsed_time(e1) for rr in runners for (e0, e1, _n) in rr.fwd_events)

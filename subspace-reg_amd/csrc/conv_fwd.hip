@@ -45,7 +45,7 @@ struct ConvArgs {
     const float* scale;  // [Cout] or null (scale folded into the weights)
     const float* shift;  // [Cout]
     const char* res;     // [npix][Cout] T residual or null
-    float* stats;        // raw: [gridDim.x*WAVES_M][Cout][2] partial (sum, sumsq)
+    float* stats;        // raw: [m_tiles*WAVES_M][Cout][2] partial (sum, sumsq)
     ConvGeom g;
     int Cin, Cin2, Cout;
     int act;             // LeakyReLU(0.1) after scale/shift/residual
@@ -111,7 +111,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
     const int wave_m = wid / WAVES_N, wave_n = wid % WAVES_N;
     const int lr = lane & 31, lh = lane >> 5;
     const ConvGeom g = a.g;
-    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    // XCD-aware tile order (MI355X: 8 XCDs with private L2s, workgroups dealt round-robin): give each XCD one
+    // CONTIGUOUS range of tiles, n-tile fastest, so that the halo rows two neighbouring m-tiles share and the whole
+    // patch the n-tiles of one m-tile share are fetched into one L2 once.  Pure placement: bijective for any grid.
+    const int ntn = (a.Cout + TN - 1) / TN;
+    int vtile;
+    {
+        const int nwg = gridDim.x, lid = blockIdx.x, q8 = nwg / 8, r8 = nwg % 8, xcd = lid % 8, slot = lid / 8;
+        vtile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int mtile = vtile / ntn;
+    const int m0 = mtile * TM, n0 = (vtile % ntn) * TN;
 
     int plo, phi;
     patch_range<POOL>(g, m0, TM, &plo, &phi);
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
             s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 32);
             if (lh == 0 && n < a.Cout) {
-                float* dst = a.stats + ((size_t)(blockIdx.x * WAVES_M + wave_m) * a.Cout + n) * 2;
+                float* dst = a.stats + ((size_t)(mtile * WAVES_M + wave_m) * a.Cout + n) * 2;
                 dst[0] = s1;
                 dst[1] = s2;
             }
@@ -415,7 +425,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
             return SUBREG_EHIP;
         attr_done = true;
     }
-    dim3 grid((a.g.M + TM - 1) / TM, (a.Cout + TN - 1) / TN);
+    dim3 grid(((a.g.M + TM - 1) / TM) * ((a.Cout + TN - 1) / TN));      // 1-D: the kernel decodes (m-tile, n-tile) itself
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, a);
     return launch_status();
 }
