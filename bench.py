@@ -187,7 +187,7 @@ def main():
     traffic = None
     tpath = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(args.dtype)
+        traffic = (json.load(open(tpath)).get(args.dtype) or {}).get("bytes_per_image")   # HBM bytes per image forwarded
     out = {
         "metric": "incremental episodes/sec, ResNet18 miniImageNet 5w5s", "value": args.steps * world / dt,
         "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -70,21 +70,22 @@ __device__ __forceinline__ void mma_step<float>(const uint4& a, const uint4& b, 
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], acc, 0, 0, 0);
 }
 
-// one 1-KiB LDS-DMA piece: 64 lanes x 16 B, LDS image lane-linear from the wave-uniform LDS byte address `lds_addr`.
+// one 1-KiB LDS-DMA piece: 64 lanes x 16 B from `base + voff` (wave-uniform 64-bit base in SGPRs, per-lane 32-bit byte
+// offset), LDS image lane-linear from the wave-uniform LDS byte address `lds_addr`.
 // Issued from inline asm ON PURPOSE: for the builtin form hipcc (ROCm 7.2) inserts `s_waitcnt vmcnt(0)` in front of
 // the next ds_read of ANY LDS address, which drains the prefetch every step; asm DMAs are invisible to that pass, so
 // the counted `s_waitcnt vmcnt(N)` + `s_barrier` at the end of each step are the only (hand-placed) waits on them.
 // M0 (the DMA's LDS base) is compiler-reserved: save / set / restore inside the one statement.
-__device__ __forceinline__ void dma16(const char* src, unsigned lds_addr) {
+__device__ __forceinline__ void dma16(const char* base, unsigned voff, unsigned lds_addr) {
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(src), "s"(lds_addr)
+        : "v"(voff), "s"(base), "s"(lds_addr)
         : "memory");
 }
 
@@ -173,33 +174,38 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
     // piece group `grp` of a patch = pieces grp*NW .. grp*NW+NW-1, one per wave (the last group re-loads the last
     // piece on the surplus waves so that every wave issues the same number of DMAs: counted vmcnt waits rely on it)
     auto stage_patch_group = [&](const char* xsrc, int cin, int chunk, int buf, int grp) {
-        const size_t xrow = (size_t)cin * ELEM;
-        const char* base = xsrc + (size_t)plo * xrow + (size_t)chunk * 32 * ELEM;
+        const unsigned xrow = (unsigned)cin * ELEM;
+        const char* base = xsrc + (size_t)plo * xrow + (size_t)chunk * 32 * ELEM;     // wave-uniform
         int q = grp * NW + wid;
         q = q < apieces ? q : apieces - 1;
         const int row = q * RPP + prl;
         const int srow = row < prow ? row : prow - 1;                // tail rows of the last piece: any valid source
-        dma16(base + (size_t)srow * xrow + ((psl ^ swz<SLOTS>(row)) << 4), lds_base + buf * ABUF + q * 1024);
+        dma16(base, (unsigned)srow * xrow + ((psl ^ swz<SLOTS>(row)) << 4), lds_base + buf * ABUF + q * 1024);
     };
     const int agroups = (apieces + NW - 1) / NW;                     // piece groups of one patch
     auto stage_patch = [&](const char* xsrc, int cin, int chunk, int buf) {
         for (int grp = 0; grp < agroups; ++grp) stage_patch_group(xsrc, cin, chunk, buf, grp);
     };
-    // weight tiles of `ntaps` consecutive taps starting at `tap` into weight buffer `buf`
-    auto stage_w = [&](const char* wsrc, int cin, int taps, int chunk, int tap, int ntaps, int buf) {
-        const size_t wrow = (size_t)taps * cin * ELEM;
-        for (int tt = 0; tt < ntaps; ++tt) {
-            const char* base = wsrc + ((size_t)(tap + tt) * cin + (size_t)chunk * 32) * ELEM;
+    // weight tiles of `ntaps` consecutive taps starting at `tap` into weight buffer `buf`.  The per-lane part of the
+    // source address (output channel row, swizzled slot) does not depend on the step: precomputed once.
+    constexpr int PW = (TN / RPP + NW - 1) / NW;                     // weight pieces per wave per tap
+    int wn[PW], wsl[PW];
 #pragma unroll
-            for (int q0 = 0; q0 < TN / RPP; q0 += NW) {
-                const int q = q0 + wid;
-                if (q < TN / RPP) {
-                    const int row = q * RPP + prl;
-                    int n = n0 + row;
-                    n = n < a.Cout ? n : a.Cout - 1;                 // N tail: those output columns are never stored
-                    dma16(base + (size_t)n * wrow + ((psl ^ swz<SLOTS>(row)) << 4),
-                          lds_base + B_BASE + buf * BBUF + tt * BTAP + q * 1024);
-                }
+    for (int k = 0; k < PW; ++k) {
+        const int q = k * NW + wid, row = q * RPP + prl;
+        const int n = n0 + row;
+        wn[k] = n < a.Cout ? n : a.Cout - 1;                         // N tail: those output columns are never stored
+        wsl[k] = (psl ^ swz<SLOTS>(row)) << 4;
+    }
+    auto stage_w = [&](const char* wsrc, int cin, int taps, int chunk, int tap, int ntaps, int buf) {
+        const unsigned wrow = (unsigned)(taps * cin) * ELEM;
+        for (int tt = 0; tt < ntaps; ++tt) {
+            const char* base = wsrc + ((size_t)(tap + tt) * cin + (size_t)chunk * 32) * ELEM;   // wave-uniform
+#pragma unroll
+            for (int k = 0; k < PW; ++k) {
+                const int q = k * NW + wid;
+                if (q < TN / RPP)
+                    dma16(base, (unsigned)wn[k] * wrow + wsl[k], lds_base + B_BASE + buf * BBUF + tt * BTAP + q * 1024);
             }
         }
     };
@@ -249,20 +255,49 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
                 }
             }
             const int boff = (step & 1) * BBUF;
+            // k-steps of this step (TPS taps x KSTEPS).  Where the register budget allows two fragment sets (small
+            // wave tiles, which also run at low occupancy), software-pipeline: the LDS reads of k-step kk+1 are issued
+            // between the MFMAs of k-step kk.  The 64x160 wave tile (160 accumulator registers) cannot afford it.
+            constexpr int NK = TPS * K::KSTEPS;
+            constexpr bool SWP = NI * NJ * 16 + 2 * (NI + NJ) * 4 + 40 <= 200;
+            auto load_frags = [&](int kk, uint4(&xa)[NI], uint4(&xb)[NJ]) {
+                const int tt = kk / K::KSTEPS, s = kk % K::KSTEPS;
 #pragma unroll
-            for (int tt = 0; tt < TPS; ++tt) {
-                if (ph1 && tt != 0) continue;
+                for (int i = 0; i < NI; ++i) {
+                    const int ad = ph1 ? aaddr[i][CENTER] : aaddr[i][tg * TPS + tt];
+                    xa[i] = *reinterpret_cast<const uint4*>(smem + aoff + (ad ^ (32 * s)));
+                }
 #pragma unroll
-                for (int s = 0; s < K::KSTEPS; ++s) {
-                    uint4 fa[NI], fb[NJ];
+                for (int j = 0; j < NJ; ++j)
+                    xb[j] = *reinterpret_cast<const uint4*>(smem + boff + tt * BTAP + (baddr[j] ^ (32 * s)));
+            };
+            if constexpr (SWP) {
+                constexpr int NRD = NI + NJ, NMM = NI * NJ * (sizeof(T) == 2 ? 1 : 4), PER = NMM / NRD > 0 ? NMM / NRD : 1;
+                uint4 fa[2][NI], fb[2][NJ];
+                load_frags(0, fa[0], fb[0]);
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) {
-                        const int ad = ph1 ? aaddr[i][CENTER] : aaddr[i][tg * TPS + tt];
-                        fa[i] = *reinterpret_cast<const uint4*>(smem + aoff + (ad ^ (32 * s)));
+                for (int kk = 0; kk < NK; ++kk) {
+                    if (ph1 && kk >= K::KSTEPS) continue;                 // the shortcut GEMM has a single tap
+                    const bool more_k = kk + 1 < NK && !(ph1 && kk + 1 >= K::KSTEPS);
+                    if (more_k) load_frags(kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) mma_step<T>(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
+                    if (kk + 1 < NK) {                                    // interleave: PER MFMAs, 1 ds_read, ...
+#pragma unroll
+                        for (int n = 0; n < NRD; ++n) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
                     }
+                }
+            } else {
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        fb[j] = *reinterpret_cast<const uint4*>(smem + boff + tt * BTAP + (baddr[j] ^ (32 * s)));
+                for (int kk = 0; kk < NK; ++kk) {
+                    if (ph1 && kk >= K::KSTEPS) continue;
+                    uint4 fa[NI], fb[NJ];
+                    load_frags(kk, fa, fb);
 #pragma unroll
                     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -506,7 +541,8 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
         const long long nt = Cout / 160;
         if (raw || ((a.g.M + 255) / 256) * nt >= 384) return launch_shape<__bf16, 2, 5, 4, 1, 1, 432, 560, 2>(a, pool, s);
         if (((a.g.M + 127) / 128) * nt >= 384) return launch_shape<__bf16, 1, 5, 4, 1, 1, 192, 432, 2>(a, pool, s);
-        return launch_shape<__bf16, 1, 5, 2, 1, 1, 128, 432, 2>(a, pool, s);
+        // smallest maps (5x5): too few tiles to hide the per-step LDS-DMA latency by occupancy => 3 taps per step
+        return launch_shape<__bf16, 1, 5, 2, 1, 3, 128, 432, 2>(a, pool, s);
     }
     return wide ? launch_shape<float, 2, 5, 2, 1, 1, 304, 408, 1>(a, pool, s) : launch_shape<float, 2, 2, 2, 1, 1, 304, 408, 1>(a, pool, s);
 }
