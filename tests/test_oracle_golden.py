@@ -176,3 +176,34 @@ def test_memory_index_formula():
     sy, _ = syn.session_labels(0)
     assert len(inds) == 25 and len(set(inds)) == 25
     assert sorted(np.bincount(sy[inds] - 60)) == [5] * 5
+
+
+# ---------------------------------------------------------------- G5 pretraining step (forward + backward)
+@pytest.mark.parametrize("hw", [32] + ([84] if os.environ.get("SUBREG_SLOW_TESTS") else []))   # hw=84: 3 min in fp64 NumPy
+def test_train_step_backward(hw):
+    from oracle import backward_ref as br
+    g = _load("train_step.npz")
+    key = "hw%d" % hw
+    sd = syn.make_state_dict(71)
+    x = syn.make_images(72, int(g[key + ".B"]), hw)
+    loss, logits, grads = br.train_step(sd, x, g[key + ".labels"], MaskSource(74))
+    _close(loss, g[key + ".loss"], 1e-5, 1e-5, "loss")
+    _close(logits, g[key + ".logits"], 5e-4, 5e-4, "logits")
+    n_full = 0
+    for k in g.files:
+        if k.startswith(key + ".gnorm."):
+            name = k[len(key) + 7:]
+            _close(np.linalg.norm(grads[name]), g[k], 1e-5, 2e-3, "gnorm " + name)
+        elif k.startswith(key + ".grad."):
+            name = k[len(key) + 6:]
+            want = g[k]
+            got = grads[name][:want.shape[0]]
+            # the reference accumulates weight gradients over B*H*W pixels in fp32: 1e-3 of the tensor's magnitude
+            _close(got, want, 1e-3 * max(1.0, float(np.abs(want).max())), 2e-3, "grad " + name)
+            n_full += 1
+    assert n_full > 50
+    for k in ("layer1.0.bn1", "layer4.1.bn3"):
+        _close(sd[k + ".running_mean"], g["%s.%s.running_mean" % (key, k)], 1e-5, 1e-4, k)
+    w = sd["classifier.weight"]
+    p, _ = br.sgd_momentum_step(w.astype(np.float64), grads["classifier.weight"], None, 0.05, 0.9, 5e-4)
+    _close(p, g[key + ".after_step.classifier.weight"], 1e-6, 1e-5, "sgd step")

@@ -349,15 +349,60 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, **optkw):
     print("loop_%s.npz" % tag, {k: v for k, v in out.items() if k.endswith("epochs")})
 
 
+# ------------------------------------------------------------------ G5: one pretraining step (train_supervised.py:205-268)
+TRAIN_SLICES = {"layer1.0.conv1.weight": None, "layer1.0.downsample.0.weight": None, "layer1.0.conv2.weight": 8,
+                "layer2.0.conv2.weight": 8, "layer2.0.downsample.0.weight": 16, "layer3.0.conv1.weight": 4,
+                "layer3.1.conv3.weight": 4, "layer4.0.downsample.0.weight": 8, "layer4.1.conv1.weight": 2,
+                "layer4.1.conv3.weight": 2, "classifier.weight": None}
+
+
+def gen_train_step():
+    opt = ref_opt()
+    out = {}
+    for hw, B in ((84, 6), (32, 8)):
+        sd = syn.make_state_dict(71)
+        net = ref_net(sd, opt)
+        x = syn.make_images(72, B, hw)
+        y = np.random.RandomState(73).randint(0, 60, B)
+        net.train()
+        set_masks(74)
+        logits = net(torch.from_numpy(x))
+        loss = torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(y))
+        loss.backward()
+        key = "hw%d" % hw
+        out[key + ".B"], out[key + ".labels"] = np.array(B), y
+        out[key + ".loss"], out[key + ".logits"] = t2n(loss), t2n(logits)
+        for name, prm in net.named_parameters():
+            g = t2n(prm.grad)
+            out["%s.gnorm.%s" % (key, name)] = np.array(np.linalg.norm(g.astype(np.float64)))
+            if name in TRAIN_SLICES:
+                k = TRAIN_SLICES[name]
+                out["%s.grad.%s" % (key, name)] = g if k is None else g[:k]
+            elif ".bn" in name or "downsample.1" in name:
+                out["%s.grad.%s" % (key, name)] = g
+        for k in ("layer1.0.bn1", "layer4.1.bn3"):
+            m = dict(net.named_modules())[k]
+            out["%s.%s.running_mean" % (key, k)], out["%s.%s.running_var" % (key, k)] = t2n(m.running_mean), t2n(m.running_var)
+        # one SGD step with train_supervised.py's hyper-parameters (configs.py:124-134: lr 0.05, momentum 0.9, wd 5e-4)
+        o = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+        o.step()
+        out[key + ".after_step.classifier.weight"] = t2n(net.classifier.weight)
+        out[key + ".after_step.layer1.0.conv1.weight"] = t2n(dict(net.named_parameters())["layer1.0.conv1.weight"])
+    np.savez_compressed(os.path.join(GOLD, "train_step.npz"), **out)
+    print("train_step.npz", sum(v.nbytes for v in out.values()) / 1e6, "MB")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["blocks", "backbone", "reg", "loop32", "loop84"]
+    what = sys.argv[1:] or ["blocks", "backbone", "reg", "train", "loop32", "loop84"]
     if "blocks" in what:
         gen_blocks()
     if "backbone" in what:
         gen_backbone()
     if "reg" in what:
         gen_reg()
+    if "train" in what:
+        gen_train_step()
     if "loop32" in what:
         gen_loop("hw32_noM", 32, 2, False, 40, seed=1, max_novel_epochs=4)
         gen_loop("hw32_M", 32, 3, True, 40, seed=2, max_novel_epochs=3)
