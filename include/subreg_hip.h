@@ -79,7 +79,7 @@ int subreg_bn_fold(const float* weight, const float* bias, const float* running_
 /* train: reduce the partials -> batch scale/shift; running stats updated in place (momentum, unbiased var) */
 int subreg_bn_train_finalize(const float* stats_partial, int rows, int C, long long count, const float* weight,
                              const float* bias, float* running_mean, float* running_var, float momentum, float eps,
-                             float* scale, float* shift, void* stream);
+                             float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
 /* train second pass: y = keep*mask_scale * [pool2]([lrelu]( x*scale+shift + residual*res_scale+res_shift )) */
 int subreg_bn_apply(const void* x, const float* scale, const float* shift, const void* residual, const float* res_scale,
                     const float* res_shift, const unsigned char* keep_mask, float mask_scale, void* y, int B, int H, int W,
@@ -136,6 +136,70 @@ int subreg_backbone_fold(const subreg_backbone_desc* d, void* stream);
  * output as NCHW fp32 (is_feat=True, :189-190). */
 int subreg_backbone_forward(const subreg_backbone_desc* d, const float* x_nchw, int B, int H, int W, float* feat,
                             float* const* stage_out, int flags, void* stream);
+
+/* ---- pretraining step: train_supervised.py:205-268 (output = model(input); loss.backward()) ----------------- */
+/* dX of a conv = subreg_conv_fwd on dY with these weights: OIHW fp32 -> [Cin][taps][Cout], taps flipped */
+int subreg_pack_conv_weight_dgrad(const float* w_oihw, void* out, int Cout, int Cin, int ksize, int dtype, void* stream);
+/* dW: gw_packed[Cout][taps][Cin] (fp32, zeroed here) = sum_p dY[p][o] * X[p+off(tap)][c]; then OIHW via unpack
+ * (mode 1: the first layer's K=32 im2col layout back to [Cout][3][k][k]) */
+int subreg_conv_wgrad(const void* x, const void* dy, float* gw_packed, int B, int H, int W, int Cin, int Cout, int ksize,
+                      int dtype, void* stream);
+int subreg_unpack_wgrad(const float* gw_packed, float* grad_oihw, int Cout, int Cin, int ksize, int mode, void* stream);
+/* BatchNorm2d training-mode backward with the LeakyReLU' of `act` fused in (act == NULL: none):
+ * g = dy*lrelu'(act); dgamma = sum g*xhat; dbeta = sum g; dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N).
+ * partial: subreg_bn_bwd_slices(npix)*C*2 DOUBLES of scratch (sums in fp64 like the reference's CPU batch_norm backward) */
+int subreg_bn_bwd_slices(long long npix);
+int subreg_bn_bwd(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
+                  const float* gamma, double* partial, float* dgamma, float* dbeta, void* dx, long long npix, int C, int dtype,
+                  void* stream);
+/* backward of  out = keep*mask_scale * [pool2](lrelu(raw3*scale3+shift3 + residual*res_scale+res_shift))  w.r.t. the
+ * pre-activation sum (MaxPool2d: first maximum of the window; BasicBlock.forward :288-299) */
+int subreg_block_tail_bwd(const void* grad_out, const unsigned char* keep_mask, float mask_scale, const void* raw3,
+                          const float* scale3, const float* shift3, const void* residual, const float* res_scale,
+                          const float* res_shift, void* dv, int B, int H, int W, int C, int pool, int dtype, void* stream);
+int subreg_avgpool_bwd(const float* dfeat, void* dx, int B, int H, int W, int C, int dtype, void* stream);
+/* torch.optim.SGD step (train_supervised.py:133-136): d = g + wd*p; buf = first ? d : m*buf + d; p -= lr*buf */
+int subreg_sgd_momentum(float* param, const float* grad, float* momentum_buf, long long n, float lr, float momentum,
+                        float weight_decay, int first_step, void* stream);
+
+typedef struct subreg_conv_train { /* per conv; every buffer caller-owned */
+    void* raw;            /* [B*H*W][cout] raw conv output (pre-BN) */
+    void* act;            /* [B*H*W][cout] BN+LeakyReLU output (conv1, conv2); NULL for conv3 / the shortcut conv */
+    float* mean;          /* [cout] batch mean */
+    float* invstd;        /* [cout] */
+    float* bscale;        /* [cout] gamma*invstd of THIS batch */
+    float* bshift;        /* [cout] beta - mean*gamma*invstd */
+    const void* w_dgrad;  /* subreg_pack_conv_weight_dgrad output; NULL when no input gradient is needed */
+    float* gw_packed;     /* [cout][taps][cin as the kernel sees it] fp32 scratch */
+    float* grad_w;        /* OIHW fp32: Conv2d.weight.grad */
+    float* grad_gamma;    /* [cout] */
+    float* grad_beta;     /* [cout] */
+} subreg_conv_train;
+
+typedef struct subreg_block_train {
+    subreg_conv_train conv1, conv2, conv3, down;
+    void* out;            /* block output [B*Ho*Wo][cout] (after pool and keep mask) */
+} subreg_block_train;
+
+typedef struct subreg_train_desc {
+    const subreg_block_train* blocks; /* HOST array, one per block of the backbone desc */
+    void* g[2];            /* activation-sized gradient ping-pong (w.r.t. block outputs / inputs) */
+    void* dv;              /* activation-sized scratch x4 */
+    void* dr;
+    void* dt;
+    void* dr2;
+    double* bn_partial;    /* subreg_bn_bwd_slices(B*H*W)*Cmax*2 doubles */
+    const float* zero_shift; /* [Cmax] zeros */
+    void* const* grad_out_dump; /* optional HOST array [n_blocks] of device buffers: receives d(loss)/d(block output)
+                                   (NHWC, compute dtype) of every block for diagnostics; NULL = off */
+} subreg_train_desc;
+
+/* train-mode forward that keeps what the backward needs (raw conv outputs, activations, batch statistics) */
+int subreg_backbone_forward_stash(const subreg_backbone_desc* d, const subreg_train_desc* t, const float* x_nchw, int B,
+                                  int H, int W, float* feat, void* stream);
+/* gradients of every conv weight and BN affine parameter given d(loss)/d(feat) [B][C_last] */
+int subreg_backbone_backward(const subreg_backbone_desc* d, const subreg_train_desc* t, const float* dfeat, int B, int H,
+                             int W, void* stream);
 
 /* ---- classifier head: nn.Linear (:138-140,187) ----------------------------------------------------------- */
 int subreg_linear_fwd(const float* feat, const float* weight, const float* bias, float* logits, int B, int N, int D,

@@ -39,7 +39,7 @@ int conv_train(const subreg_backbone_desc* d, const subreg_conv_desc& c, const v
                         SUBREG_CONV_RAW_STATS, d->dtype, stream));
     const int rows = subreg_conv_stats_rows(d->dtype, B, H, W, c.cout);
     return subreg_bn_train_finalize(d->stats, rows, c.cout, (long long)B * H * W, c.bn_weight, c.bn_bias, c.running_mean,
-                                    c.running_var, d->bn_momentum, d->bn_eps, c.scale, c.shift, stream);
+                                    c.running_var, d->bn_momentum, d->bn_eps, c.scale, c.shift, nullptr, nullptr, stream);
 }
 
 }  // namespace

@@ -1,0 +1,306 @@
+// Backward kernels of one pretraining step (train_supervised.py:205-268: loss.backward() through
+// models/resnet_language.py BasicBlock.forward :268-301), gfx950.
+//
+//   block_tail_bwd   dropout/DropBlock mask, MaxPool2d(2) (first maximum of the window), LeakyReLU' of the block output
+//   bn_bwd_*         BatchNorm2d training-mode backward (d gamma, d beta, d x) with the preceding LeakyReLU' fused in
+//   conv_wgrad       dW[o][tap][c] = sum_p dY[p][o] * X[p+off(tap)][c]   (exact-f32 MFMA, fp32 atomics over K splits)
+//   (dX of a conv is the forward kernel run on dY with flipped/transposed weights: pack_conv_weight_dgrad)
+//   avgpool_bwd, unpack_wgrad, sgd_momentum
+// Round 1: correctness first.  conv_wgrad runs on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32) for BOTH dtypes with
+// operands fetched straight from global memory (bf16 operands are widened on the fly); a bf16-MFMA version with LDS
+// transposing reads is the next step.
+#include "conv_index.h"
+#include "subreg_common.h"
+
+namespace subreg {
+
+constexpr int BW_THREADS = 256;
+static inline int bw_blocks(size_t n) { return (int)((n + BW_THREADS - 1) / BW_THREADS); }
+
+__device__ __forceinline__ float lrelu_grad(float pre) { return pre > 0.f ? 1.f : 0.1f; }
+
+// ---------------------------------------------------------------- block tail
+// out = mask*scale * pool(lrelu(v)), v = raw3*sc3+sh3 + (res*rsc+rsh | res).  One thread per OUTPUT element; writes
+// dV at the argmax pixel (dv must be zero-filled by the caller when pool != 0).
+template <typename T>
+__global__ void block_tail_bwd_kernel(const T* __restrict__ gout, const unsigned char* __restrict__ keep, float mask_scale,
+                                      const T* __restrict__ raw3, const float* __restrict__ sc3, const float* __restrict__ sh3,
+                                      const T* __restrict__ res, const float* __restrict__ rsc, const float* __restrict__ rsh,
+                                      T* __restrict__ dv, int B, int H, int W, int C, int pool) {
+    const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * Ho * Wo * C) return;
+    const int c = i % C;
+    const size_t po = i / C;
+    const int wo = po % Wo, ho = (po / Wo) % Ho, b = po / ((size_t)Wo * Ho);
+    float g = ElemTraits<T>::to_float(gout[i]);
+    if (keep) g = keep[i] ? g * mask_scale : 0.f;
+    const float a = sc3[c], s = sh3[c], ra = rsc ? rsc[c] : 1.f, rs = rsh ? rsh[c] : 0.f;
+    const int n = pool ? 2 : 1;
+    float best = 0.f;
+    size_t bestp = 0;
+    for (int dy = 0; dy < n; ++dy)
+        for (int dx = 0; dx < n; ++dx) {
+            const size_t p = ((size_t)b * H + (pool ? 2 * ho + dy : ho)) * W + (pool ? 2 * wo + dx : wo);
+            const float v = ElemTraits<T>::to_float(raw3[p * C + c]) * a + s + ElemTraits<T>::to_float(res[p * C + c]) * ra + rs;
+            if ((dy == 0 && dx == 0) || v > best) { best = v; bestp = p; }     // first maximum in scan order
+        }
+    dv[bestp * C + c] = ElemTraits<T>::from_float(g * lrelu_grad(best));
+}
+
+// ---------------------------------------------------------------- BN backward
+// g = dy * lrelu'(act) (act == NULL: g = dy); xhat = (raw - mean) * invstd.
+// reduce: partial[slice][C][2] = (sum g, sum g*xhat) over the slice's pixels.  block (32 channels x 8 pixel lanes).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ act,
+                                                            const T* __restrict__ raw, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, double* __restrict__ partial,
+                                                            long long npix, int C, int pix_per_slice) {
+    // fp64 accumulation like the reference's CPU batch_norm backward (acc_type<float> = double): d beta of a BN that
+    // feeds another BN is a sum with near-total cancellation, fp32 partial sums lose 2-3 digits there
+    __shared__ double s1[8][33], s2[8][33];
+    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    const long long p0 = (long long)blockIdx.y * pix_per_slice;
+    long long p1 = p0 + pix_per_slice;
+    if (p1 > npix) p1 = npix;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < C) {
+        const double m = mean[c], is = invstd[c];
+        for (long long p = p0 + py; p < p1; p += 8) {
+            float g = ElemTraits<T>::to_float(dy[p * C + c]);
+            if (act) g *= lrelu_grad(ElemTraits<T>::to_float(act[p * C + c]));
+            a1 += (double)g;
+            a2 += (double)g * ((double)ElemTraits<T>::to_float(raw[p * C + c]) - m) * is;
+        }
+    }
+    s1[py][cx] = a1;
+    s2[py][cx] = a2;
+    __syncthreads();
+    if (py == 0 && c < C) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { t1 += s1[k][cx]; t2 += s2[k][cx]; }
+        partial[((size_t)blockIdx.y * C + c) * 2] = t1;
+        partial[((size_t)blockIdx.y * C + c) * 2 + 1] = t2;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int slices, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double t1 = 0.0, t2 = 0.0;
+    for (int s = 0; s < slices; ++s) {
+        t1 += partial[((size_t)s * C + c) * 2];
+        t2 += partial[((size_t)s * C + c) * 2 + 1];
+    }
+    dbeta[c] = (float)t1;
+    dgamma[c] = (float)t2;
+}
+
+// dx = gamma*invstd * (g - dbeta/N - xhat*dgamma/N)
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ act, const T* __restrict__ raw,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                    const float* __restrict__ dbeta, T* __restrict__ dx, long long npix, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)npix * C) return;
+    const int c = i % C;
+    float g = ElemTraits<T>::to_float(dy[i]);
+    if (act) g *= lrelu_grad(ElemTraits<T>::to_float(act[i]));
+    const double is = invstd[c], xh = ((double)ElemTraits<T>::to_float(raw[i]) - (double)mean[c]) * is;
+    const double inv_n = 1.0 / (double)npix;
+    dx[i] = ElemTraits<T>::from_float((float)((double)gamma[c] * is * ((double)g - (double)dbeta[c] * inv_n - xh * (double)dgamma[c] * inv_n)));
+}
+
+// ---------------------------------------------------------------- AdaptiveAvgPool2d(1) backward
+template <typename T>
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dfeat, T* __restrict__ dx, int B, int HW, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * HW * C) return;
+    const int c = i % C, b = i / ((size_t)HW * C);
+    dx[i] = ElemTraits<T>::from_float(dfeat[(size_t)b * C + c] / (float)HW);
+}
+
+// ---------------------------------------------------------------- weight gradient (exact-f32 MFMA)
+// One wave: output tile 32 (o) x 32 (c) for all taps over a pixel range; C[o][c] += A[o][k] B[k][c] with k = pixel:
+// lane (lr, lh) supplies A = dY[p+lh][o0+lr] and B = X[p+lh+off(tap)][c0+lr] (0 outside the image) - both coalesced.
+template <typename T, int TAPS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                         float* __restrict__ gw, ConvGeom g, int Cin, int Cout,
+                                                         int pix_per_wave) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+    const int n_ct = Cin / 32;
+    const int o0 = (blockIdx.x / n_ct) * 32, c0 = (blockIdx.x % n_ct) * 32;
+    const long long pstart = ((long long)blockIdx.y * 4 + wid) * pix_per_wave;
+    if (pstart >= g.npix) return;
+    long long pend = pstart + pix_per_wave;
+    if (pend > g.npix) pend = g.npix;
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // this lane walks pixels pstart+lh, +2, +4, ...
+    long long p = pstart + lh;
+    int rem = (int)(p % ((long long)g.H * g.W));
+    int h = rem / g.W, w = rem % g.W;
+    for (; p - lh < pend; p += 2) {
+        const bool pv = p < pend;
+        const float a = pv ? ElemTraits<T>::to_float(dy[(size_t)p * Cout + o0 + lr]) : 0.f;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int ddy = TAPS == 9 ? t / 3 - 1 : 0, ddx = TAPS == 9 ? t % 3 - 1 : 0;
+            const bool ok = pv && tap_valid(g, h, w, ddy, ddx);
+            const float b = ok ? ElemTraits<T>::to_float(x[(size_t)(p + ddy * g.W + ddx) * Cin + c0 + lr]) : 0.f;
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+        w += 2;
+        while (w >= g.W) { w -= g.W; if (++h >= g.H) h = 0; }
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            atomicAdd(&gw[((size_t)o * TAPS + t) * Cin + c0 + lr], acc[t][r]);
+        }
+}
+
+// packed fp32 [Cout][taps][Cin_k] -> Conv2d.weight.grad OIHW (mode 1: first-layer K=32 layout, see pack_weight_kernel)
+__global__ void unpack_wgrad_kernel(const float* __restrict__ gw, float* __restrict__ grad, int Cout, int Cin, int ks, int mode) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over OIHW
+    const int taps = ks * ks;
+    if (i >= (size_t)Cout * Cin * taps) return;
+    const int t = i % taps, c = (i / taps) % Cin, o = i / ((size_t)taps * Cin);
+    if (mode == 0) grad[i] = gw[((size_t)o * taps + t) * Cin + c];
+    else grad[i] = gw[(size_t)o * 32 + (ks == 3 ? 3 * t + c : 12 + c)];
+}
+
+// OIHW fp32 -> dgrad operand [Cin][taps][Cout] T with the taps flipped: dX = conv(dY, this)
+template <typename T>
+__global__ void pack_weight_dgrad_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int ks) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [Cin][taps][Cout]
+    const int taps = ks * ks;
+    if (i >= (size_t)Cin * taps * Cout) return;
+    const int o = i % Cout, t = (i / Cout) % taps, c = i / ((size_t)Cout * taps);
+    out[i] = ElemTraits<T>::from_float(w[((size_t)o * Cin + c) * taps + (taps - 1 - t)]);
+}
+
+// torch.optim.SGD (dampening 0, no nesterov): d = g + wd*p; buf = first ? d : m*buf + d; p -= lr*buf
+__global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, size_t n,
+                                    float lr, float momentum, float wd, int first) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float d = g[i] + wd * p[i];
+    const float b = first ? d : momentum * buf[i] + d;
+    buf[i] = b;
+    p[i] -= lr * b;
+}
+
+}  // namespace subreg
+
+using namespace subreg;
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16)      \
+    if ((dtype) == SUBREG_F32) { CALL_F32; }        \
+    else if ((dtype) == SUBREG_BF16) { CALL_BF16; } \
+    else return SUBREG_EINVAL;
+
+extern "C" int subreg_block_tail_bwd(const void* grad_out, const unsigned char* keep_mask, float mask_scale, const void* raw3,
+                                     const float* scale3, const float* shift3, const void* residual, const float* res_scale,
+                                     const float* res_shift, void* dv, int B, int H, int W, int C, int pool, int dtype,
+                                     void* stream) {
+    SUBREG_CHECK_ARG(grad_out && raw3 && scale3 && shift3 && residual && dv && B > 0 && H > 0 && W > 0 && C > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t es = dtype == SUBREG_BF16 ? 2 : 4;
+    if (pool && hipMemsetAsync(dv, 0, (size_t)B * H * W * C * es, s) != hipSuccess) return SUBREG_EHIP;
+    const size_t n = (size_t)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * C;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(block_tail_bwd_kernel<float>, bw_blocks(n), BW_THREADS, 0, s, (const float*)grad_out, keep_mask, mask_scale,
+                                  (const float*)raw3, scale3, shift3, (const float*)residual, res_scale, res_shift, (float*)dv, B, H, W, C, pool),
+               hipLaunchKernelGGL(block_tail_bwd_kernel<__bf16>, bw_blocks(n), BW_THREADS, 0, s, (const __bf16*)grad_out, keep_mask, mask_scale,
+                                  (const __bf16*)raw3, scale3, shift3, (const __bf16*)residual, res_scale, res_shift, (__bf16*)dv, B, H, W, C, pool));
+    return launch_status();
+}
+
+extern "C" int subreg_bn_bwd_slices(long long npix) { return (int)((npix + 2047) / 2048); }
+
+extern "C" int subreg_bn_bwd(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
+                             const float* gamma, double* partial, float* dgamma, float* dbeta, void* dx, long long npix, int C,
+                             int dtype, void* stream) {
+    SUBREG_CHECK_ARG(dy && raw && mean && invstd && gamma && partial && dgamma && dbeta && dx && npix > 0 && C > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int slices = subreg_bn_bwd_slices(npix);
+    dim3 grid((C + 31) / 32, slices);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, 256, 0, s, (const float*)dy, (const float*)act, (const float*)raw, mean, invstd, partial, npix, C, 2048),
+               hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, grid, 256, 0, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, partial, npix, C, 2048));
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, (C + 255) / 256, 256, 0, s, partial, slices, C, dgamma, dbeta);
+    const size_t n = (size_t)npix * C;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, bw_blocks(n), BW_THREADS, 0, s, (const float*)dy, (const float*)act, (const float*)raw, mean, invstd, gamma, dgamma, dbeta, (float*)dx, npix, C),
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, bw_blocks(n), BW_THREADS, 0, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, gamma, dgamma, dbeta, (__bf16*)dx, npix, C));
+    return launch_status();
+}
+
+extern "C" int subreg_avgpool_bwd(const float* dfeat, void* dx, int B, int H, int W, int C, int dtype, void* stream) {
+    SUBREG_CHECK_ARG(dfeat && dx && B > 0 && H > 0 && W > 0 && C > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * H * W * C;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(avgpool_bwd_kernel<float>, bw_blocks(n), BW_THREADS, 0, s, dfeat, (float*)dx, B, H * W, C),
+               hipLaunchKernelGGL(avgpool_bwd_kernel<__bf16>, bw_blocks(n), BW_THREADS, 0, s, dfeat, (__bf16*)dx, B, H * W, C));
+    return launch_status();
+}
+
+extern "C" int subreg_conv_wgrad(const void* x, const void* dy, float* gw_packed, int B, int H, int W, int Cin, int Cout,
+                                 int ksize, int dtype, void* stream) {
+    SUBREG_CHECK_ARG(x && dy && gw_packed && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+    SUBREG_CHECK_ARG((ksize == 1 || ksize == 3) && Cin % 32 == 0 && Cout % 32 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int taps = ksize * ksize;
+    if (hipMemsetAsync(gw_packed, 0, sizeof(float) * (size_t)Cout * taps * Cin, s) != hipSuccess) return SUBREG_EHIP;
+    const ConvGeom g = make_geom(B, H, W, taps, false);
+    const int tiles = (Cout / 32) * (Cin / 32);
+    // enough waves to fill the chip, but at least 64 pixels per wave
+    long long ppw = ((long long)g.npix * tiles + 8191) / 8192;
+    ppw = ((ppw + 63) / 64) * 64;
+    if (ppw < 64) ppw = 64;
+    const int ky = (int)((g.npix + ppw * 4 - 1) / (ppw * 4));
+    dim3 grid(tiles, ky);
+#define WG(TT, TAPS) hipLaunchKernelGGL((conv_wgrad_kernel<TT, TAPS>), grid, 256, 0, s, (const TT*)x, (const TT*)dy, gw_packed, g, Cin, Cout, (int)ppw)
+    if (dtype == SUBREG_F32) { if (taps == 9) WG(float, 9); else WG(float, 1); }
+    else if (dtype == SUBREG_BF16) { if (taps == 9) WG(__bf16, 9); else WG(__bf16, 1); }
+    else return SUBREG_EINVAL;
+#undef WG
+    return launch_status();
+}
+
+extern "C" int subreg_unpack_wgrad(const float* gw_packed, float* grad_oihw, int Cout, int Cin, int ksize, int mode,
+                                   void* stream) {
+    SUBREG_CHECK_ARG(gw_packed && grad_oihw && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3));
+    SUBREG_CHECK_ARG(mode == 0 || (mode == 1 && Cin == 3));
+    const size_t n = (size_t)Cout * Cin * ksize * ksize;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, bw_blocks(n), BW_THREADS, 0, (hipStream_t)stream, gw_packed, grad_oihw, Cout, Cin, ksize, mode);
+    return launch_status();
+}
+
+extern "C" int subreg_pack_conv_weight_dgrad(const float* w_oihw, void* out, int Cout, int Cin, int ksize, int dtype,
+                                             void* stream) {
+    SUBREG_CHECK_ARG(w_oihw && out && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)Cout * Cin * ksize * ksize;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_dgrad_kernel<float>, bw_blocks(n), BW_THREADS, 0, s, w_oihw, (float*)out, Cout, Cin, ksize),
+               hipLaunchKernelGGL(pack_weight_dgrad_kernel<__bf16>, bw_blocks(n), BW_THREADS, 0, s, w_oihw, (__bf16*)out, Cout, Cin, ksize));
+    return launch_status();
+}
+
+extern "C" int subreg_sgd_momentum(float* param, const float* grad, float* momentum_buf, long long n, float lr, float momentum,
+                                   float weight_decay, int first_step, void* stream) {
+    SUBREG_CHECK_ARG(param && grad && momentum_buf && n > 0);
+    hipLaunchKernelGGL(sgd_momentum_kernel, bw_blocks((size_t)n), BW_THREADS, 0, (hipStream_t)stream, param, grad, momentum_buf,
+                       (size_t)n, lr, momentum, weight_decay, first_step);
+    return launch_status();
+}

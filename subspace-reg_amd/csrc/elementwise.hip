@@ -116,7 +116,8 @@ __global__ void bn_fold_kernel(const float* __restrict__ weight, const float* __
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
                                                           const float* __restrict__ weight, const float* __restrict__ bias,
                                                           float* __restrict__ rm, float* __restrict__ rv, float momentum,
-                                                          float eps, float* __restrict__ scale, float* __restrict__ shift) {
+                                                          float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                          float* __restrict__ save_mean, float* __restrict__ save_invstd) {
     __shared__ double r1[256], r2[256];
     const int c = blockIdx.x, tid = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
@@ -141,6 +142,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const double sc = (double)weight[c] * inv;
     scale[c] = (float)sc;
     shift[c] = (float)((double)bias[c] - mean * sc);
+    if (save_mean) save_mean[c] = (float)mean;
+    if (save_invstd) save_invstd[c] = (float)inv;
     const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
     rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * mean);
     rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * unbiased);
@@ -292,11 +295,12 @@ extern "C" int subreg_bn_fold(const float* weight, const float* bias, const floa
 
 extern "C" int subreg_bn_train_finalize(const float* stats_partial, int rows, int C, long long count, const float* weight,
                                         const float* bias, float* running_mean, float* running_var, float momentum,
-                                        float eps, float* scale, float* shift, void* stream) {
+                                        float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
+                                        void* stream) {
     SUBREG_CHECK_ARG(stats_partial && weight && bias && running_mean && running_var && scale && shift);
     SUBREG_CHECK_ARG(rows > 0 && C > 0 && count > 0);
     hipLaunchKernelGGL(bn_finalize_kernel, C, 256, 0, (hipStream_t)stream, stats_partial, rows, C,
-                       (double)count, weight, bias, running_mean, running_var, momentum, eps, scale, shift);
+                       (double)count, weight, bias, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
     return launch_status();
 }
 

@@ -37,6 +37,20 @@ class BackboneDesc(C.Structure):
                 ("ws", c_void_p * 4), ("stats", c_void_p), ("bn_eps", c_float), ("bn_momentum", c_float)]
 
 
+class ConvTrain(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("raw", "act", "mean", "invstd", "bscale", "bshift", "w_dgrad", "gw_packed", "grad_w",
+                                         "grad_gamma", "grad_beta")]
+
+
+class BlockTrain(C.Structure):
+    _fields_ = [("conv1", ConvTrain), ("conv2", ConvTrain), ("conv3", ConvTrain), ("down", ConvTrain), ("out", c_void_p)]
+
+
+class TrainDesc(C.Structure):
+    _fields_ = [("blocks", C.POINTER(BlockTrain)), ("g", c_void_p * 2), ("dv", c_void_p), ("dr", c_void_p), ("dt", c_void_p),
+                ("dr2", c_void_p), ("bn_partial", c_void_p), ("zero_shift", c_void_p), ("grad_out_dump", C.POINTER(c_void_p))]
+
+
 class LoopState(C.Structure):
     _fields_ = [("epoch", c_int), ("stop", c_int), ("stable", c_int), ("val_epoch", c_int), ("train_loss", c_float)]
 
@@ -69,7 +83,17 @@ SIGNATURES = {
     "subreg_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "subreg_conv_stats_rows": (_I, [_I, _I, _I, _I, _I]),
     "subreg_bn_fold": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _P]),
-    "subreg_bn_train_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P]),
+    "subreg_bn_train_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "subreg_pack_conv_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "subreg_conv_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "subreg_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "subreg_bn_bwd_slices": (_I, [_L]),
+    "subreg_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "subreg_block_tail_bwd": (_I, [_P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "subreg_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "subreg_sgd_momentum": (_I, [_P, _P, _P, _L, _F, _F, _F, _I, _P]),
+    "subreg_backbone_forward_stash": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P, _I, _I, _I, _P, _P]),
+    "subreg_backbone_backward": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P, _I, _I, _I, _P]),
     "subreg_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P]),
     "subreg_mask_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_random_keep_mask": (_I, [_P, _L, C.c_ulonglong, _F, _P, _P]),

@@ -199,10 +199,19 @@ class ResNet(nn.Module):
     def features(self, x, return_stages=False):
         if not x.is_cuda:
             raise RuntimeError("subreg_hip.ResNet runs on the MI355X only (no CPU fallback); move the input to cuda")
+        hb = self.hip_backbone()
         if torch.is_grad_enabled() and any(p.requires_grad for n, p in self.named_parameters()
                                            if not n.startswith("classifier")):
-            raise NotImplementedError("backbone parameters require grad: conv/BN backward (train_supervised.py) is "
-                                      "not built yet - freeze the backbone (freeze_backbone_weights, eval/util.py:62-69)")
+            # pretraining path (train_supervised.py:229-244): forward with a stash, backward on the HIP kernels
+            if not self.training or return_stages:
+                raise NotImplementedError("backbone gradients are built for train-mode forwards (model.train(), "
+                                          "train_supervised.py:207); freeze the backbone for eval-mode fine-tuning")
+            from .train import BackboneTrainFn
+            names, params = zip(*[(n, p) for n, p in self.named_parameters() if not n.startswith("classifier")])
+            feat = BackboneTrainFn.apply(x, hb, self.mask_source, names, *params)
+            for m in self._bns:
+                m.num_batches_tracked += 1
+            return feat
         hb = self.hip_backbone()
         out = hb.forward(x.float(), train=self.training, masks=self.mask_source, return_stages=return_stages)
         if self.training:

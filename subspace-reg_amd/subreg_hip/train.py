@@ -1,0 +1,143 @@
+"""Pretraining step on the HIP backbone: train-mode forward with a stash + backward, exposed to torch autograd.
+
+Counterpart of /root/reference/train_supervised.py:229-244 (`output = model(input)`; `loss.backward()`): when the
+backbone's parameters require grad, `ResNet.features` routes through `BackboneTrainFn`, whose backward fills the
+gradients of all conv weights and BN affine parameters with the gfx950 kernels of csrc/backward.hip.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class TrainStash:
+    """Caller-owned buffers of one (B, H, W) training step (include/subreg_hip.h: subreg_train_desc)."""
+
+    def __init__(self, hb, B, H, W):
+        self.hb, self.shape = hb, (B, H, W)
+        lib, dev, td = hb.lib, hb.device, hb.tdtype
+        f32 = torch.float32
+        self.keep = []                       # every tensor the descriptors point at
+        self.named = {}                      # (block, slot, field) -> tensor, for tests / diagnostics
+        self.blk = (_lib.BlockTrain * len(hb.blocks))()
+        self.desc = _lib.TrainDesc()
+        self.desc.blocks = C.cast(self.blk, C.POINTER(_lib.BlockTrain))
+
+        def buf(n, dtype=td):
+            t = torch.empty(int(n), dtype=dtype, device=dev)
+            self.keep.append(t)
+            return t
+
+        h, w, cmax, amax = H, W, 0, B * H * W * 32
+        self.grads = {}                      # state_dict key -> fp32 gradient tensor
+        self.dgrad = []                      # (conv name, cout, cin, k, packed tensor)
+        for bi, (name, cin, cout, stride, ds, _db) in enumerate(hb.blocks):
+            npix = B * h * w
+            amax, cmax = max(amax, npix * cout), max(cmax, cout)
+            convs = [("conv1", name + ".conv1", name + ".bn1", cin, 3, True), ("conv2", name + ".conv2", name + ".bn2", cout, 3, True),
+                     ("conv3", name + ".conv3", name + ".bn3", cout, 3, False)]
+            if ds:
+                convs.append(("down", name + ".downsample.0", name + ".downsample.1", cin, 1, False))
+            for slot, cname, bname, ci, k, has_act in convs:
+                tc = getattr(self.blk[bi], slot)
+                self.named[(bi, slot, "raw")] = buf(npix * cout)
+                tc.raw = self.named[(bi, slot, "raw")].data_ptr()
+                tc.act = None
+                if has_act:
+                    self.named[(bi, slot, "act")] = buf(npix * cout)
+                    tc.act = self.named[(bi, slot, "act")].data_ptr()
+                for f in ("mean", "invstd", "bscale", "bshift"):
+                    self.named[(bi, slot, f)] = buf(cout, f32)
+                    setattr(tc, f, self.named[(bi, slot, f)].data_ptr())
+                kin = 32 if ci == 3 else ci
+                kk = 1 if ci == 3 else k
+                tc.gw_packed = buf(cout * kk * kk * kin, f32).data_ptr()
+                gw = torch.zeros(cout, ci, k, k, dtype=f32, device=dev)
+                gg, gb = torch.zeros(cout, dtype=f32, device=dev), torch.zeros(cout, dtype=f32, device=dev)
+                self.grads[cname + ".weight"], self.grads[bname + ".weight"], self.grads[bname + ".bias"] = gw, gg, gb
+                tc.grad_w, tc.grad_gamma, tc.grad_beta = gw.data_ptr(), gg.data_ptr(), gb.data_ptr()
+                tc.w_dgrad = None
+                if bi > 0 or slot in ("conv2", "conv3"):      # no gradient w.r.t. the images: layer1.0 conv1/shortcut need none
+                    wd = buf(cout * k * k * ci)
+                    self.named[(bi, slot, "w_dgrad")] = wd
+                    tc.w_dgrad = wd.data_ptr()
+                    self.dgrad.append((cname, cout, ci, k, wd))
+            h, w = h // stride, w // stride
+            self.named[(bi, "out")] = buf(B * h * w * cout)
+            self.blk[bi].out = self.named[(bi, "out")].data_ptr()
+        for i in range(2):
+            self.desc.g[i] = buf(amax).data_ptr()
+        for f in ("dv", "dr", "dt", "dr2"):
+            setattr(self.desc, f, buf(amax).data_ptr())
+        self.desc.bn_partial = buf(lib.subreg_bn_bwd_slices(B * H * W) * cmax * 2, torch.float64).data_ptr()
+        z = torch.zeros(cmax, dtype=f32, device=dev)
+        self.keep.append(z)
+        self.desc.zero_shift = z.data_ptr()
+
+    def repack_dgrad(self):
+        s = _lib.stream_ptr()
+        p = self.hb.params
+        for cname, cout, ci, k, wd in self.dgrad:
+            _lib.check(self.hb.lib.subreg_pack_conv_weight_dgrad(_lib.ptr(p[cname + ".weight"]), _lib.ptr(wd), cout, ci, k,
+                                                                 self.hb.dtype, s), "pack_conv_weight_dgrad")
+
+
+class BackboneTrainFn(torch.autograd.Function):
+    """feat = backbone(x) in train mode; backward -> gradients of every backbone parameter (`names` order)."""
+
+    @staticmethod
+    def forward(ctx, x, hb, masks, names, *params):
+        B, _, H, W = x.shape
+        x = x.contiguous().float()
+        hb.refresh()
+        for i in range(len(hb.nbt)):
+            hb.nbt[i] += 1
+        stash = getattr(hb, "_train_stash", None)
+        if stash is None or stash.shape != (B, H, W):
+            stash = TrainStash(hb, B, H, W)
+        hb._train_stash = stash
+        hb._ensure_workspace(B, H, W)
+        hb._prepare_masks(B, H, W, masks)
+        stash.repack_dgrad()
+        feat = torch.empty(B, hb.out_dim, dtype=torch.float32, device=x.device)
+        _lib.check(hb.lib.subreg_backbone_forward_stash(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(x), B, H, W,
+                                                        _lib.ptr(feat), _lib.stream_ptr()), "backbone_forward_stash")
+        hb._fold_versions = None             # running statistics moved
+        ctx.hb, ctx.stash, ctx.names, ctx.bhw = hb, stash, names, (B, H, W)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        hb, stash = ctx.hb, ctx.stash
+        B, H, W = ctx.bhw
+        dfeat = dfeat.contiguous().float()
+        _lib.check(hb.lib.subreg_backbone_backward(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(dfeat), B, H, W,
+                                                   _lib.stream_ptr()), "backbone_backward")
+        grads = tuple(stash.grads[n].clone() for n in ctx.names)
+        return (None, None, None, None) + grads
+
+
+class SGD:
+    """torch.optim.SGD(momentum, weight_decay) semantics (train_supervised.py:133-136) on the fused HIP kernel."""
+
+    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0):
+        self.params = [p for p in params]
+        self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        self.bufs = [None] * len(self.params)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def step(self):
+        lib = _lib.load()
+        for i, p in enumerate(self.params):
+            if p.grad is None:
+                continue
+            first = self.bufs[i] is None
+            if first:
+                self.bufs[i] = torch.empty_like(p.data)
+            g = p.grad.contiguous()
+            _lib.check(lib.subreg_sgd_momentum(_lib.ptr(p.data), _lib.ptr(g), _lib.ptr(self.bufs[i]), p.numel(), self.lr,
+                                               self.momentum, self.weight_decay, int(first), _lib.stream_ptr()), "sgd_momentum")

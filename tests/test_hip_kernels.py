@@ -141,6 +141,9 @@ FUSED_CASES = [
     (5, 10, 10, 640, 640, 320, True),    # layer4.0
     (7, 5, 5, 640, 640, 0, False),       # layer4.1
     (2, 7, 9, 64, 96, 32, False),        # ragged N tail + ragged M
+    (6, 10, 10, 640, 320, 640, False),   # the fused input-gradient call of layer4.0 (dX(conv1) + dX(shortcut)), 64-row tiles
+    (6, 21, 21, 320, 160, 320, False),   # ... of layer3.0
+    (6, 42, 42, 160, 64, 160, False),    # ... of layer2.0 (Cout = 64 tile shape)
 ]
 
 
@@ -212,7 +215,7 @@ def test_conv_raw_stats_and_bn_train(shape, dtype):
     drm, drv, gwd, gbd = _t(rm), _t(rv), _t(gw), _t(gb)
     sc, sh = torch.empty(Cout, device=_dev()), torch.empty(Cout, device=_dev())
     _lib.check(lib.subreg_bn_train_finalize(_lib.ptr(stats), rows, Cout, B * H * W, _lib.ptr(gwd), _lib.ptr(gbd),
-                                            _lib.ptr(drm), _lib.ptr(drv), 0.1, 1e-5, _lib.ptr(sc), _lib.ptr(sh),
+                                            _lib.ptr(drm), _lib.ptr(drv), 0.1, 1e-5, _lib.ptr(sc), _lib.ptr(sh), None, None,
                                             _lib.stream_ptr()))
     _lib.check(lib.subreg_bn_apply(_lib.ptr(y), _lib.ptr(sc), _lib.ptr(sh), None, None, None, None, 1.0, _lib.ptr(y), B, H, W,
                                    Cout, _lib.CONV_LRELU, dt, _lib.stream_ptr()))

@@ -1,0 +1,184 @@
+"""GPU parity of the pretraining step (train_supervised.py:205-268: forward in train mode, loss.backward(), SGD step):
+backward kernels through the C ABI against the oracle, and the whole step against the golden produced by the
+reference's own autograd (tests/golden/train_step.npz).
+
+Tolerances: f32 mode - gradients 1e-3 of the tensor's magnitude (the reference itself accumulates weight gradients over
+B*H*W pixels in fp32), BN/activation gradients 2e-4; bf16 mode - 5e-2 of the tensor's magnitude (activations AND
+gradient tensors are rounded to bf16 between layers) on the gradient norms and the sampled tensors.
+"""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import backward_ref as br, resnet_ref as rr             # noqa: E402
+from oracle.resnet_ref import MaskSource                           # noqa: E402
+from subreg_hip import _lib, synthetic as syn                       # noqa: E402
+
+from conftest import GOLDEN                                         # noqa: E402
+from test_hip_kernels import _cmp, _dev, _nchw_host, _nhwc_dev, _round_bf16, _t   # noqa: E402
+
+
+def _td(dtype):
+    return torch.bfloat16 if dtype == "bf16" else torch.float32
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 21, 21, 64, 96, 3), (3, 10, 10, 160, 64, 1), (2, 9, 7, 32, 32, 3), (4, 5, 5, 320, 320, 3)])
+def test_conv_wgrad_and_dgrad(shape, dtype):
+    B, H, W, Cin, Cout, k = shape
+    lib = _lib.load()
+    rs = np.random.RandomState(11)
+    x = rs.standard_normal((B, Cin, H, W)).astype(np.float32)
+    dy = rs.standard_normal((B, Cout, H, W)).astype(np.float32)
+    w = (rs.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    if dtype == "bf16":
+        x, dy, w = _round_bf16(x), _round_bf16(dy), _round_bf16(w)
+    dx_ref, dw_ref = br.conv_backward(rr._nhwc(x), w, rr._nhwc(dy))
+    dt = _lib.dtype_code(dtype)
+    xd, dyd = _nhwc_dev(x, dtype), _nhwc_dev(dy, dtype)
+    gw = torch.empty(Cout * k * k * Cin, dtype=torch.float32, device=_dev())
+    grad = torch.empty(Cout, Cin, k, k, dtype=torch.float32, device=_dev())
+    _lib.check(lib.subreg_conv_wgrad(_lib.ptr(xd), _lib.ptr(dyd), _lib.ptr(gw), B, H, W, Cin, Cout, k, dt, _lib.stream_ptr()))
+    _lib.check(lib.subreg_unpack_wgrad(_lib.ptr(gw), _lib.ptr(grad), Cout, Cin, k, 0, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    _cmp("dW", grad.cpu().numpy(), dw_ref, 1e-3 * np.abs(dw_ref).max(), 1e-4)
+    # dX = forward kernel on dY with the flipped / transposed weights
+    wt, wd = _t(w), torch.empty(Cin * k * k * Cout, dtype=_td(dtype), device=_dev())
+    _lib.check(lib.subreg_pack_conv_weight_dgrad(_lib.ptr(wt), _lib.ptr(wd), Cout, Cin, k, dt, _lib.stream_ptr()))
+    dx = torch.empty(B * H * W * Cin, dtype=_td(dtype), device=_dev())
+    zero = torch.zeros(Cin, device=_dev())
+    _lib.check(lib.subreg_conv_fwd(_lib.ptr(dyd), _lib.ptr(wd), _lib.ptr(dx), None, _lib.ptr(zero), None, None, None, None, 0, B, H, W,
+                                   Cout, Cin, k, 0, dt, _lib.stream_ptr()))
+    got = _nchw_host(dx, B, Cin, H, W, dtype)
+    tol = 2e-4 if dtype == "f32" else 1e-2
+    _cmp("dX", got, rr._nchw(dx_ref), tol * np.abs(dx_ref).max(), tol)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("with_act", [False, True])
+def test_bn_backward(dtype, with_act):
+    B, H, W, Cc = 3, 10, 9, 96
+    lib = _lib.load()
+    rs = np.random.RandomState(5)
+    raw = rs.standard_normal((B, H, W, Cc)) * 1.5 + 0.3
+    dy = rs.standard_normal((B, H, W, Cc))
+    gamma, beta = rs.uniform(0.5, 1.5, Cc).astype(np.float32), (rs.standard_normal(Cc) * 0.1).astype(np.float32)
+    if dtype == "bf16":
+        raw, dy = _round_bf16(raw.astype(np.float32)).astype(np.float64), _round_bf16(dy.astype(np.float32)).astype(np.float64)
+    y, cache = br.bn_train_forward(raw, gamma, beta)
+    act = rr.leaky_relu(y)
+    if dtype == "bf16":
+        act = _round_bf16(act.astype(np.float32)).astype(np.float64)
+    g = br.lrelu_backward(dy, act) if with_act else dy
+    dx_ref, dg_ref, db_ref = br.bn_train_backward(g, cache, gamma)
+    dt, td = _lib.dtype_code(dtype), _td(dtype)
+    dev = _dev()
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev, td)
+    rawd, dyd, actd = f(raw), f(dy), f(act)
+    mean, invstd = _t(cache[2].astype(np.float32)), _t(cache[1].astype(np.float32))
+    npix = B * H * W
+    part = torch.empty(lib.subreg_bn_bwd_slices(npix) * Cc * 2, dtype=torch.float64, device=dev)
+    dgam, dbet, dx = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), torch.empty(npix * Cc, dtype=td, device=dev)
+    gd = _t(gamma)
+    _lib.check(lib.subreg_bn_bwd(_lib.ptr(dyd), _lib.ptr(actd) if with_act else None, _lib.ptr(rawd), _lib.ptr(mean), _lib.ptr(invstd),
+                                 _lib.ptr(gd), _lib.ptr(part), _lib.ptr(dgam), _lib.ptr(dbet), _lib.ptr(dx), npix, Cc, dt, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    tol = 2e-4 if dtype == "f32" else 1e-2
+    _cmp("dgamma", dgam.cpu().numpy(), dg_ref, tol * np.abs(dg_ref).max(), tol)
+    _cmp("dbeta", dbet.cpu().numpy(), db_ref, tol * np.abs(db_ref).max(), tol)
+    _cmp("dx", dx.float().cpu().numpy().reshape(B, H, W, Cc), dx_ref, tol * np.abs(dx_ref).max(), tol)
+
+
+@pytest.mark.parametrize("pool", [0, 1])
+def test_block_tail_backward(pool):
+    """keep mask * scale, MaxPool2d(2) routing to the first maximum (floor mode: 9x7 -> 4x3), LeakyReLU'."""
+    B, H, W, Cc = 2, 9, 7, 64
+    lib = _lib.load()
+    rs = np.random.RandomState(8)
+    raw3, res = rs.standard_normal((B, H, W, Cc)), rs.standard_normal((B, H, W, Cc))
+    raw3[0, 0:2, 0:2, :8] = 0.25                      # ties inside a window: gradient must go to the first element
+    res[0, 0:2, 0:2, :8] = 0.0
+    sc, sh = rs.uniform(0.5, 1.5, Cc).astype(np.float32), (rs.standard_normal(Cc) * 0.1).astype(np.float32)
+    sc[:8], sh[:8] = 1.0, 0.0
+    rsc, rsh = rs.uniform(0.5, 1.5, Cc).astype(np.float32), (rs.standard_normal(Cc) * 0.1).astype(np.float32)
+    v = raw3 * sc + sh + res * rsc + rsh
+    z = rr.leaky_relu(v)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    gout = rs.standard_normal((B, Ho, Wo, Cc))
+    keep = (rs.random_sample((B, Ho, Wo, Cc)) > 0.2)
+    want = br.lrelu_backward(br.maxpool_backward(gout * keep * 1.25, z, 2 if pool else 1), v)
+    dev = _dev()
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    r3, rd, gd, kd = f(raw3), f(res), f(gout), torch.from_numpy(keep.astype(np.uint8)).to(dev)
+    scd, shd, rscd, rshd = _t(sc), _t(sh), _t(rsc), _t(rsh)
+    dv = torch.full((B * H * W * Cc,), float("nan"), device=dev) if pool else torch.empty(B * H * W * Cc, device=dev)
+    _lib.check(lib.subreg_block_tail_bwd(_lib.ptr(gd), _lib.ptr(kd), 1.25, _lib.ptr(r3), _lib.ptr(scd), _lib.ptr(shd), _lib.ptr(rd),
+                                         _lib.ptr(rscd), _lib.ptr(rshd), _lib.ptr(dv), B, H, W, Cc, pool, _lib.F32, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    _cmp("dv", dv.cpu().numpy().reshape(B, H, W, Cc), want, 1e-5, 1e-5)
+
+
+def _train_net(dtype):
+    from subreg_hip.resnet_language import create_model
+    from test_hip_loop import make_opt
+    net = create_model("resnet18", 60, make_opt(hip_dtype=dtype))
+    sd = syn.make_state_dict(71)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    net = net.cuda()
+    net.mask_source = MaskSource(74)
+    return net
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("hw", [32, 84])
+def test_train_step_against_reference_autograd(hw, dtype):
+    from subreg_hip.train import SGD
+    g = np.load(os.path.join(GOLDEN, "train_step.npz"))
+    key = "hw%d" % hw
+    net = _train_net(dtype)
+    x = torch.from_numpy(syn.make_images(72, int(g[key + ".B"]), hw)).cuda()
+    y = torch.from_numpy(g[key + ".labels"]).cuda()
+    net.train()
+    logits = net(x)
+    loss = torch.nn.CrossEntropyLoss()(logits, y)
+    loss.backward()
+    f32 = dtype == "f32"
+    _cmp("loss", loss.item(), g[key + ".loss"], 2e-4 if f32 else 5e-2, 2e-4 if f32 else 2e-2)
+    grads = {n: p.grad.detach().cpu().numpy() for n, p in net.named_parameters()}
+    # LeakyReLU has a kink: one pre-activation within rounding distance of 0 changes its slope from 1 to 0.1 between two
+    # fp implementations and perturbs every gradient below it by ~1e-2 in a few channels (measured at hw=84: one element
+    # of layer3.1.bn2 with |y| < 1e-6; the fp64 oracle differs from the fp32 reference in the same way at layer3.0).
+    # So: element-wise 1e-3 where no such event happened (hw=32, and the layers above the event), L2-relative otherwise.
+    # bf16 rounds activations and gradient tensors between all 22 layers: direction (cosine) and norm are gated.
+    exact_prefixes = ("classifier", "layer4") if hw == 84 else ("classifier", "layer")
+    for k in g.files:
+        if k.startswith(key + ".gnorm."):
+            name = k[len(key) + 7:]
+            rel = abs(np.linalg.norm(grads[name].astype(np.float64)) - float(g[k])) / max(float(g[k]), 1e-12)
+            assert rel < (5e-3 if f32 else 0.25), ("gnorm", name, rel)
+        elif k.startswith(key + ".grad."):
+            name = k[len(key) + 6:]
+            want = g[k].astype(np.float64)
+            got = grads[name][:want.shape[0]].astype(np.float64)
+            l2 = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-20)
+            cos = float((got * want).sum() / max(np.linalg.norm(got) * np.linalg.norm(want), 1e-30))
+            if f32:
+                assert l2 < 1.5e-2, ("l2", name, l2)
+                if name.startswith(exact_prefixes):
+                    _cmp("grad " + name, got, want, 1e-3 * max(float(np.abs(want).max()), 1e-6), 2e-3)
+            elif ".conv" in name or name.startswith("classifier") or "downsample.0" in name:
+                assert cos > 0.9 and l2 < 0.5, ("bf16 direction", name, cos, l2)     # BN affine grads: norm gate only
+    if f32:
+        sdn = net.state_dict()
+        for k in ("layer1.0.bn1", "layer4.1.bn3"):
+            _cmp(k, sdn[k + ".running_mean"].cpu().numpy(), g["%s.%s.running_mean" % (key, k)], 1e-5, 1e-4)
+        opt = SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+        opt.step()
+        torch.cuda.synchronize()
+        _cmp("sgd classifier", net.classifier.weight.detach().cpu().numpy(), g[key + ".after_step.classifier.weight"], 2e-5, 1e-4)
+        _cmp("sgd conv1", dict(net.named_parameters())["layer1.0.conv1.weight"].detach().cpu().numpy(),
+             g[key + ".after_step.layer1.0.conv1.weight"], 1e-3, 1e-3)    # lr 0.05 x the kink-event gradient perturbation
