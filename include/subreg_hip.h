@@ -141,9 +141,10 @@ int subreg_backbone_forward(const subreg_backbone_desc* d, const float* x_nchw, 
 /* dX of a conv = subreg_conv_fwd on dY with these weights: OIHW fp32 -> [Cin][taps][Cout], taps flipped */
 int subreg_pack_conv_weight_dgrad(const float* w_oihw, void* out, int Cout, int Cin, int ksize, int dtype, void* stream);
 /* dW: gw_packed[Cout][taps][Cin] (fp32, zeroed here) = sum_p dY[p][o] * X[p+off(tap)][c]; then OIHW via unpack
- * (mode 1: the first layer's K=32 im2col layout back to [Cout][3][k][k]) */
-int subreg_conv_wgrad(const void* x, const void* dy, float* gw_packed, int B, int H, int W, int Cin, int Cout, int ksize,
-                      int dtype, void* stream);
+ * (mode 1: the first layer's K=32 im2col layout back to [Cout][3][k][k]).  pad_x / pad_dy: optional scratch of
+ * B*(H+2)*(W+2)*Cin resp. *Cout elements enabling the bf16-MFMA path for 3x3 convs (NULL: exact-f32 MFMA path) */
+int subreg_conv_wgrad(const void* x, const void* dy, float* gw_packed, void* pad_x, void* pad_dy, int B, int H, int W, int Cin,
+                      int Cout, int ksize, int dtype, void* stream);
 int subreg_unpack_wgrad(const float* gw_packed, float* grad_oihw, int Cout, int Cin, int ksize, int mode, void* stream);
 /* BatchNorm2d training-mode backward with the LeakyReLU' of `act` fused in (act == NULL: none):
  * g = dy*lrelu'(act); dgamma = sum g*xhat; dbeta = sum g; dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N).
@@ -189,6 +190,8 @@ typedef struct subreg_train_desc {
     void* dt;
     void* dr2;
     double* bn_partial;    /* subreg_bn_bwd_slices(B*H*W)*Cmax*2 doubles */
+    void* pad_x;           /* max over convs of B*(H+2)*(W+2)*Cin elements (bf16 wgrad scratch; may be NULL) */
+    void* pad_dy;          /* ... *Cout elements */
     const float* zero_shift; /* [Cmax] zeros */
     void* const* grad_out_dump; /* optional HOST array [n_blocks] of device buffers: receives d(loss)/d(block output)
                                    (NHWC, compute dtype) of every block for diagnostics; NULL = off */

@@ -169,6 +169,132 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
         }
 }
 
+// ---------------------------------------------------------------- weight gradient, bf16 MFMA
+// Zero-bordered copies: compact [B][H][W][C] -> padded [B][H+2][W+2][C]; in padded coordinates q a tap is the constant
+// row offset dy*(W+2)+dx and every out-of-image product vanishes because one of its factors is a border zero.
+__global__ void pad_copy_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y, int B, int H, int W, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // over padded elements / 8 (16-byte vectors)
+    const int C8 = C / 8;
+    if (i >= (size_t)B * (H + 2) * (W + 2) * C8) return;
+    const int c8 = i % C8;
+    const size_t q = i / C8;
+    const int w = q % (W + 2), h = (q / (W + 2)) % (H + 2), b = q / ((size_t)(W + 2) * (H + 2));
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (h >= 1 && h <= H && w >= 1 && w <= W)
+        v = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + (h - 1)) * W + (w - 1)) * C + c8 * 8);
+    *reinterpret_cast<uint4*>(y + q * C + c8 * 8) = v;
+}
+
+// ds_read_b64_tr_b16: per 16-lane group a 4 (rows = pixels) x 16 (columns = channels) block is delivered transposed:
+// lane i of the group gets column i, element e = row e.  Lane 4*qr+pc supplies the address of row qr, columns 4pc..4pc+3.
+__device__ __forceinline__ uint2 tr_read(unsigned addr) {
+    uint2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
+    return r;
+}
+
+// One workgroup = NCW waves: output channels [o0, o0+32) x input channels [c0, c0+32*NCW), all TAPS, over a range of padded
+// pixel rows.  Both operands are pixel-major in memory and in LDS; the MFMA wants 8 consecutive K (= pixels) per lane and
+// channel, which the transposing LDS read provides.  dW accumulated with fp32 atomics over the K splits.
+template <int NCW, int TAPS>
+__global__ __launch_bounds__(NCW * 64) void conv_wgrad_bf16_kernel(const __bf16* __restrict__ xq, const __bf16* __restrict__ dyq,
+                                                                    float* __restrict__ gw, long long Q, int Wrow, int Cin,
+                                                                    int Cout, int rows_per_block) {
+    constexpr int KCH = 64;                              // pixel rows per chunk (4 MFMA k-steps)
+    constexpr int NT = NCW * 64;
+    constexpr int XS = NCW * 64 + 16, DS = 64 + 16;      // LDS row strides (bytes): 32 channels per wave / tile + 16 B pad
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int halo = TAPS == 9 ? Wrow + 1 : 0;
+    const int xrows = KCH + 2 * halo;
+    char* const sD = smem;
+    char* const sX = smem + KCH * DS;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ncg = Cin / (32 * NCW);
+    const int o0 = (blockIdx.x / ncg) * 32, c0 = (blockIdx.x % ncg) * 32 * NCW;
+    const long long qb = (long long)blockIdx.y * rows_per_block;
+    long long qe = qb + rows_per_block;
+    if (qe > Q) qe = Q;
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // per-lane part of the transposing-read addresses
+    const int li = lane & 15, grp = lane >> 4, qr = li >> 2, pc = li & 3;
+    const unsigned a_lane = (unsigned)((8 * (grp >> 1) + qr) * DS + (16 * (grp & 1) + 4 * pc) * 2);
+    const unsigned b_lane = (unsigned)((8 * (grp >> 1) + qr) * XS + wid * 64 + (16 * (grp & 1) + 4 * pc) * 2);
+    const unsigned sD_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sD;
+    const unsigned sX_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sX;
+    for (long long q0 = qb; q0 < qe; q0 += KCH) {
+        __syncthreads();
+        for (int idx = tid; idx < KCH * 4; idx += NT) {                 // dY tile: KCH rows x 64 B
+            const int row = idx >> 2, sl = idx & 3;
+            const long long q = q0 + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q < qe) v = *reinterpret_cast<const uint4*>(dyq + (size_t)q * Cout + o0 + sl * 8);
+            *reinterpret_cast<uint4*>(sD + row * DS + sl * 16) = v;
+        }
+        for (int idx = tid; idx < xrows * NCW * 4; idx += NT) {         // X tile: (KCH + 2 halo) rows x NCW*64 B
+            const int row = idx / (NCW * 4), sl = idx % (NCW * 4);
+            const long long q = q0 - halo + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q >= 0 && q < Q) v = *reinterpret_cast<const uint4*>(xq + (size_t)q * Cin + c0 + sl * 8);
+            *reinterpret_cast<uint4*>(sX + row * XS + sl * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KCH / 16; ++ks) {
+            uint2 a0 = tr_read(sD_addr + a_lane + (16 * ks) * DS), a1 = tr_read(sD_addr + a_lane + (16 * ks + 4) * DS);
+            uint2 b0[TAPS], b1[TAPS];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int off = TAPS == 9 ? (t / 3 - 1) * Wrow + (t % 3 - 1) : 0;
+                const unsigned base = sX_addr + b_lane + (unsigned)((16 * ks + halo + off) * XS);
+                b0[t] = tr_read(base);
+                b1[t] = tr_read(base + 4 * XS);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const uint4 av = make_uint4(a0.x, a0.y, a1.x, a1.y);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const uint4 bv = make_uint4(b0[t].x, b0[t].y, b1[t].x, b1[t].y);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
+            }
+        }
+    }
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            atomicAdd(&gw[((size_t)o * TAPS + t) * Cin + c0 + wid * 32 + lr], acc[t][r]);
+        }
+}
+
+template <int NCW, int TAPS>
+static int launch_wgrad_bf16(const __bf16* xq, const __bf16* dyq, float* gw, long long Q, int Wrow, int Cin, int Cout,
+                             hipStream_t s) {
+    const int halo = TAPS == 9 ? Wrow + 1 : 0;
+    const size_t lds = (size_t)64 * (64 + 16) + (size_t)(64 + 2 * halo) * (NCW * 64 + 16);
+    if (lds > 160 * 1024) return SUBREG_EUNSUPPORTED;
+    auto kern = conv_wgrad_bf16_kernel<NCW, TAPS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return SUBREG_EHIP;
+        attr_done = true;
+    }
+    const int tiles = (Cout / 32) * (Cin / (32 * NCW));
+    long long splits = (1536 + tiles - 1) / tiles;                        // ~6 workgroups per CU in total
+    long long rpb = ((Q + splits - 1) / splits + 63) / 64 * 64;
+    if (rpb < 64) rpb = 64;
+    dim3 grid(tiles, (unsigned)((Q + rpb - 1) / rpb));
+    hipLaunchKernelGGL(kern, grid, dim3(NCW * 64), lds, s, xq, dyq, gw, Q, Wrow, Cin, Cout, (int)rpb);
+    return launch_status();
+}
+
 // packed fp32 [Cout][taps][Cin_k] -> Conv2d.weight.grad OIHW (mode 1: first-layer K=32 layout, see pack_weight_kernel)
 __global__ void unpack_wgrad_kernel(const float* __restrict__ gw, float* __restrict__ grad, int Cout, int Cin, int ks, int mode) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over OIHW
@@ -255,14 +381,33 @@ extern "C" int subreg_avgpool_bwd(const float* dfeat, void* dx, int B, int H, in
     return launch_status();
 }
 
-extern "C" int subreg_conv_wgrad(const void* x, const void* dy, float* gw_packed, int B, int H, int W, int Cin, int Cout,
-                                 int ksize, int dtype, void* stream) {
+extern "C" int subreg_conv_wgrad(const void* x, const void* dy, float* gw_packed, void* pad_x, void* pad_dy, int B, int H, int W,
+                                 int Cin, int Cout, int ksize, int dtype, void* stream) {
     SUBREG_CHECK_ARG(x && dy && gw_packed && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
     SUBREG_CHECK_ARG((ksize == 1 || ksize == 3) && Cin % 32 == 0 && Cout % 32 == 0);
     hipStream_t s = (hipStream_t)stream;
     const int taps = ksize * ksize;
     if (hipMemsetAsync(gw_packed, 0, sizeof(float) * (size_t)Cout * taps * Cin, s) != hipSuccess) return SUBREG_EHIP;
     const ConvGeom g = make_geom(B, H, W, taps, false);
+    if (dtype == SUBREG_BF16 && (taps == 1 || (pad_x && pad_dy))) {
+        // bf16 MFMA path: 3x3 on zero-bordered copies (padded pixel coordinates), 1x1 directly on the compact tensors
+        const __bf16 *xq = (const __bf16*)x, *dq = (const __bf16*)dy;
+        long long Q = g.npix;
+        if (taps == 9) {
+            Q = (long long)B * (H + 2) * (W + 2);
+            hipLaunchKernelGGL(pad_copy_kernel, bw_blocks((size_t)Q * Cin / 8), BW_THREADS, 0, s, (const __bf16*)x, (__bf16*)pad_x, B, H, W, Cin);
+            hipLaunchKernelGGL(pad_copy_kernel, bw_blocks((size_t)Q * Cout / 8), BW_THREADS, 0, s, (const __bf16*)dy, (__bf16*)pad_dy, B, H, W, Cout);
+            xq = (const __bf16*)pad_x; dq = (const __bf16*)pad_dy;
+        }
+#define WGB(NCW) (taps == 9 ? launch_wgrad_bf16<NCW, 9>(xq, dq, gw_packed, Q, W + 2, Cin, Cout, s) \
+                            : launch_wgrad_bf16<NCW, 1>(xq, dq, gw_packed, Q, W + 2, Cin, Cout, s))
+        int rc;
+        if (Cin % 160 == 0) rc = WGB(5);
+        else if (Cin % 64 == 0) rc = WGB(2);
+        else rc = WGB(1);
+#undef WGB
+        if (rc != SUBREG_EUNSUPPORTED) return rc;
+    }
     const int tiles = (Cout / 32) * (Cin / 32);
     // enough waves to fill the chip, but at least 64 pixels per wave
     long long ppw = ((long long)g.npix * tiles + 8191) / 8192;

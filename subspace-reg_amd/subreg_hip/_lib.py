@@ -48,7 +48,8 @@ class BlockTrain(C.Structure):
 
 class TrainDesc(C.Structure):
     _fields_ = [("blocks", C.POINTER(BlockTrain)), ("g", c_void_p * 2), ("dv", c_void_p), ("dr", c_void_p), ("dt", c_void_p),
-                ("dr2", c_void_p), ("bn_partial", c_void_p), ("zero_shift", c_void_p), ("grad_out_dump", C.POINTER(c_void_p))]
+                ("dr2", c_void_p), ("bn_partial", c_void_p), ("pad_x", c_void_p), ("pad_dy", c_void_p),
+                ("zero_shift", c_void_p), ("grad_out_dump", C.POINTER(c_void_p))]
 
 
 class LoopState(C.Structure):
@@ -85,7 +86,7 @@ SIGNATURES = {
     "subreg_bn_fold": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _P]),
     "subreg_bn_train_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "subreg_pack_conv_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    "subreg_conv_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "subreg_conv_wgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "subreg_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "subreg_bn_bwd_slices": (_I, [_L]),
     "subreg_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),

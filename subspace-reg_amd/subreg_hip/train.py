@@ -29,12 +29,13 @@ class TrainStash:
             self.keep.append(t)
             return t
 
-        h, w, cmax, amax = H, W, 0, B * H * W * 32
+        h, w, cmax, amax, pmax = H, W, 0, B * H * W * 32, 0
         self.grads = {}                      # state_dict key -> fp32 gradient tensor
         self.dgrad = []                      # (conv name, cout, cin, k, packed tensor)
         for bi, (name, cin, cout, stride, ds, _db) in enumerate(hb.blocks):
             npix = B * h * w
             amax, cmax = max(amax, npix * cout), max(cmax, cout)
+            pmax = max(pmax, B * (h + 2) * (w + 2) * cout)
             convs = [("conv1", name + ".conv1", name + ".bn1", cin, 3, True), ("conv2", name + ".conv2", name + ".bn2", cout, 3, True),
                      ("conv3", name + ".conv3", name + ".bn3", cout, 3, False)]
             if ds:
@@ -70,6 +71,8 @@ class TrainStash:
             self.desc.g[i] = buf(amax).data_ptr()
         for f in ("dv", "dr", "dt", "dr2"):
             setattr(self.desc, f, buf(amax).data_ptr())
+        self.desc.pad_x = buf(pmax).data_ptr() if hb.dtype == _lib.BF16 else None
+        self.desc.pad_dy = buf(pmax).data_ptr() if hb.dtype == _lib.BF16 else None
         self.desc.bn_partial = buf(lib.subreg_bn_bwd_slices(B * H * W) * cmax * 2, torch.float64).data_ptr()
         z = torch.zeros(cmax, dtype=f32, device=dev)
         self.keep.append(z)

@@ -27,7 +27,8 @@ def _td(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("shape", [(2, 21, 21, 64, 96, 3), (3, 10, 10, 160, 64, 1), (2, 9, 7, 32, 32, 3), (4, 5, 5, 320, 320, 3)])
+@pytest.mark.parametrize("shape", [(2, 21, 21, 64, 96, 3), (3, 10, 10, 160, 64, 1), (2, 9, 7, 32, 32, 3), (4, 5, 5, 320, 320, 3),
+                                   (2, 42, 42, 160, 160, 3), (3, 84, 84, 32, 64, 1), (2, 84, 84, 64, 64, 3), (3, 10, 10, 640, 320, 1)])
 def test_conv_wgrad_and_dgrad(shape, dtype):
     B, H, W, Cin, Cout, k = shape
     lib = _lib.load()
@@ -42,7 +43,9 @@ def test_conv_wgrad_and_dgrad(shape, dtype):
     xd, dyd = _nhwc_dev(x, dtype), _nhwc_dev(dy, dtype)
     gw = torch.empty(Cout * k * k * Cin, dtype=torch.float32, device=_dev())
     grad = torch.empty(Cout, Cin, k, k, dtype=torch.float32, device=_dev())
-    _lib.check(lib.subreg_conv_wgrad(_lib.ptr(xd), _lib.ptr(dyd), _lib.ptr(gw), B, H, W, Cin, Cout, k, dt, _lib.stream_ptr()))
+    pads = [torch.empty(B * (H + 2) * (W + 2) * c, dtype=_td(dtype), device=_dev()) for c in (Cin, Cout)] if dtype == "bf16" else [None, None]
+    _lib.check(lib.subreg_conv_wgrad(_lib.ptr(xd), _lib.ptr(dyd), _lib.ptr(gw), _lib.ptr(pads[0]), _lib.ptr(pads[1]), B, H, W, Cin, Cout,
+                                     k, dt, _lib.stream_ptr()))
     _lib.check(lib.subreg_unpack_wgrad(_lib.ptr(gw), _lib.ptr(grad), Cout, Cin, k, 0, _lib.stream_ptr()))
     torch.cuda.synchronize()
     _cmp("dW", grad.cpu().numpy(), dw_ref, 1e-3 * np.abs(dw_ref).max(), 1e-4)

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Pretraining-step benchmark (BASELINE.json configs[2]: train_supervised.py step, ResNet18, batch 64, bf16, 1 GPU):
+train-mode forward with stash + backward + SGD(0.05, 0.9, 5e-4) on all 26.29 M parameters, synthetic 84x84 batch.
+Algorithmic work: 24.339 GFLOP per image (fwd + dgrad + wgrad)."""
+import argparse
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "subspace-reg_amd")]
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+from subreg_hip import synthetic as syn                 # noqa: E402
+from subreg_hip.resnet_language import create_model     # noqa: E402
+from subreg_hip.train import SGD                        # noqa: E402
+from types import SimpleNamespace                       # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    net = create_model("resnet18", 60, SimpleNamespace(no_dropblock=True, linear_bias=False, hip_dtype=a.dtype))
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in syn.make_state_dict(1, randomize_bn=False).items()})
+    net = net.to(dev).train()
+    opt = SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+    crit = torch.nn.CrossEntropyLoss()
+    x = torch.randn(a.batch, 3, 84, 84, device=dev)
+    y = torch.randint(0, 60, (a.batch,), device=dev)
+
+    def step():
+        out = net(x)
+        loss = crit(out, y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print("train step B=%d %s: %.2f ms/step, %.0f img/s, %.1f TFLOP/s algorithmic (24.339 GFLOP/img), loss %.3f" %
+          (a.batch, a.dtype, dt * 1e3, a.batch / dt, a.batch * 24.339e9 / dt / 1e12, loss.item()))
+
+
+if __name__ == "__main__":
+    main()
