@@ -56,33 +56,50 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const T* __restrict__ raw, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, double* __restrict__ partial,
                                                             long long npix, int C, int pix_per_slice) {
-    // fp64 accumulation like the reference's CPU batch_norm backward (acc_type<float> = double): d beta of a BN that
-    // feeds another BN is a sum with near-total cancellation, fp32 partial sums lose 2-3 digits there
-    __shared__ double s1[8][33], s2[8][33];
-    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
-    const long long p0 = (long long)blockIdx.y * pix_per_slice;
+    // 16-byte vector loads: thread = (channel group of VEC channels, pixel lane); per-thread fp32 partials over <= ~100
+    // pixels, then fp64 across the pixel lanes and slices like the reference's CPU batch_norm backward
+    // (acc_type<float> = double): d beta of a BN that feeds another BN is a sum with near-total cancellation.
+    constexpr int VEC = 16 / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char bsm[];
+    const int ngrp = C / VEC;                      // channel groups per pixel row
+    const int lanes = 256 / ngrp;                  // pixel lanes of this block (threads beyond lanes*ngrp idle)
+    const int tid = threadIdx.x, cg = tid % ngrp, pl = tid / ngrp;
+    const long long p0 = (long long)blockIdx.x * pix_per_slice;
     long long p1 = p0 + pix_per_slice;
     if (p1 > npix) p1 = npix;
-    double a1 = 0.0, a2 = 0.0;
-    if (c < C) {
-        const double m = mean[c], is = invstd[c];
-        for (long long p = p0 + py; p < p1; p += 8) {
-            float g = ElemTraits<T>::to_float(dy[p * C + c]);
-            if (act) g *= lrelu_grad(ElemTraits<T>::to_float(act[p * C + c]));
-            a1 += (double)g;
-            a2 += (double)g * ((double)ElemTraits<T>::to_float(raw[p * C + c]) - m) * is;
+    float a1[VEC], a2[VEC], m[VEC], is[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { a1[k] = 0.f; a2[k] = 0.f; m[k] = mean[cg * VEC + k]; is[k] = invstd[cg * VEC + k]; }
+    if (pl < lanes) {
+        for (long long p = p0 + pl; p < p1; p += lanes) {
+            const size_t e = (size_t)p * C + cg * VEC;
+            const uint4 vd = *reinterpret_cast<const uint4*>(dy + e), vr = *reinterpret_cast<const uint4*>(raw + e);
+            uint4 va = make_uint4(0, 0, 0, 0);
+            if (act) va = *reinterpret_cast<const uint4*>(act + e);
+            const T* td = reinterpret_cast<const T*>(&vd);
+            const T* tr = reinterpret_cast<const T*>(&vr);
+            const T* ta = reinterpret_cast<const T*>(&va);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float g = ElemTraits<T>::to_float(td[k]);
+                if (act) g *= lrelu_grad(ElemTraits<T>::to_float(ta[k]));
+                a1[k] += g;
+                a2[k] += g * (ElemTraits<T>::to_float(tr[k]) - m[k]) * is[k];
+            }
         }
     }
-    s1[py][cx] = a1;
-    s2[py][cx] = a2;
-    __syncthreads();
-    if (py == 0 && c < C) {
-        double t1 = 0.0, t2 = 0.0;
+    float* s1 = reinterpret_cast<float*>(bsm);     // [lanes][C] x 2
+    float* s2 = s1 + (size_t)lanes * C;
+    if (pl < lanes) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { t1 += s1[k][cx]; t2 += s2[k][cx]; }
-        partial[((size_t)blockIdx.y * C + c) * 2] = t1;
-        partial[((size_t)blockIdx.y * C + c) * 2 + 1] = t2;
+        for (int k = 0; k < VEC; ++k) { s1[pl * C + cg * VEC + k] = a1[k]; s2[pl * C + cg * VEC + k] = a2[k]; }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int l = 0; l < lanes; ++l) { t1 += (double)s1[l * C + c]; t2 += (double)s2[l * C + c]; }
+        partial[((size_t)blockIdx.x * C + c) * 2] = t1;
+        partial[((size_t)blockIdx.x * C + c) * 2 + 1] = t2;
     }
 }
 
@@ -352,7 +369,7 @@ extern "C" int subreg_block_tail_bwd(const void* grad_out, const unsigned char* 
     return launch_status();
 }
 
-extern "C" int subreg_bn_bwd_slices(long long npix) { return (int)((npix + 2047) / 2048); }
+extern "C" int subreg_bn_bwd_slices(long long npix) { return (int)((npix + 255) / 256); }
 
 extern "C" int subreg_bn_bwd(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
                              const float* gamma, double* partial, float* dgamma, float* dbeta, void* dx, long long npix, int C,
@@ -360,10 +377,12 @@ extern "C" int subreg_bn_bwd(const void* dy, const void* act, const void* raw, c
     SUBREG_CHECK_ARG(dy && raw && mean && invstd && gamma && partial && dgamma && dbeta && dx && npix > 0 && C > 0);
     hipStream_t s = (hipStream_t)stream;
     const int slices = subreg_bn_bwd_slices(npix);
-    dim3 grid((C + 31) / 32, slices);
+    const int vec = dtype == SUBREG_BF16 ? 8 : 4;
+    SUBREG_CHECK_ARG(C % vec == 0 && C / vec <= 256);
+    const size_t lds = (size_t)(256 / (C / vec)) * C * 2 * sizeof(float);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, 256, 0, s, (const float*)dy, (const float*)act, (const float*)raw, mean, invstd, partial, npix, C, 2048),
-               hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, grid, 256, 0, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, partial, npix, C, 2048));
+               hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, slices, 256, lds, s, (const float*)dy, (const float*)act, (const float*)raw, mean, invstd, partial, npix, C, 256),
+               hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, slices, 256, lds, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, partial, npix, C, 256));
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, (C + 255) / 256, 256, 0, s, partial, slices, C, dgamma, dbeta);
     const size_t n = (size_t)npix * C;
     DISPATCH_T(dtype,
