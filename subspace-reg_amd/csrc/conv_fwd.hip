@@ -23,6 +23,8 @@
 // chunk ahead, the per-tap weight tile one step ahead, one barrier per step.
 //   bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate      (throughput mode)
 //   f32 : v_mfma_f32_32x32x2_f32, bitwise an fmaf chain  (parity mode, 1e-4 gate)
+#include <stdlib.h>
+
 #include "conv_index.h"
 #include "subreg_common.h"
 
@@ -390,6 +392,39 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
         }
         return;
     }
+    if constexpr (POOL && SLAB_FITS) if (full && !res) {
+        // Full pooled tile: 2x2 max in registers (4 consecutive accumulator registers = one window), the 8 pooled rows
+        // of every 32-row slab staged through LDS and written as whole 16-byte vectors.
+        constexpr int TNW = NJ * 32, RS = TNW * ELEM + 16, VPR = TNW * ELEM / 16, NV = 8 * VPR;
+        char* const slab = smem + wid * (32 * RS);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + (wave_n * NJ + j) * 32 + lr;
+                const float sh = a.shift[n], sc = a.scale ? a.scale[n] : 1.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float best = fmaxf(fmaxf(acc[i][j][4 * q] * sc + sh, acc[i][j][4 * q + 1] * sc + sh),
+                                       fmaxf(acc[i][j][4 * q + 2] * sc + sh, acc[i][j][4 * q + 3] * sc + sh));
+                    if (a.act) best = fmaxf(best, best * 0.1f);       // monotone => lrelu(max) == max(lrelu)
+                    *reinterpret_cast<T*>(slab + (2 * q + lh) * RS + (j * 32 + lr) * ELEM) = ElemTraits<T>::from_float(best);
+                }
+            }
+            const int win0 = (m0 + (wave_m * NI + i) * 32) >> 2;      // first pooled pixel of this slab
+            char* const ybase = a.y + ((size_t)win0 * a.Cout + n0 + wave_n * TNW) * ELEM;
+#pragma unroll
+            for (int v0 = 0; v0 < NV; v0 += 64) {
+                const int v = v0 + lane;
+                if (NV % 64 == 0 || v < NV) {
+                    const int row = v / VPR, c16 = v % VPR;
+                    const uint4 val = *reinterpret_cast<const uint4*>(slab + row * RS + c16 * 16);
+                    *reinterpret_cast<uint4*>(ybase + (size_t)row * a.Cout * ELEM + c16 * 16) = val;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + (wave_n * NJ + j) * 32 + lr;
@@ -540,9 +575,10 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
         }
         const long long nt = Cout / 160;
         if (raw || ((a.g.M + 255) / 256) * nt >= 384) return launch_shape<__bf16, 2, 5, 4, 1, 1, 432, 560, 2>(a, pool, s);
-        if (((a.g.M + 127) / 128) * nt >= 384) return launch_shape<__bf16, 1, 5, 4, 1, 1, 192, 432, 2>(a, pool, s);
-        // smallest maps (5x5): too few tiles to hide the per-step LDS-DMA latency by occupancy => 3 taps per step
-        return launch_shape<__bf16, 1, 5, 2, 1, 3, 128, 432, 2>(a, pool, s);
+        // small maps (10x10, 5x5): 128-row tiles.  If they all fit one per CU (<= 256 workgroups) stage 3 taps per step
+        // (84 KB LDS, covers the LDS-DMA latency at that occupancy); otherwise 1 tap per step and 3 workgroups per CU.
+        if (((a.g.M + 127) / 128) * nt > 256) return launch_shape<__bf16, 1, 5, 4, 1, 1, 192, 432, 2>(a, pool, s);
+        return launch_shape<__bf16, 1, 5, 4, 1, 3, 192, 432, 2>(a, pool, s);
     }
     return wide ? launch_shape<float, 2, 5, 2, 1, 1, 304, 408, 1>(a, pool, s) : launch_shape<float, 2, 2, 2, 1, 1, 304, 408, 1>(a, pool, s);
 }
