@@ -52,11 +52,12 @@ const char* subreg_strerror(int code);
 /* First layer (Cin = 3): x NCHW fp32 [B,3,H,W] -> im2col rows [B*H*W][32], k = 3*(3*ky+kx)+c, zero padded.
  * Turns models/resnet_language.py:249 (conv1 of layer1.0) and :146 (its 1x1 shortcut) into K=32 GEMMs. */
 int subreg_pack_input(const float* x_nchw, void* col, int B, int H, int W, int dtype, void* stream);
-/* Conv2d.weight OIHW fp32 -> [Cout][k*k][Cin] (mode 0) or the K=32 first-layer layout (mode 1, Cin == 3);
+/* Conv2d.weight OIHW fp32 -> [k*k][Cin/32][Cout][32] (mode 0: one (tap, 32-channel chunk) tile = Cout contiguous rows,
+ * the unit subreg_conv_fwd stages) or the K=32 first-layer layout [Cout][32] (mode 1, Cin == 3);
  * fold_scale [Cout] (may be NULL) multiplies output channel o by fold_scale[o] (eval-mode BN scale folded in). */
 int subreg_pack_conv_weight(const float* w_oihw, const float* fold_scale, void* out, int Cout, int Cin, int ksize, int mode,
                             int dtype, void* stream);
-/* identity weights [C][C] for the identity-shortcut GEMM (layer3.1 / layer4.1, resnet_language.py:271,288) */
+/* identity weights [C/32][C][32] (the 1x1 layout above) for the identity-shortcut GEMM (layer3.1 / layer4.1, resnet_language.py:271,288) */
 int subreg_pack_identity(void* out, int C, int dtype, void* stream);
 int subreg_vec_add(float* dst, const float* a, const float* b, int n, void* stream);
 int subreg_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, int dtype, void* stream);
@@ -65,7 +66,7 @@ int subreg_nhwc_to_nchw(const void* x_nhwc, float* y_nchw, int B, int C, int H, 
 /* ---- convolution: replaces nn.Conv2d (conv3x3 :402-405, 1x1 shortcut :146-147) + fused epilogue -------- */
 /* y = [pool2]( [lrelu]( (conv(x,w) + x2*w2^T) * scale + shift [+ residual] ) ), or with SUBREG_CONV_RAW_STATS:
  * y = conv(x,w) and stats_partial[rows][Cout][2] (rows = subreg_conv_stats_rows).  scale == NULL: already folded into
- * the packed weights.  (x2 [B*H*W][Cin2], w2 [Cout][Cin2]) is the fused shortcut GEMM of BasicBlock.forward :286-288
+ * the packed weights.  (x2 [B*H*W][Cin2], w2 [Cin2/32][Cout][32]) is the fused shortcut GEMM of BasicBlock.forward :286-288
  * (1x1 conv+BN, or the identity with w2 = I); x2 == NULL: none.  Cin, Cin2, Cout multiples of 32; ksize 1 or 3. */
 int subreg_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* shift, const void* residual,
                     float* stats_partial, const void* x2, const void* w2, int Cin2, int B, int H, int W, int Cin, int Cout,
@@ -110,7 +111,7 @@ typedef struct subreg_conv_desc {
 
 typedef struct subreg_block_desc {
     subreg_conv_desc conv1, conv2, conv3, down;
-    const void* w_identity;         /* [cout][cout] identity (subreg_pack_identity) for an identity shortcut, else NULL */
+    const void* w_identity;         /* [cout/32][cout][32] identity (subreg_pack_identity) for an identity shortcut, else NULL */
     float* shift3;                  /* [cout] conv3 epilogue shift: bn3 shift + shortcut-BN shift, written by the fold */
     int stride;                     /* 2: MaxPool2d(2); 1: identity */
     const unsigned char* keep_mask; /* train: NHWC u8 keep mask of the block output, NULL = keep all */
@@ -138,7 +139,7 @@ int subreg_backbone_forward(const subreg_backbone_desc* d, const float* x_nchw, 
                             float* const* stage_out, int flags, void* stream);
 
 /* ---- pretraining step: train_supervised.py:205-268 (output = model(input); loss.backward()) ----------------- */
-/* dX of a conv = subreg_conv_fwd on dY with these weights: OIHW fp32 -> [Cin][taps][Cout], taps flipped */
+/* dX of a conv = subreg_conv_fwd on dY with these weights: OIHW fp32 -> [taps][Cout/32][Cin][32], taps flipped */
 int subreg_pack_conv_weight_dgrad(const float* w_oihw, void* out, int Cout, int Cin, int ksize, int dtype, void* stream);
 /* dW: gw_packed[Cout][taps][Cin] (fp32, zeroed here) = sum_p dY[p][o] * X[p+off(tap)][c]; then OIHW via unpack
  * (mode 1: the first layer's K=32 im2col layout back to [Cout][3][k][k]).  pad_x / pad_dy: optional scratch of

@@ -322,14 +322,16 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ gw, float* __restr
     else grad[i] = gw[(size_t)o * 32 + (ks == 3 ? 3 * t + c : 12 + c)];
 }
 
-// OIHW fp32 -> dgrad operand [Cin][taps][Cout] T with the taps flipped: dX = conv(dY, this)
+// OIHW fp32 -> dgrad operand: the forward weight layout [taps][Cout/32][Cin][32] T of the transposed conv (output
+// channels = Cin, reduction over Cout) with the taps flipped: dX = conv(dY, this)
 template <typename T>
 __global__ void pack_weight_dgrad_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int ks) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [Cin][taps][Cout]
     const int taps = ks * ks;
     if (i >= (size_t)Cin * taps * Cout) return;
-    const int o = i % Cout, t = (i / Cout) % taps, c = i / ((size_t)Cout * taps);
-    out[i] = ElemTraits<T>::from_float(w[((size_t)o * Cin + c) * taps + (taps - 1 - t)]);
+    const int nch = Cout / 32;
+    const int o32 = i % 32, c = (i / 32) % Cin, ch = (i / ((size_t)32 * Cin)) % nch, t = i / ((size_t)32 * Cin * nch);
+    out[i] = ElemTraits<T>::from_float(w[((size_t)(ch * 32 + o32) * Cin + c) * taps + (taps - 1 - t)]);
 }
 
 // torch.optim.SGD (dampening 0, no nesterov): d = g + wd*p; buf = first ? d : m*buf + d; p -= lr*buf

@@ -10,8 +10,8 @@
 // eval/language_eval.py:211) it writes the raw convolution and per-channel
 // partial sums for the batch statistics instead (elementwise.hip finishes it).
 //
-// Data layout: activations compact NHWC [B*H*W][C]; weights [Cout][tap][Cin]
-// (tap = 3*ky+kx), both in the compute type T (bf16 or f32).  One workgroup
+// Data layout: activations compact NHWC [B*H*W][C]; weights [tap][Cin/32][Cout][32]
+// (tap = 3*ky+kx; one (tap, 32-channel chunk) tile = Cout contiguous rows), both in the compute type T (bf16 or f32).  One workgroup
 // computes TM rows x TN channels.  Per 32-channel chunk of Cin it stages the
 // CONTIGUOUS pixel range that the tile touches through all nine taps (the
 // "patch": tile rows +- (W+1) pixels) into LDS once and reuses it for the 9 taps;
@@ -21,28 +21,57 @@
 // Staging is LDS-DMA (global_load_lds_dwordx4: lane-linear LDS image, the swizzle
 // is applied to the per-lane SOURCE address): the patch is double-buffered one
 // chunk ahead, the per-tap weight tile one step ahead, one barrier per step.
-//   bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate      (throughput mode)
+//   bf16: v_mfma_f32_16x16x32_bf16, fp32 accumulate      (throughput mode; the 16x16 shape holds a higher clock
+//         under load than 32x32x16 at equal cycles per FLOP - MI355X_MICROARCH.md, DVFS give-back item 7)
 //   f32 : v_mfma_f32_32x32x2_f32, bitwise an fmaf chain  (parity mode, 1e-4 gate)
 #include <stdlib.h>
 
 #include "conv_index.h"
 #include "subreg_common.h"
 
+// Build-time switches.  DIAG is for measurements only; the others are design alternatives that were built, verified
+// bit-for-bit against the same tests and measured on MI355X (tools/bench_conv.py, B=256, whole conv stack), kept so the
+// next experiment starts from working code.  Defaults are the fastest measured combination.
+#ifndef SUBREG_DIAG
+#define SUBREG_DIAG 0            // 1 = no in-loop staging, 2 = no LDS reads / MFMAs (both: wrong results, timing only);
+                                 // 3 = per-wave s_memtime stamps into `stats` of a non-raw call (tools/diag_conv.py)
+#endif
+#ifndef SUBREG_BF16_MFMA16
+#define SUBREG_BF16_MFMA16 1     // 1: v_mfma_f32_16x16x32_bf16, 0: v_mfma_f32_32x32x16_bf16.  Equal within 1 % once the B
+                                 // fragments are ring-pipelined; the 16x16 shape lets the 32x160 tiles pipeline too (+15 %)
+#endif
+#ifndef SUBREG_DMA_INTERLEAVE
+#define SUBREG_DMA_INTERLEAVE 0  // 1: issue the step's DMAs between MFMA groups instead of in a burst: -3 % (fewer issue
+                                 // stalls, but the weights land later and the end-of-step wait grows by as much)
+#endif
+#ifndef SUBREG_WRING3
+#define SUBREG_WRING3 0          // 1: weight tiles staged two steps ahead (3 buffers): 0 % on 64x160 wave tiles, -15 % on
+                                 // the 128-row tiles (one workgroup fewer per CU)
+#endif
+#ifndef SUBREG_TM512
+#define SUBREG_TM512 0           // 1: 512-row, 8-wave workgroups for the big wide layers: -10..20 % at 42x42 / 21x21
+#endif
+
 namespace subreg {
 
 template <typename T> struct KT;
 template <> struct KT<__bf16> {
-    static constexpr int ELEM = 2, SLOTS = 4, KSTEPS = 2, ROWB = 64;
+    // TR: MFMA tile height/width; KSTEPS: MFMA k-steps per 32-channel chunk
+#if SUBREG_BF16_MFMA16
+    static constexpr int ELEM = 2, SLOTS = 4, KSTEPS = 1, ROWB = 64, TR = 16;
+#else
+    static constexpr int ELEM = 2, SLOTS = 4, KSTEPS = 2, ROWB = 64, TR = 32;
+#endif
 };
 template <> struct KT<float> {
-    static constexpr int ELEM = 4, SLOTS = 8, KSTEPS = 4, ROWB = 128;
+    static constexpr int ELEM = 4, SLOTS = 8, KSTEPS = 4, ROWB = 128, TR = 32;
 };
 
 struct ConvArgs {
     const char* x;       // [npix][Cin] T
-    const char* w;       // [Cout][taps][Cin] T
+    const char* w;       // [taps][Cin/32][Cout][32] T
     const char* x2;      // fused shortcut GEMM: [npix][Cin2] T (centre tap only) or null
-    const char* w2;      // [Cout][Cin2] T
+    const char* w2;      // [Cin2/32][Cout][32] T
     char* y;             // LINEAR [npix][Cout] T ; POOL [B*Hp*Wp][Cout] T
     const float* scale;  // [Cout] or null (scale folded into the weights)
     const float* shift;  // [Cout]
@@ -54,13 +83,32 @@ struct ConvArgs {
     int raw;             // write the un-normalised conv + stats partials
 };
 
+// Depth of the weight-tile ring.  The L2 -> LDS latency of a tile under load (1300+ cycles by in-kernel stamps) exceeds
+// one step of a 64x160 wave tile, so stage two steps ahead wherever three buffers still leave two workgroups per CU.
+constexpr int weight_buffers(int abuf, int bbuf) {
+    return SUBREG_WRING3 && 2 * (2 * abuf + 3 * bbuf) <= 160 * 1024 ? 3 : 2;
+}
+
+template <int TR> struct AccT;                       // accumulator registers of one TR x TR tile (TR*TR/64 per lane)
+template <> struct AccT<32> { typedef f32x16 type; };
+template <> struct AccT<16> { typedef f32x4 type; };
+
 template <typename T>
 __device__ __forceinline__ void mma_step(const uint4& a, const uint4& b, f32x16& acc);
 
+// 16x16x32: lane l holds k = 8*(l/16) .. +7 of row (column) l%16; D[4*(l/16) + r][l%16] in register r
+__device__ __forceinline__ void mma_step16(const uint4& a, const uint4& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
+                                                  0, 0, 0);
+}
 template <>
 __device__ __forceinline__ void mma_step<__bf16>(const uint4& a, const uint4& b, f32x16& acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
                                                   0, 0, 0);
+}
+template <typename T>
+__device__ __forceinline__ void mma_step(const uint4& a, const uint4& b, f32x4& acc) {
+    mma_step16(a, b, acc);
 }
 template <>
 __device__ __forceinline__ void mma_step<float>(const uint4& a, const uint4& b, f32x16& acc) {
@@ -78,7 +126,12 @@ __device__ __forceinline__ void mma_step<float>(const uint4& a, const uint4& b, 
 // the next ds_read of ANY LDS address, which drains the prefetch every step; asm DMAs are invisible to that pass, so
 // the counted `s_waitcnt vmcnt(N)` + `s_barrier` at the end of each step are the only (hand-placed) waits on them.
 // M0 (the DMA's LDS base) is compiler-reserved: save / set / restore inside the one statement.
-__device__ __forceinline__ void dma16(const char* base, unsigned voff, unsigned lds_addr) {
+__device__ __forceinline__ void dma16(const char* base_in, unsigned voff, unsigned lds_addr) {
+    // the base is wave-uniform by construction; say so where the compiler's uniformity analysis cannot see it
+    const unsigned long long bu = (unsigned long long)(size_t)base_in;
+    const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bu);
+    const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bu >> 32));
+    const char* base = (const char*)(size_t)(((unsigned long long)bhi << 32) | blo);
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -91,7 +144,7 @@ __device__ __forceinline__ void dma16(const char* base, unsigned voff, unsigned 
         : "memory");
 }
 
-// NI x NJ 32x32 accumulator tiles per wave; WAVES_M x WAVES_N waves per workgroup; TPS taps staged per step
+// NI x NJ 32x32 accumulator blocks per wave (held as TR x TR MFMA tiles); WAVES_M x WAVES_N waves per workgroup; TPS taps staged per step
 // (one barrier per step); MINW = minimum waves per SIMD the register allocation must allow.
 template <typename T, int NI, int NJ, int WAVES_M, int WAVES_N, int TAPS, int TPS, bool POOL, int AROWS, int MINW>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(const ConvArgs a) {
@@ -104,7 +157,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
     constexpr int BTAP = TN * ROWB;                      // one tap's weight tile
     constexpr int BBUF = TPS * BTAP;
     constexpr int B_BASE = 2 * ABUF;
+    constexpr int NWB = weight_buffers(ABUF, BBUF);      // weight ring depth: steps are staged NWB-1 ahead
     constexpr int CENTER = TAPS / 2;
+    constexpr int TR = K::TR, LG = 64 / TR, NR = TR * TR / 64;   // MFMA tile edge, lane groups per tile, regs per tile
+    constexpr int MI = NI * 32 / TR, MJ = NJ * 32 / TR;          // MFMA tiles per wave
+    static_assert(K::KSTEPS * LG == SLOTS, "one row = KSTEPS k-steps of LG 16-byte slots");
+    typedef typename AccT<TR>::type acc_t;
     constexpr int NG = TAPS / TPS;                       // tap groups (= steps) per chunk
     static_assert(AROWS % RPP == 0 && TN % RPP == 0 && TAPS % TPS == 0, "DMA pieces must tile the buffers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -112,7 +170,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wid / WAVES_N, wave_n = wid % WAVES_N;
-    const int lr = lane & 31, lh = lane >> 5;
+    const int lr = lane % TR, lh = lane / TR;            // column (A: row) within an MFMA tile, k-slot / row group
     const ConvGeom g = a.g;
     // XCD-aware tile order (MI355X: 8 XCDs with private L2s, workgroups dealt round-robin): give each XCD one
     // CONTIGUOUS range of tiles, n-tile fastest, so that the halo rows two neighbouring m-tiles share and the whole
@@ -137,11 +195,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
         *reinterpret_cast<uint4*>(smem + b * ABUF + AROWS * ROWB + q * 16) = make_uint4(0, 0, 0, 0);
     }
 
-    // per-lane LDS addresses of this lane's A rows for every tap (k-step 0; k-step s is addr ^ 32*s)
-    int aaddr[NI][TAPS];
+    // per-lane LDS addresses of this lane's A rows for every tap (k-step 0; k-step s is addr ^ 16*LG*s): logical slot
+    // LG*s + lh of the row, physical slot = logical ^ swz.  Kept as 16-bit halves (every patch buffer is < 64 KiB):
+    // the 16x16 MFMA shape needs MI = 4 row addresses per tap and the accumulators leave no room for 36 registers.
+    static_assert(ABUF < 65536, "packed A addresses are 16-bit");
+    constexpr int NAP = (MI * TAPS + 1) / 2;
+    unsigned apk[NAP];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int m = m0 + (wave_m * NI + i) * 32 + lr;
+    for (int k = 0; k < NAP; ++k) apk[k] = 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + (wave_m * MI + i) * TR + lr;
         const bool mv = m < g.M;
         const Pix px = row_to_pixel<POOL>(g, mv ? m : 0);
 #pragma unroll
@@ -149,25 +213,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
             const int dy = TAPS == 9 ? t / 3 - 1 : 0, dx = TAPS == 9 ? t % 3 - 1 : 0;
             const bool ok = mv && tap_valid(g, px.h, px.w, dy, dx);
             const int row = px.p + dy * g.W + dx - plo;
-            const int f = swz<SLOTS>(row);
-            aaddr[i][t] = ok ? row * ROWB + 32 * (f >> 1) + 16 * (lh ^ (f & 1)) : AROWS * ROWB + 16 * lh;
+            const unsigned ad = ok ? row * ROWB + 16 * (lh ^ swz_tr<SLOTS, TR>(row)) : AROWS * ROWB + 16 * lh;
+            apk[(i * TAPS + t) >> 1] |= ad << (16 * ((i * TAPS + t) & 1));
         }
     }
-    int baddr[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int nl = (wave_n * NJ + j) * 32 + lr;
-        const int f = swz<SLOTS>(nl);
-        baddr[j] = B_BASE + nl * ROWB + 32 * (f >> 1) + 16 * (lh ^ (f & 1));
-    }
+    auto aaddr = [&](int i, int t) -> int {
+        const int idx = i * TAPS + t;
+        return (idx & 1) ? (int)(apk[idx >> 1] >> 16) : (int)(apk[idx >> 1] & 0xffffu);
+    };
+    // B rows are the tile's consecutive output channels: tile j sits j*TR rows further (a multiple of the swizzle period)
+    const int baddr0 = B_BASE + (wave_n * MJ * TR + lr) * ROWB + 16 * (lh ^ swz_tr<SLOTS, TR>(lr));
+    static_assert(TR % 16 == 0, "swizzle period");
 
-    f32x16 acc[NI][NJ];
+    acc_t acc[MI][MJ];
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < MJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < NR; ++r) acc[i][j][r] = 0.f;
 
     // ---- staging (LDS-DMA).  Lane l of a piece writes LDS row 16q + l/SLOTS, physical slot l%SLOTS, so it must
     //      FETCH logical slot (l%SLOTS) ^ swz(row): the swizzle lives on the source address (rule 21).
@@ -182,7 +246,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
         q = q < apieces ? q : apieces - 1;
         const int row = q * RPP + prl;
         const int srow = row < prow ? row : prow - 1;                // tail rows of the last piece: any valid source
-        dma16(base, (unsigned)srow * xrow + ((psl ^ swz<SLOTS>(row)) << 4), lds_base + buf * ABUF + q * 1024);
+        dma16(base, (unsigned)srow * xrow + ((psl ^ swz_tr<SLOTS, TR>(row)) << 4), lds_base + buf * ABUF + q * 1024);
     };
     const int agroups = (apieces + NW - 1) / NW;                     // piece groups of one patch
     auto stage_patch = [&](const char* xsrc, int cin, int chunk, int buf) {
@@ -191,40 +255,60 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
     // weight tiles of `ntaps` consecutive taps starting at `tap` into weight buffer `buf`.  The per-lane part of the
     // source address (output channel row, swizzled slot) does not depend on the step: precomputed once.
     constexpr int PW = (TN / RPP + NW - 1) / NW;                     // weight pieces per wave per tap
-    int wn[PW], wsl[PW];
+    unsigned wvoff[PW];
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
         const int q = k * NW + wid, row = q * RPP + prl;
         const int n = n0 + row;
-        wn[k] = n < a.Cout ? n : a.Cout - 1;                         // N tail: those output columns are never stored
-        wsl[k] = (psl ^ swz<SLOTS>(row)) << 4;
+        const int wn = n < a.Cout ? n : a.Cout - 1;                  // N tail: those output columns are never stored
+        wvoff[k] = (unsigned)wn * ROWB + ((psl ^ swz_tr<SLOTS, TR>(row)) << 4);
     }
-    auto stage_w = [&](const char* wsrc, int cin, int taps, int chunk, int tap, int ntaps, int buf) {
-        const unsigned wrow = (unsigned)(taps * cin) * ELEM;
-        for (int tt = 0; tt < ntaps; ++tt) {
-            const char* base = wsrc + ((size_t)(tap + tt) * cin + (size_t)chunk * 32) * ELEM;   // wave-uniform
-#pragma unroll
-            for (int k = 0; k < PW; ++k) {
-                const int q = k * NW + wid;
-                if (q < TN / RPP)
-                    dma16(base, (unsigned)wn[k] * wrow + wsl[k], lds_base + B_BASE + buf * BBUF + tt * BTAP + q * 1024);
-            }
-        }
-    };
-
     // ---- step list: phase 0 = the convolution (nch0 chunks x NG tap groups); phase 1 = the fused shortcut GEMM
-    //      (nch1 chunks, centre tap only).  Patch of chunk c lives in buffer c&1, weights of step s in buffer s&1.
+    //      (nch1 chunks, centre tap only).  Patch of chunk c lives in buffer c&1, weights of step s in buffer s%NWB.
     const int nch0 = a.Cin / 32, nch1 = a.x2 ? a.Cin2 / 32 : 0;
     const int nchunks = nch0 + nch1;
+    constexpr bool STAMPS = SUBREG_DIAG == 3;
+    unsigned long long t_begin = 0, t_loop = 0, t_issue = 0, t_wait = 0, t_bar = 0, t_mma = 0, tq = 0, r_begin = 0;
+    if (STAMPS) { t_begin = __builtin_amdgcn_s_memtime(); r_begin = __builtin_amdgcn_s_memrealtime(); }
+    // one weight piece (tap-in-step tt, piece kw of this wave) of the step at (chunk sc, tap group stg) into ring slot wb
+    auto stage_w_piece = [&](int sc, int stg, int tt, int kw, int wb) {
+        const int q = kw * NW + wid;
+        if (sc >= nchunks || q >= TN / RPP) return 0;
+        const unsigned dst = lds_base + B_BASE + wb * BBUF + tt * BTAP + q * 1024;
+        if (sc < nch0) {                                              // tile (tap, chunk): Cout contiguous rows
+            dma16(a.w + ((size_t)(stg * TPS + tt) * nch0 + sc) * a.Cout * ROWB, wvoff[kw], dst);
+            return 1;
+        }
+        if (tt != 0) return 0;                                        // the shortcut GEMM has a single tap
+        dma16(a.w2 + (size_t)(sc - nch0) * a.Cout * ROWB, wvoff[kw], dst);
+        return 1;
+    };
+    // the step after (sc, stg)
+    auto advance = [&](int& sc, int& stg) {
+        if (sc >= nch0 || stg == NG - 1) { ++sc; stg = 0; } else { ++stg; }
+    };
     stage_patch(a.x, a.Cin, 0, 0);
-    stage_w(a.w, a.Cin, TAPS, 0, 0, TPS, 0);
+    {
+        int sc = 0, stg = 0;
+#pragma unroll
+        for (int d = 0; d < NWB - 1; ++d) {
+#pragma unroll
+            for (int k = 0; k < TPS * PW; ++k) stage_w_piece(sc, stg, k / PW, k % PW, d);
+            advance(sc, stg);
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's DMA landed ...
     __syncthreads();                                                  // ... everyone's did; zero rows visible
-    // Patch of chunk c+1 is prefetched during chunk c, PA piece groups per step, issued AFTER the step's weight
-    // prefetch: LDS-DMA completes in issue order, so the end-of-step wait `vmcnt(groups issued this step)` covers
-    // the L2-resident weights of the next step but leaves the (HBM) patch pieces in flight for one more step.
-    constexpr int PA = (AROWS / RPP + NW * NG - 1) / (NW * NG);
+    // Patch of chunk c+1 is prefetched during chunk c, PA piece groups per step (none in the chunk's last step when
+    // there are several).  LDS-DMA completes in issue order and the end-of-step wait is `vmcnt(N)` with N = the
+    // youngest DMAs that may stay in flight:
+    //   NWB = 2: a step issues [weights of step+1][patch groups]   and waits N = patch groups (0 at a chunk end);
+    //   NWB = 3: a step issues [patch groups][weights of step+2]   and waits N = weights (+ patch groups unless at
+    //            a chunk end): the weights of step+1 went out a whole step earlier.
+    constexpr int PSTEPS = NG > 1 ? NG - 1 : 1;                       // steps of a chunk that carry patch groups
+    constexpr int PA = (AROWS / RPP + NW * PSTEPS - 1) / (NW * PSTEPS);
     int step = 0;
+    if (STAMPS) t_loop = __builtin_amdgcn_s_memtime();
     for (int c = 0; c < nchunks; ++c) {
         const bool ph1 = c >= nch0;
         const bool more = c + 1 < nchunks;
@@ -235,57 +319,83 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
         for (int tg = 0; tg < NG; ++tg) {
             if (ph1 && tg != 0) continue;
             const bool last_grp = ph1 || tg == NG - 1;
-            // prefetch the NEXT step's weight tiles
-            {
-                const int nc = last_grp ? c + 1 : c;
-                if (nc < nchunks) {
-                    if (nc < nch0) stage_w(a.w, a.Cin, TAPS, nc, last_grp ? 0 : (tg + 1) * TPS, TPS, (step + 1) & 1);
-                    else stage_w(a.w2, a.Cin2, 1, nc - nch0, 0, 1, (step + 1) & 1);
-                }
-            }
-            // ... then this step's share of the next chunk's patch
-            int issued = 0;
-            if (more) {
-                if (ph1) {
-                    for (int grp = 0; grp < agroups; ++grp) stage_patch_group(nx, ncin, nck, (c + 1) & 1, grp);
-                } else {
+            // DMA work of this step as numbered slots (PA patch slots, NSW weight slots; order by NWB as above).
+            // Issued in one burst right after the barrier the DMAs of the four waves queue up behind each other in the
+            // CU's one address path (~75 stalled cycles each, in-kernel stamps); SUBREG_DMA_INTERLEAVE issues one slot
+            // after each of the first MFMA groups instead.
+            if (STAMPS) tq = __builtin_amdgcn_s_memtime();
+            constexpr int NSW = TPS * PW, NS = NSW + PA;
+            int wc = c, wtg = tg;                                     // the step whose weights this step stages
 #pragma unroll
-                    for (int k = 0; k < PA; ++k) {
-                        const int grp = tg * PA + k;
-                        if (grp < agroups) { stage_patch_group(nx, ncin, nck, (c + 1) & 1, grp); ++issued; }
-                    }
+            for (int d = 0; d < NWB - 1; ++d) advance(wc, wtg);
+            const int wb = (step + NWB - 1) % NWB;
+            int n_patch = 0, n_w = 0;
+            auto slot = [&](int k) {
+                const bool is_w = NWB == 2 ? k < NSW : k >= PA;
+                const int kk = NWB == 2 ? (is_w ? k : k - NSW) : (is_w ? k - PA : k);
+                if (SUBREG_DIAG == 1) return;
+                if (is_w) {
+                    n_w += stage_w_piece(wc, wtg, kk / PW, kk % PW, wb);
+                } else if (!ph1) {
+                    const int grp = tg * PA + kk;
+                    if (more && (NG == 1 || tg < PSTEPS) && grp < agroups) { stage_patch_group(nx, ncin, nck, (c + 1) & 1, grp); ++n_patch; }
+                } else if (kk == 0 && more) {                         // a shortcut step consumes a whole patch: stage all of the next
+                    for (int grp = 0; grp < agroups; ++grp) stage_patch_group(nx, ncin, nck, (c + 1) & 1, grp);
                 }
+            };
+            const bool interleave = SUBREG_DMA_INTERLEAVE && !ph1 && NG > 1;
+            if (!interleave) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) slot(k);
             }
-            const int boff = (step & 1) * BBUF;
+            if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_issue += n - tq; tq = n; }
+            const int boff = (step % NWB) * BBUF;
             // k-steps of this step (TPS taps x KSTEPS).  Where the register budget allows two fragment sets (small
             // wave tiles, which also run at low occupancy), software-pipeline: the LDS reads of k-step kk+1 are issued
             // between the MFMAs of k-step kk.  The 64x160 wave tile (160 accumulator registers) cannot afford it.
             constexpr int NK = TPS * K::KSTEPS;
-            constexpr bool SWP = NI * NJ * 16 + 2 * (NI + NJ) * 4 + 40 <= 200;
-            auto load_frags = [&](int kk, uint4(&xa)[NI], uint4(&xb)[NJ]) {
+            constexpr int KX = 16 * LG;                               // address XOR per k-step
+            constexpr bool SWP = NI * NJ * 16 + 2 * (MI + MJ) * 4 + 40 <= 200;
+            constexpr int NGRP = SWP ? NK : NK * MJ;                  // MFMA groups of a step (DMA slots go between them)
+            constexpr int SPG = (NS + NGRP - 1) / NGRP;               // slots per group
+            auto after_group = [&](int gi) {
+                if (!interleave) return;
+#pragma unroll
+                for (int k = gi * SPG; k < (gi + 1) * SPG; ++k)
+                    if (k < NS) slot(k);
+            };
+            auto load_a = [&](int kk, uint4(&xa)[MI]) {
                 const int tt = kk / K::KSTEPS, s = kk % K::KSTEPS;
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int ad = ph1 ? aaddr[i][CENTER] : aaddr[i][tg * TPS + tt];
-                    xa[i] = *reinterpret_cast<const uint4*>(smem + aoff + (ad ^ (32 * s)));
+                for (int i = 0; i < MI; ++i) {
+                    const int ad = ph1 ? aaddr(i, CENTER) : aaddr(i, tg * TPS + tt);
+                    xa[i] = *reinterpret_cast<const uint4*>(smem + aoff + (ad ^ (KX * s)));
                 }
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    xb[j] = *reinterpret_cast<const uint4*>(smem + boff + tt * BTAP + (baddr[j] ^ (32 * s)));
             };
-            if constexpr (SWP) {
-                constexpr int NRD = NI + NJ, NMM = NI * NJ * (sizeof(T) == 2 ? 1 : 4), PER = NMM / NRD > 0 ? NMM / NRD : 1;
-                uint4 fa[2][NI], fb[2][NJ];
-                load_frags(0, fa[0], fb[0]);
+            auto load_b1 = [&](int kk, int j) -> uint4 {
+                const int tt = kk / K::KSTEPS, s = kk % K::KSTEPS;
+                return *reinterpret_cast<const uint4*>(smem + boff + tt * BTAP + j * (TR * ROWB) + (baddr0 ^ (KX * s)));
+            };
+            if constexpr (SUBREG_DIAG == 2) {
+            } else if constexpr (SWP) {
+                constexpr int NRD = MI + MJ, NMM = MI * MJ * (sizeof(T) == 2 ? 1 : 4), PER = NMM / NRD > 0 ? NMM / NRD : 1;
+                uint4 fa[2][MI], fb[2][MJ];
+                load_a(0, fa[0]);
+#pragma unroll
+                for (int j = 0; j < MJ; ++j) fb[0][j] = load_b1(0, j);
 #pragma unroll
                 for (int kk = 0; kk < NK; ++kk) {
                     if (ph1 && kk >= K::KSTEPS) continue;                 // the shortcut GEMM has a single tap
                     const bool more_k = kk + 1 < NK && !(ph1 && kk + 1 >= K::KSTEPS);
-                    if (more_k) load_frags(kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+                    if (more_k) {
+                        load_a(kk + 1, fa[(kk + 1) & 1]);
 #pragma unroll
-                    for (int i = 0; i < NI; ++i)
+                        for (int j = 0; j < MJ; ++j) fb[(kk + 1) & 1][j] = load_b1(kk + 1, j);
+                    }
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) mma_step<T>(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < MJ; ++j) mma_step<T>(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
                     if (kk + 1 < NK) {                                    // interleave: PER MFMAs, 1 ds_read, ...
 #pragma unroll
                         for (int n = 0; n < NRD; ++n) {
@@ -293,47 +403,88 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
                             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         }
                     }
+                    after_group(kk);
                 }
             } else {
+                // big wave tiles: no room for a second fragment set.  Per k-step: the A fragments, then the B fragments
+                // streamed column tile by column tile through a 3-deep register ring, each read issued two tiles (2*MI
+                // MFMAs) ahead of its use.  The order is pinned with sched_group_barriers: left alone, the scheduler
+                // sinks every read next to its use and waits lgkmcnt(0) on it (one exposed LDS latency per MI MFMAs).
+                constexpr int MPG = MI * (sizeof(T) == 2 ? 1 : 4);    // MFMAs per column tile
 #pragma unroll
                 for (int kk = 0; kk < NK; ++kk) {
                     if (ph1 && kk >= K::KSTEPS) continue;
-                    uint4 fa[NI], fb[NJ];
-                    load_frags(kk, fa, fb);
+                    const int tt = kk / K::KSTEPS, s = kk % K::KSTEPS;
+                    uint4 fa[MI], fb[3];
+                    auto rd_a = [&](int i) {
+                        const int ad = ph1 ? aaddr(i, CENTER) : aaddr(i, tg * TPS + tt);
+                        fa[i] = *reinterpret_cast<const uint4*>(smem + aoff + (ad ^ (KX * s)));
+                    };
+                    rd_a(0);
+                    fb[0] = load_b1(kk, 0);
 #pragma unroll
-                    for (int i = 0; i < NI; ++i)
+                    for (int i = 1; i < MI; ++i) rd_a(i);
+                    if (MJ > 1) fb[1] = load_b1(kk, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, MI + (MJ > 1 ? 2 : 1), 0);
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) mma_step<T>(fa[i], fb[j], acc[i][j]);
+                    for (int j = 0; j < MJ; ++j) {
+                        if (j + 2 < MJ) {
+                            fb[(j + 2) % 3] = load_b1(kk, j + 2);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) mma_step<T>(fa[i], fb[j % 3], acc[i][j]);
+                        __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
+                        after_group(kk * MJ + j);
+                    }
                 }
             }
             ++step;
+            if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_mma += n - tq; tq = n; }
             // end of step: next step's weights landed (and, at a chunk boundary, the whole next patch); this wave's
             // LDS reads are complete (their results fed the MFMAs); then the workgroup barrier
-            if (last_grp || issued == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (issued == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else if (issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (issued == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            {
+                const int keep = NWB == 2 ? (last_grp ? 0 : n_patch) : n_w + (last_grp ? 0 : n_patch);
+                switch (keep) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                }
+            }
+            if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_wait += n - tq; tq = n; }
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_bar += n - tq; tq = n; }
         }
     }
 
+    if (STAMPS && a.stats && !a.raw && lane == 0) {
+        const unsigned long long n = __builtin_amdgcn_s_memtime(), rn = __builtin_amdgcn_s_memrealtime();
+        float* d = a.stats + ((size_t)blockIdx.x * NW + wid) * 8;
+        d[0] = (float)(t_loop - t_begin); d[1] = (float)(n - t_loop); d[2] = (float)t_issue; d[3] = (float)t_mma;
+        d[4] = (float)t_wait; d[5] = (float)t_bar; d[6] = (float)(rn - r_begin); d[7] = (float)step;
+    }
     // ------------------------------------------------------------------ epilogue
-    // C layout of a 32x32 tile: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // C layout of a TR x TR tile: column = lane % TR; register r holds row (r&3) + 8*(r>>2) + 4*(lane / TR)
+    // (32x32: 16 registers, 16x16: 4).  Registers 4q..4q+3 are 4 consecutive rows = one 2x2 pooling window.
     T* const y = reinterpret_cast<T*>(a.y);
     const T* const res = reinterpret_cast<const T*>(a.res);
     const bool full = m0 + TM <= g.M && n0 + TN <= a.Cout;            // no ragged edge in this tile
     if (a.raw) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + (wave_n * NJ + j) * 32 + lr;
+        for (int j = 0; j < MJ; ++j) {
+            const int n = n0 + (wave_n * MJ + j) * TR + lr;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int mb = m0 + (wave_m * NI + i) * 32 + 4 * lh;
+            for (int i = 0; i < MI; ++i) {
+                const int mb = m0 + (wave_m * MI + i) * TR + 4 * lh;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < NR; ++r) {
                     const int m = mb + (r & 3) + 8 * (r >> 2);
                     if (full || (m < g.M && n < a.Cout)) {
                         const float v = acc[i][j][r];
@@ -343,8 +494,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
                     }
                 }
             }
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
+#pragma unroll
+            for (int o = TR; o < 64; o <<= 1) {                      // the LG lane groups hold the other rows
+                s1 += __shfl_xor(s1, o);
+                s2 += __shfl_xor(s2, o);
+            }
             if (lh == 0 && n < a.Cout) {
                 float* dst = a.stats + ((size_t)(mtile * WAVES_M + wave_m) * a.Cout + n) * 2;
                 dst[0] = s1;
@@ -353,32 +507,35 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
         }
         return;
     }
-    constexpr bool SLAB_FITS = NW * 32 * (NJ * 32 * ELEM + 16) <= 2 * ABUF + 2 * BBUF;   // epilogue slabs reuse the staging LDS
+    constexpr int TPB = 32 / TR;                                      // MFMA tiles per 32-row slab
+    constexpr bool SLAB_FITS = NW * 32 * (NJ * 32 * ELEM + 16) <= 2 * ABUF + NWB * BBUF;   // epilogue slabs reuse the staging LDS
     if constexpr (!POOL && SLAB_FITS) if (full && !res) {
         // Full linear tile: stage each 32-row slab of this wave's tile through LDS ([row][channel], +16 B row pad) and
         // write it back as whole 16-byte vectors, consecutive lanes on consecutive addresses of a pixel row.  (The
         // direct path below needs one 2/4-byte store per accumulator register and dominated short-K layers.)
         constexpr int TNW = NJ * 32, RS = TNW * ELEM + 16, VPR = TNW * ELEM / 16, NV = 32 * VPR;
         char* const slab = smem + wid * (32 * RS);               // all waves are past the last step's barrier
-        float shj[NJ], scj[NJ];
+        float shj[MJ], scj[MJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + (wave_n * NJ + j) * 32 + lr;
+        for (int j = 0; j < MJ; ++j) {
+            const int n = n0 + (wave_n * MJ + j) * TR + lr;
             shj[j] = a.shift[n];
             scj[j] = a.scale ? a.scale[n] : 1.f;
         }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
+        for (int ib = 0; ib < NI; ++ib) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+            for (int ii = 0; ii < TPB; ++ii)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r] * scj[j] + shj[j];
-                    if (a.act) v = fmaxf(v, v * 0.1f);            // LeakyReLU(0.1)
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    *reinterpret_cast<T*>(slab + row * RS + (j * 32 + lr) * ELEM) = ElemTraits<T>::from_float(v);
-                }
-            const int mrow0 = m0 + (wave_m * NI + i) * 32;
+                for (int j = 0; j < MJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        float v = acc[ib * TPB + ii][j][r] * scj[j] + shj[j];
+                        if (a.act) v = fmaxf(v, v * 0.1f);            // LeakyReLU(0.1)
+                        const int row = ii * TR + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        *reinterpret_cast<T*>(slab + row * RS + (j * TR + lr) * ELEM) = ElemTraits<T>::from_float(v);
+                    }
+            const int mrow0 = m0 + (wave_m * NI + ib) * 32;
             char* const ybase = a.y + ((size_t)mrow0 * a.Cout + n0 + wave_n * TNW) * ELEM;
 #pragma unroll
             for (int v0 = 0; v0 < NV; v0 += 64) {
@@ -398,20 +555,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
         constexpr int TNW = NJ * 32, RS = TNW * ELEM + 16, VPR = TNW * ELEM / 16, NV = 8 * VPR;
         char* const slab = smem + wid * (32 * RS);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
+        for (int ib = 0; ib < NI; ++ib) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = n0 + (wave_n * NJ + j) * 32 + lr;
-                const float sh = a.shift[n], sc = a.scale ? a.scale[n] : 1.f;
+            for (int ii = 0; ii < TPB; ++ii)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float best = fmaxf(fmaxf(acc[i][j][4 * q] * sc + sh, acc[i][j][4 * q + 1] * sc + sh),
-                                       fmaxf(acc[i][j][4 * q + 2] * sc + sh, acc[i][j][4 * q + 3] * sc + sh));
-                    if (a.act) best = fmaxf(best, best * 0.1f);       // monotone => lrelu(max) == max(lrelu)
-                    *reinterpret_cast<T*>(slab + (2 * q + lh) * RS + (j * 32 + lr) * ELEM) = ElemTraits<T>::from_float(best);
+                for (int j = 0; j < MJ; ++j) {
+                    const int n = n0 + (wave_n * MJ + j) * TR + lr;
+                    const float sh = a.shift[n], sc = a.scale ? a.scale[n] : 1.f;
+                    const acc_t& c = acc[ib * TPB + ii][j];
+#pragma unroll
+                    for (int q = 0; q < NR / 4; ++q) {
+                        float best = fmaxf(fmaxf(c[4 * q] * sc + sh, c[4 * q + 1] * sc + sh),
+                                           fmaxf(c[4 * q + 2] * sc + sh, c[4 * q + 3] * sc + sh));
+                        if (a.act) best = fmaxf(best, best * 0.1f);       // monotone => lrelu(max) == max(lrelu)
+                        const int prow = ii * (TR / 4) + 2 * q + lh;     // window (ii*TR + 8q + 4lh) / 4 of the slab
+                        *reinterpret_cast<T*>(slab + prow * RS + (j * TR + lr) * ELEM) = ElemTraits<T>::from_float(best);
+                    }
                 }
-            }
-            const int win0 = (m0 + (wave_m * NI + i) * 32) >> 2;      // first pooled pixel of this slab
+            const int win0 = (m0 + (wave_m * NI + ib) * 32) >> 2;     // first pooled pixel of this slab
             char* const ybase = a.y + ((size_t)win0 * a.Cout + n0 + wave_n * TNW) * ELEM;
 #pragma unroll
             for (int v0 = 0; v0 < NV; v0 += 64) {
@@ -426,17 +587,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
         return;
     }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + (wave_n * NJ + j) * 32 + lr;
+    for (int j = 0; j < MJ; ++j) {
+        const int n = n0 + (wave_n * MJ + j) * TR + lr;
         const bool nv = full || n < a.Cout;
         const float sc = (a.scale && nv) ? a.scale[n] : 1.f, sh = nv ? a.shift[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int mb = m0 + (wave_m * NI + i) * 32 + 4 * lh;
+        for (int i = 0; i < MI; ++i) {
+            const int mb = m0 + (wave_m * MI + i) * TR + 4 * lh;
             if (!POOL) {
                 const unsigned obase = (unsigned)(mb * a.Cout + n);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < NR; ++r) {
                     const int dr = (r & 3) + 8 * (r >> 2);
                     if (full || (mb + dr < g.M && nv)) {
                         float v = acc[i][j][r] * sc + sh;
@@ -447,7 +608,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {          // register group q: rows mb + 8q + {0,1,2,3} == one 2x2 window
+                for (int q = 0; q < NR / 4; ++q) {     // register group q: rows mb + 8q + {0,1,2,3} == one 2x2 window
                     const int m = mb + 8 * q;
                     if (full || (m < g.M && nv)) {
                         float v0 = acc[i][j][4 * q] * sc + sh, v1 = acc[i][j][4 * q + 1] * sc + sh;
@@ -486,7 +647,8 @@ template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool PO
 static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     using K = KT<T>;
     constexpr int TM = WM * NI * 32, TN = WN * NJ * 32;
-    const size_t lds = 2 * (size_t)(AROWS + 1) * K::ROWB + 2 * (size_t)TPS * TN * K::ROWB;
+    constexpr int ABUF = (AROWS + 1) * K::ROWB, BBUF = TPS * TN * K::ROWB;
+    const size_t lds = 2 * (size_t)ABUF + (size_t)weight_buffers(ABUF, BBUF) * BBUF;
     auto kern = conv_fwd_kernel<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AROWS, MINW>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
@@ -574,7 +736,17 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
             return launch_rows<__bf16, 1, 2, 4, 1, 9, 3, true, 416, 560, 2>(a, s);
         }
         const long long nt = Cout / 160;
-        if (raw || ((a.g.M + 255) / 256) * nt >= 384) return launch_shape<__bf16, 2, 5, 4, 1, 1, 432, 560, 2>(a, pool, s);
+#if SUBREG_TM512
+        // big maps: 512-row tiles, 8 waves, one workgroup per CU.  Same waves per SIMD as two 256-row workgroups, but
+        // every weight tile staged from L2 feeds twice the rows (the L2 -> LDS weight stream is what the 256-row tiling
+        // was bound by) and 3 taps per step = a third of the barriers.
+        if (!raw && ((a.g.M + 255) / 256) * nt >= 384) return launch_shape<__bf16, 2, 5, 8, 1, 3, 608, 704, 2>(a, pool, s);
+#endif
+        if (raw || ((a.g.M + 255) / 256) * nt >= 384) {
+            // patches of <= 352 rows (W <= 42 unpooled) leave room for the 3-deep weight ring at two workgroups per CU
+            const int rc = launch_shape<__bf16, 2, 5, 4, 1, 1, 352, 432, 2>(a, pool, s);
+            return rc != SUBREG_EUNSUPPORTED ? rc : launch_shape<__bf16, 2, 5, 4, 1, 1, 560, 560, 2>(a, pool, s);
+        }
         // small maps (10x10, 5x5): 128-row tiles.  If they all fit one per CU (<= 256 workgroups) stage 3 taps per step
         // (84 KB LDS, covers the LDS-DMA latency at that occupancy); otherwise 1 tap per step and 3 workgroups per CU.
         if (((a.g.M + 127) / 128) * nt > 256) return launch_shape<__bf16, 1, 5, 4, 1, 1, 192, 432, 2>(a, pool, s);

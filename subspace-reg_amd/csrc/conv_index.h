@@ -98,4 +98,13 @@ SUBREG_HD int swz(int row) {
     return SLOTS == 4 ? ((row >> 2) & 3) : ((row >> 1) & 7);
 }
 
+// The same for a given MFMA tile height TR.  TR = 32: lane l reads row l%32 at logical slot 2s + l/32 (above).
+// TR = 16 (v_mfma_f32_16x16x32_bf16): lane l reads row l%16 at logical slot l/16, so one 16-lane group of a
+// ds_read_b128 mixes two slots ({0-3,12-15} at slot g, {20-27} at slot g+1 ...): swz = 2*((row>>2)&1) keeps every
+// group on 16 distinct 16-byte bank columns for any base row (checked exhaustively in tests/csrc/conv_index_test.cpp).
+template <int SLOTS, int TR>
+SUBREG_HD int swz_tr(int row) {
+    return TR == 16 ? (((row >> 2) & 1) << 1) : swz<SLOTS>(row);
+}
+
 }  // namespace subreg

@@ -39,7 +39,8 @@ __global__ void pack_input_kernel(const float* __restrict__ x, T* __restrict__ c
 }
 
 // ---------------------------------------------------------------- weight packing
-// mode 0: OIHW f32 -> [Cout][k*k][Cin] T.
+// mode 0: OIHW f32 -> [k*k][Cin/32][Cout][32] T: one (tap, 32-channel chunk) weight tile is Cout contiguous 64/128-byte
+//         rows, so every 1-KiB LDS-DMA piece of conv_fwd.hip (16 or 8 rows) reads whole cache lines.
 // mode 1 (Cin == 3): -> [Cout][32] T over the im2col K axis (3x3: k = 3*tap + c; 1x1: centre tap 4).
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, const float* __restrict__ fold, T* __restrict__ out, int Cout,
@@ -49,8 +50,9 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, const float* __r
     if (mode == 0) {
         const size_t total = (size_t)Cout * taps * Cin;
         if (i >= total) return;
-        const int c = i % Cin, t = (i / Cin) % taps, o = i / ((size_t)Cin * taps);
-        out[i] = ElemTraits<T>::from_float(w[((size_t)o * Cin + c) * taps + t] * (fold ? fold[o] : 1.f));
+        const int nch = Cin / 32;
+        const int c32 = i % 32, o = (i / 32) % Cout, ch = (i / ((size_t)32 * Cout)) % nch, t = i / ((size_t)32 * Cout * nch);
+        out[i] = ElemTraits<T>::from_float(w[((size_t)o * Cin + ch * 32 + c32) * taps + t] * (fold ? fold[o] : 1.f));
     } else {
         const size_t total = (size_t)Cout * 32;
         if (i >= total) return;
@@ -69,7 +71,8 @@ template <typename T>
 __global__ void pack_identity_kernel(T* __restrict__ out, int C) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)C * C) return;
-    out[i] = ElemTraits<T>::from_float((i / C) == (i % C) ? 1.f : 0.f);
+    const int c32 = i % 32, o = (i / 32) % C, ch = i / ((size_t)32 * C);     // [C/32][C][32], as pack_weight_kernel
+    out[i] = ElemTraits<T>::from_float(o == ch * 32 + c32 ? 1.f : 0.f);
 }
 
 __global__ void vec_add_kernel(float* __restrict__ dst, const float* __restrict__ a, const float* __restrict__ b, int n) {

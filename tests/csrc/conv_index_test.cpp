@@ -114,10 +114,36 @@ static int swizzle_check() {
     return bad ? 1 : 0;
 }
 
+// 16x16x32 MFMA operand reads: lane l reads row off + l%16 at logical slot l/16 (bf16, 64-byte rows)
+static int swizzle_check_tr16() {
+    int bad = 0;
+    const int g0[16] = {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27};
+    const int g1[16] = {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31};
+    for (int off = 0; off < 64; ++off)
+        for (int half = 0; half < 2; ++half)
+            for (int gi = 0; gi < 2; ++gi) {
+                int used[16] = {0};
+                for (int l = 0; l < 16; ++l) {
+                    const int lane = (gi ? g1[l] : g0[l]) + 32 * half;
+                    const int row = off + lane % 16, slot = lane / 16;
+                    const int addr = row * 64 + ((slot ^ swz_tr<4, 16>(row)) << 4);
+                    if (used[(addr / 16) % 16]++) bad++;
+                }
+            }
+    for (int row = 0; row < 64; ++row) {                     // bijection per row
+        int seen = 0;
+        for (int slot = 0; slot < 4; ++slot) seen |= 1 << (slot ^ swz_tr<4, 16>(row));
+        if (seen != 15) bad++;
+    }
+    printf("swizzle TR=16: %d conflicts\n", bad);
+    return bad ? 1 : 0;
+}
+
 int main() {
     int rc = 0;
     rc |= swizzle_check<4>();
     rc |= swizzle_check<8>();
+    rc |= swizzle_check_tr16();
     // bf16 config: TM 256, AROWS 704 ; f32 config: TM 128, AROWS 448
     rc |= run_case<false>(2, 84, 84, 4, 3, 9, 256, 704);
     rc |= run_case<true>(2, 84, 84, 4, 3, 9, 256, 704);
