@@ -141,12 +141,15 @@ int subreg_backbone_forward(const subreg_backbone_desc* d, const float* x_nchw, 
 /* ---- pretraining step: train_supervised.py:205-268 (output = model(input); loss.backward()) ----------------- */
 /* dX of a conv = subreg_conv_fwd on dY with these weights: OIHW fp32 -> [taps][Cout/32][Cin][32], taps flipped */
 int subreg_pack_conv_weight_dgrad(const float* w_oihw, void* out, int Cout, int Cin, int ksize, int dtype, void* stream);
-/* dW: gw_packed[Cout][taps][Cin] (fp32, zeroed here) = sum_p dY[p][o] * X[p+off(tap)][c]; then OIHW via unpack
- * (mode 1: the first layer's K=32 im2col layout back to [Cout][3][k][k]).  pad_x / pad_dy: optional scratch of
- * B*(H+2)*(W+2)*Cin resp. *Cout elements enabling the bf16-MFMA path for 3x3 convs (NULL: exact-f32 MFMA path) */
+/* dW: gw_packed[splits][Cout][taps][Cin] fp32 = per-K-split partial sums of dY[p][o] * X[p+off(tap)][c]
+ * (splits = subreg_conv_wgrad_splits(...) >= 1; the caller sizes gw_packed with it), then OIHW via unpack, which adds
+ * the splits up (mode 1: the first layer's K=32 im2col layout back to [Cout][3][k][k]).  pad_x / pad_dy: scratch of
+ * B*(H+2)*(W+2)*Cin resp. *Cout elements for the bf16 3x3 kernels (zero-bordered copies); NULL selects the exact-f32
+ * MFMA kernel that reads the compact tensors (always used for dtype f32). */
+int subreg_conv_wgrad_splits(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
 int subreg_conv_wgrad(const void* x, const void* dy, float* gw_packed, void* pad_x, void* pad_dy, int B, int H, int W, int Cin,
                       int Cout, int ksize, int dtype, void* stream);
-int subreg_unpack_wgrad(const float* gw_packed, float* grad_oihw, int Cout, int Cin, int ksize, int mode, void* stream);
+int subreg_unpack_wgrad(const float* gw_packed, float* grad_oihw, int Cout, int Cin, int ksize, int mode, int splits, void* stream);
 /* BatchNorm2d training-mode backward with the LeakyReLU' of `act` fused in (act == NULL: none):
  * g = dy*lrelu'(act); dgamma = sum g*xhat; dbeta = sum g; dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N).
  * partial: subreg_bn_bwd_slices(npix)*C*2 DOUBLES of scratch (sums in fp64 like the reference's CPU batch_norm backward) */
@@ -172,7 +175,7 @@ typedef struct subreg_conv_train { /* per conv; every buffer caller-owned */
     float* bscale;        /* [cout] gamma*invstd of THIS batch */
     float* bshift;        /* [cout] beta - mean*gamma*invstd */
     const void* w_dgrad;  /* subreg_pack_conv_weight_dgrad output; NULL when no input gradient is needed */
-    float* gw_packed;     /* [cout][taps][cin as the kernel sees it] fp32 scratch */
+    float* gw_packed;     /* [splits][cout][taps][cin as the kernel sees it] fp32 scratch (may be shared by all convs) */
     float* grad_w;        /* OIHW fp32: Conv2d.weight.grad */
     float* grad_gamma;    /* [cout] */
     float* grad_beta;     /* [cout] */

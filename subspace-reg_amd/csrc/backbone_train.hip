@@ -28,7 +28,8 @@ int bn_and_wgrad(const subreg_backbone_desc* d, const subreg_train_desc* t, cons
     TRY(subreg_bn_bwd(dy, act, tc.raw, tc.mean, tc.invstd, c.bn_weight, t->bn_partial, tc.grad_gamma, tc.grad_beta, draw,
                       (long long)B * H * W, c.cout, d->dtype, stream));
     TRY(subreg_conv_wgrad(conv_input, draw, tc.gw_packed, t->pad_x, t->pad_dy, B, H, W, c.cin, c.cout, c.ksize, d->dtype, stream));
-    return subreg_unpack_wgrad(tc.gw_packed, tc.grad_w, c.cout, c.cin_raw, c.ksize_raw, c.cin_raw == 3 ? 1 : 0, stream);
+    return subreg_unpack_wgrad(tc.gw_packed, tc.grad_w, c.cout, c.cin_raw, c.ksize_raw, c.cin_raw == 3 ? 1 : 0,
+                               subreg_conv_wgrad_splits(B, H, W, c.cin, c.cout, c.ksize, d->dtype), stream);
 }
 
 }  // namespace

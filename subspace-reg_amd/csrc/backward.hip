@@ -103,33 +103,58 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int slices, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// block = 16 channels x 16 slice lanes: the slices of a channel are summed by 16 threads (fixed order, fp64), not by one
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int slices, int C,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double red[2][16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
     double t1 = 0.0, t2 = 0.0;
-    for (int s = 0; s < slices; ++s) {
-        t1 += partial[((size_t)s * C + c) * 2];
-        t2 += partial[((size_t)s * C + c) * 2 + 1];
+    if (c < C)
+        for (int s = sl; s < slices; s += 16) {
+            t1 += partial[((size_t)s * C + c) * 2];
+            t2 += partial[((size_t)s * C + c) * 2 + 1];
+        }
+    red[0][sl][cl] = t1;
+    red[1][sl][cl] = t2;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        t1 = 0.0; t2 = 0.0;
+        for (int l = 0; l < 16; ++l) { t1 += red[0][l][cl]; t2 += red[1][l][cl]; }
+        dbeta[c] = (float)t1;
+        dgamma[c] = (float)t2;
     }
-    dbeta[c] = (float)t1;
-    dgamma[c] = (float)t2;
 }
 
 // dx = gamma*invstd * (g - dbeta/N - xhat*dgamma/N)
+// One thread = 16 bytes (8 bf16 / 4 f32 channels of one pixel): the pass is HBM-bound (3 tensors read, 1 written).
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ act, const T* __restrict__ raw,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ dgamma,
                                     const float* __restrict__ dbeta, T* __restrict__ dx, long long npix, int C) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)npix * C) return;
-    const int c = i % C;
-    float g = ElemTraits<T>::to_float(dy[i]);
-    if (act) g *= lrelu_grad(ElemTraits<T>::to_float(act[i]));
-    const double is = invstd[c], xh = ((double)ElemTraits<T>::to_float(raw[i]) - (double)mean[c]) * is;
-    const double inv_n = 1.0 / (double)npix;
-    dx[i] = ElemTraits<T>::from_float((float)((double)gamma[c] * is * ((double)g - (double)dbeta[c] * inv_n - xh * (double)dgamma[c] * inv_n)));
+    constexpr int VEC = 16 / sizeof(T);
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t e = v * VEC;
+    if (e >= (size_t)npix * C) return;
+    const int c0 = e % C;
+    const uint4 vd = *reinterpret_cast<const uint4*>(dy + e), vr = *reinterpret_cast<const uint4*>(raw + e);
+    uint4 va = make_uint4(0, 0, 0, 0);
+    if (act) va = *reinterpret_cast<const uint4*>(act + e);
+    const T* td = reinterpret_cast<const T*>(&vd);
+    const T* tr = reinterpret_cast<const T*>(&vr);
+    const T* ta = reinterpret_cast<const T*>(&va);
+    const float inv_n = 1.0f / (float)npix;
+    uint4 vo;
+    T* to = reinterpret_cast<T*>(&vo);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const int c = c0 + k;
+        float g = ElemTraits<T>::to_float(td[k]);
+        if (act) g *= lrelu_grad(ElemTraits<T>::to_float(ta[k]));
+        const float is = invstd[c], xh = (ElemTraits<T>::to_float(tr[k]) - mean[c]) * is;
+        to[k] = ElemTraits<T>::from_float(gamma[c] * is * (g - dbeta[c] * inv_n - xh * (dgamma[c] * inv_n)));
+    }
+    *reinterpret_cast<uint4*>(dx + e) = vo;
 }
 
 // ---------------------------------------------------------------- AdaptiveAvgPool2d(1) backward
@@ -214,7 +239,7 @@ __device__ __forceinline__ uint2 tr_read(unsigned addr) {
 // pixel rows.  Both operands are pixel-major in memory and in LDS; the MFMA wants 8 consecutive K (= pixels) per lane and
 // channel, which the transposing LDS read provides.  dW accumulated with fp32 atomics over the K splits.
 template <int NCW, int TAPS>
-__global__ __launch_bounds__(NCW * 64) void conv_wgrad_bf16_kernel(const __bf16* __restrict__ xq, const __bf16* __restrict__ dyq,
+__global__ __launch_bounds__(NCW * 64, 2) void conv_wgrad_bf16_kernel(const __bf16* __restrict__ xq, const __bf16* __restrict__ dyq,
                                                                     float* __restrict__ gw, long long Q, int Wrow, int Cin,
                                                                     int Cout, int rows_per_block) {
     constexpr int KCH = 64;                              // pixel rows per chunk (4 MFMA k-steps)
@@ -312,14 +337,151 @@ static int launch_wgrad_bf16(const __bf16* xq, const __bf16* dyq, float* gw, lon
     return launch_status();
 }
 
-// packed fp32 [Cout][taps][Cin_k] -> Conv2d.weight.grad OIHW (mode 1: first-layer K=32 layout, see pack_weight_kernel)
-__global__ void unpack_wgrad_kernel(const float* __restrict__ gw, float* __restrict__ grad, int Cout, int Cin, int ks, int mode) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over OIHW
+// ---------------------------------------------------------------- weight gradient, bf16 MFMA, 3x3, streaming version
+// One WAVE per workgroup: dW tile 32 (o) x 32 (c) x 9 taps (nine 32x32 accumulators) over the padded pixel rows
+// [qb, qe) of one K split.  X rows live in an LDS RING (64-byte rows, slot = (q - qbase) mod R): a chunk of 64 pixels
+// only stages its 64 NEW rows (the 2*halo rows the taps reach back/forward to are still resident), where the tiled
+// kernel above re-reads 64 + 2*halo rows per chunk (3.7x at 84x84).  The first 32 ring rows are mirrored behind the
+// ring's end so that a lane's row offset (< 20 rows) never needs a per-lane wrap: one v_add per transposing read.
+// Staging is LDS-DMA one chunk ahead (X: 4 pieces, dY: 4 pieces into a double buffer); a single wave needs no barrier,
+// only s_waitcnt vmcnt(0) before it reads what it staged.  Each split writes its own partial dW with plain stores
+// (float atomics run at 1.3 TB/s chip-wide and were 40 % of this kernel at 1536+ workgroups); unpack sums the splits.
+__global__ __launch_bounds__(64, 2) void conv_wgrad3x3_stream_kernel(const __bf16* __restrict__ xq, const __bf16* __restrict__ dyq,
+                                                                     float* __restrict__ gw_part, long long Q, int Wrow, int Cin,
+                                                                     int Cout, int rows_per_block, int ring_rows) {
+    constexpr int KCH = 64, MIRROR = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const int halo = Wrow + 1;
+    const int ncg = Cin / 32;
+    const int o0 = (blockIdx.x / ncg) * 32, c0 = (blockIdx.x % ncg) * 32;
+    const long long qb = (long long)blockIdx.y * rows_per_block;
+    long long qe = qb + rows_per_block;
+    if (qe > Q) qe = Q;
+    const unsigned sX = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned sD = sX + (unsigned)(ring_rows + MIRROR) * 64;
+    const int R = ring_rows;
+    // ---- staging
+    const int prow = lane >> 2, pslot = (lane & 3) * 16;
+    const char* const xbase = reinterpret_cast<const char*>(xq + c0);
+    const char* const dbase = reinterpret_cast<const char*>(dyq + o0);
+    const long long qbase = ((qb - halo) >> 4) << 4;                   // floor to a piece boundary (may be negative)
+    auto stage_x = [&](long long q16, int slot16) {                    // piece of rows q16..q16+15 into ring slot slot16
+        long long row = q16 + prow;
+        row = row < 0 ? 0 : (row >= Q ? Q - 1 : row);                   // outside the tensor: any finite row (its dY factor is a border zero)
+        const unsigned voff = (unsigned)row * (unsigned)(Cin * 2) + pslot;
+        dma16(xbase, voff, sX + (unsigned)slot16 * 64);
+        if (slot16 < MIRROR) dma16(xbase, voff, sX + (unsigned)(R + slot16) * 64);
+    };
+    auto stage_d = [&](long long q0, int buf) {
+#pragma unroll
+        for (int j = 0; j < KCH / 16; ++j) {
+            const long long row = q0 + 16 * j + prow;
+            const unsigned srow = row < qe ? (unsigned)row : 0u;       // beyond the split: row 0 of padded dY, a zero border row
+            dma16(dbase, srow * (unsigned)(Cout * 2) + pslot, sD + (unsigned)buf * (KCH * 64) + j * 1024);
+        }
+    };
+    long long fq = qbase;                                               // staging frontier (absolute row) ...
+    int fslot = 0;                                                      // ... and its ring slot
+    const long long f0 = ((qb + KCH + halo + 15) >> 4) << 4;
+    for (; fq < f0; fq += 16) {
+        stage_x(fq, fslot);
+        fslot += 16;
+        if (fslot >= R) fslot -= R;
+    }
+    stage_d(qb, 0);
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // per-lane part of the transposing-read addresses (see tr_read): 64-byte rows
+    const int li = lane & 15, grp = lane >> 4, qr = li >> 2, pc = li & 3;
+    const unsigned lane_part = (unsigned)((8 * (grp >> 1) + qr) * 64 + (16 * (grp & 1) + 4 * pc) * 2);
+    int base_slot = (int)(qb - halo - qbase);                           // ring slot of row q0 - halo (0..15 at the start)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int it = 0;
+    for (long long q0 = qb; q0 < qe; q0 += KCH, ++it) {
+        if (q0 + KCH < qe) {                                            // stage the next chunk while this one computes
+#pragma unroll
+            for (int k = 0; k < KCH / 16; ++k) {
+                stage_x(fq, fslot);
+                fq += 16;
+                fslot += 16;
+                if (fslot >= R) fslot -= R;
+            }
+            stage_d(q0 + KCH, (it + 1) & 1);
+        }
+        const unsigned dbuf = sD + (unsigned)(it & 1) * (KCH * 64) + lane_part;
+#pragma unroll
+        for (int ks = 0; ks < KCH / 16; ++ks) {
+            const uint2 a0 = tr_read(dbuf + (16 * ks) * 64), a1 = tr_read(dbuf + (16 * ks + 4) * 64);
+            uint2 b0[9], b1[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                int slot = base_slot + 16 * ks + halo + (t / 3 - 1) * Wrow + (t % 3 - 1);   // wave-uniform: scalar ALU
+                if (slot >= R) slot -= R;
+                const unsigned ad = sX + (unsigned)slot * 64 + lane_part;
+                b0[t] = tr_read(ad);
+                b1[t] = tr_read(ad + 4 * 64);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const uint4 av = make_uint4(a0.x, a0.y, a1.x, a1.y);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const uint4 bv = make_uint4(b0[t].x, b0[t].y, b1[t].x, b1[t].y);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
+            }
+        }
+        base_slot += KCH;
+        if (base_slot >= R) base_slot -= R;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the next chunk landed
+    }
+    float* const out = gw_part + (size_t)blockIdx.y * ((size_t)Cout * 9 * Cin);
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            out[((size_t)o * 9 + t) * Cin + c0 + lr] = acc[t][r];
+        }
+}
+
+// K splits of the streaming kernel: one wave per workgroup, ~2048 resident waves on the chip (8 per CU)
+static void wgrad_stream_plan(long long Q, int Cin, int Cout, int* splits, int* rows_per_block) {
+    const int tiles = (Cout / 32) * (Cin / 32);
+    long long sp = (2048 + tiles - 1) / tiles;
+    long long rpb = ((Q + sp - 1) / sp + 63) / 64 * 64;
+    if (rpb < 64) rpb = 64;
+    *splits = (int)((Q + rpb - 1) / rpb);
+    *rows_per_block = (int)rpb;
+}
+
+static bool wgrad_stream_ok(long long Q, int W, int Cin, int Cout) {
+    const int ring = (128 + 2 * (W + 3) + 32 + 15) / 16 * 16;
+    return (size_t)(ring + 32) * 64 + 2 * 64 * 64 <= 64 * 1024 && Q * Cin * 2 < (1LL << 32) && Q * Cout * 2 < (1LL << 32);
+}
+
+// packed fp32 [splits][Cout][taps][Cin_k] -> Conv2d.weight.grad OIHW, summing the K splits (mode 1: first-layer K=32
+// layout, see pack_weight_kernel).  One thread per PACKED element: the (large) reads are coalesced, the writes scatter.
+__global__ void unpack_wgrad_kernel(const float* __restrict__ gw, float* __restrict__ grad, int Cout, int Cin, int ks, int mode,
+                                    int splits) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int taps = ks * ks;
-    if (i >= (size_t)Cout * Cin * taps) return;
-    const int t = i % taps, c = (i / taps) % Cin, o = i / ((size_t)taps * Cin);
-    if (mode == 0) grad[i] = gw[((size_t)o * taps + t) * Cin + c];
-    else grad[i] = gw[(size_t)o * 32 + (ks == 3 ? 3 * t + c : 12 + c)];
+    const size_t n = mode == 0 ? (size_t)Cout * taps * Cin : (size_t)Cout * 32;
+    if (i >= n) return;
+    float v = 0.f;
+    for (int sp = 0; sp < splits; ++sp) v += gw[(size_t)sp * n + i];
+    if (mode == 0) {
+        const int c = i % Cin, t = (i / Cin) % taps, o = i / ((size_t)Cin * taps);
+        grad[((size_t)o * Cin + c) * taps + t] = v;
+    } else {
+        const int k = i % 32, o = i / 32;
+        if (ks == 3) { if (k < 27) grad[((size_t)o * 3 + k % 3) * 9 + k / 3] = v; }
+        else if (k >= 12 && k < 15) grad[(size_t)o * 3 + (k - 12)] = v;
+    }
 }
 
 // OIHW fp32 -> dgrad operand: the forward weight layout [taps][Cout/32][Cin][32] T of the transposed conv (output
@@ -385,11 +547,11 @@ extern "C" int subreg_bn_bwd(const void* dy, const void* act, const void* raw, c
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, slices, 256, lds, s, (const float*)dy, (const float*)act, (const float*)raw, mean, invstd, partial, npix, C, 256),
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, slices, 256, lds, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, partial, npix, C, 256));
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, (C + 255) / 256, 256, 0, s, partial, slices, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, (C + 15) / 16, 256, 0, s, partial, slices, C, dgamma, dbeta);
     const size_t n = (size_t)npix * C;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, bw_blocks(n), BW_THREADS, 0, s, (const float*)dy, (const float*)act, (const float*)raw, mean, invstd, gamma, dgamma, dbeta, (float*)dx, npix, C),
-               hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, bw_blocks(n), BW_THREADS, 0, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, gamma, dgamma, dbeta, (__bf16*)dx, npix, C));
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, bw_blocks(n / 4), BW_THREADS, 0, s, (const float*)dy, (const float*)act, (const float*)raw, mean, invstd, gamma, dgamma, dbeta, (float*)dx, npix, C),
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, bw_blocks(n / 8), BW_THREADS, 0, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, gamma, dgamma, dbeta, (__bf16*)dx, npix, C));
     return launch_status();
 }
 
@@ -402,14 +564,39 @@ extern "C" int subreg_avgpool_bwd(const float* dfeat, void* dx, int B, int H, in
     return launch_status();
 }
 
+extern "C" int subreg_conv_wgrad_splits(int B, int H, int W, int Cin, int Cout, int ksize, int dtype) {
+    if (dtype != SUBREG_BF16 || ksize != 3 || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32) return 1;
+    const long long Q = (long long)B * (H + 2) * (W + 2);
+    if (!wgrad_stream_ok(Q, W, Cin, Cout)) return 1;
+    int splits, rpb;
+    wgrad_stream_plan(Q, Cin, Cout, &splits, &rpb);
+    return splits > 1 ? splits : 1;
+}
+
 extern "C" int subreg_conv_wgrad(const void* x, const void* dy, float* gw_packed, void* pad_x, void* pad_dy, int B, int H, int W,
                                  int Cin, int Cout, int ksize, int dtype, void* stream) {
     SUBREG_CHECK_ARG(x && dy && gw_packed && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
     SUBREG_CHECK_ARG((ksize == 1 || ksize == 3) && Cin % 32 == 0 && Cout % 32 == 0);
     hipStream_t s = (hipStream_t)stream;
     const int taps = ksize * ksize;
-    if (hipMemsetAsync(gw_packed, 0, sizeof(float) * (size_t)Cout * taps * Cin, s) != hipSuccess) return SUBREG_EHIP;
     const ConvGeom g = make_geom(B, H, W, taps, false);
+    const int nsplit = subreg_conv_wgrad_splits(B, H, W, Cin, Cout, ksize, dtype);
+    if (nsplit > 1 && pad_x && pad_dy) {
+        // streaming bf16 3x3 kernel: per-split partial dW, no zero-fill, no atomics
+        const long long Q = (long long)B * (H + 2) * (W + 2);
+        hipLaunchKernelGGL(pad_copy_kernel, bw_blocks((size_t)Q * Cin / 8), BW_THREADS, 0, s, (const __bf16*)x, (__bf16*)pad_x, B, H, W, Cin);
+        hipLaunchKernelGGL(pad_copy_kernel, bw_blocks((size_t)Q * Cout / 8), BW_THREADS, 0, s, (const __bf16*)dy, (__bf16*)pad_dy, B, H, W, Cout);
+        int splits, rpb;
+        wgrad_stream_plan(Q, Cin, Cout, &splits, &rpb);
+        const int ring = (128 + 2 * (W + 3) + 32 + 15) / 16 * 16;
+        const size_t lds = (size_t)(ring + 32) * 64 + 2 * 64 * 64;
+        dim3 grid((Cout / 32) * (Cin / 32), splits);
+        hipLaunchKernelGGL(conv_wgrad3x3_stream_kernel, grid, dim3(64), lds, s, (const __bf16*)pad_x, (const __bf16*)pad_dy, gw_packed,
+                           Q, W + 2, Cin, Cout, rpb, ring);
+        return launch_status();
+    }
+    // the kernels below accumulate into copy 0 with atomics; the caller adds all nsplit copies up
+    if (hipMemsetAsync(gw_packed, 0, sizeof(float) * (size_t)nsplit * Cout * taps * Cin, s) != hipSuccess) return SUBREG_EHIP;
     if (dtype == SUBREG_BF16 && (taps == 1 || (pad_x && pad_dy))) {
         // bf16 MFMA path: 3x3 on zero-bordered copies (padded pixel coordinates), 1x1 directly on the compact tensors
         const __bf16 *xq = (const __bf16*)x, *dq = (const __bf16*)dy;
@@ -423,7 +610,8 @@ extern "C" int subreg_conv_wgrad(const void* x, const void* dy, float* gw_packed
 #define WGB(NCW) (taps == 9 ? launch_wgrad_bf16<NCW, 9>(xq, dq, gw_packed, Q, W + 2, Cin, Cout, s) \
                             : launch_wgrad_bf16<NCW, 1>(xq, dq, gw_packed, Q, W + 2, Cin, Cout, s))
         int rc;
-        if (Cin % 160 == 0) rc = WGB(5);
+        if (taps == 9) rc = WGB(1);           // 144 accumulator registers per wave: one-wave workgroups keep 8 waves per CU
+        else if (Cin % 160 == 0) rc = WGB(5);
         else if (Cin % 64 == 0) rc = WGB(2);
         else rc = WGB(1);
 #undef WGB
@@ -444,12 +632,13 @@ extern "C" int subreg_conv_wgrad(const void* x, const void* dy, float* gw_packed
     return launch_status();
 }
 
-extern "C" int subreg_unpack_wgrad(const float* gw_packed, float* grad_oihw, int Cout, int Cin, int ksize, int mode,
+extern "C" int subreg_unpack_wgrad(const float* gw_packed, float* grad_oihw, int Cout, int Cin, int ksize, int mode, int splits,
                                    void* stream) {
-    SUBREG_CHECK_ARG(gw_packed && grad_oihw && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3));
+    SUBREG_CHECK_ARG(gw_packed && grad_oihw && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3) && splits >= 1);
     SUBREG_CHECK_ARG(mode == 0 || (mode == 1 && Cin == 3));
-    const size_t n = (size_t)Cout * Cin * ksize * ksize;
-    hipLaunchKernelGGL(unpack_wgrad_kernel, bw_blocks(n), BW_THREADS, 0, (hipStream_t)stream, gw_packed, grad_oihw, Cout, Cin, ksize, mode);
+    const size_t n = mode == 0 ? (size_t)Cout * Cin * ksize * ksize : (size_t)Cout * 32;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, bw_blocks(n), BW_THREADS, 0, (hipStream_t)stream, gw_packed, grad_oihw, Cout, Cin, ksize, mode,
+                       splits);
     return launch_status();
 }
 

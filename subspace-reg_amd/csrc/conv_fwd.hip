@@ -120,30 +120,6 @@ __device__ __forceinline__ void mma_step<float>(const uint4& a, const uint4& b, 
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], acc, 0, 0, 0);
 }
 
-// one 1-KiB LDS-DMA piece: 64 lanes x 16 B from `base + voff` (wave-uniform 64-bit base in SGPRs, per-lane 32-bit byte
-// offset), LDS image lane-linear from the wave-uniform LDS byte address `lds_addr`.
-// Issued from inline asm ON PURPOSE: for the builtin form hipcc (ROCm 7.2) inserts `s_waitcnt vmcnt(0)` in front of
-// the next ds_read of ANY LDS address, which drains the prefetch every step; asm DMAs are invisible to that pass, so
-// the counted `s_waitcnt vmcnt(N)` + `s_barrier` at the end of each step are the only (hand-placed) waits on them.
-// M0 (the DMA's LDS base) is compiler-reserved: save / set / restore inside the one statement.
-__device__ __forceinline__ void dma16(const char* base_in, unsigned voff, unsigned lds_addr) {
-    // the base is wave-uniform by construction; say so where the compiler's uniformity analysis cannot see it
-    const unsigned long long bu = (unsigned long long)(size_t)base_in;
-    const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bu);
-    const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bu >> 32));
-    const char* base = (const char*)(size_t)(((unsigned long long)bhi << 32) | blo);
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(base), "s"(lds_addr)
-        : "memory");
-}
-
 // NI x NJ 32x32 accumulator blocks per wave (held as TR x TR MFMA tiles); WAVES_M x WAVES_N waves per workgroup; TPS taps staged per step
 // (one barrier per step); MINW = minimum waves per SIMD the register allocation must allow.
 template <typename T, int NI, int NJ, int WAVES_M, int WAVES_N, int TAPS, int TPS, bool POOL, int AROWS, int MINW>

@@ -154,31 +154,52 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 
 // ---------------------------------------------------------------- train-mode apply pass
 // y = mask * mask_scale * pool( act( x*scale+shift + (res*rscale+rshift | res) ) ), all NHWC.
+// One thread = 16 bytes of output (8 bf16 / 4 f32 channels of one output pixel): HBM-bound pass.
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                 const T* __restrict__ res, const float* __restrict__ rscale,
                                 const float* __restrict__ rshift, const unsigned char* __restrict__ keep,
                                 float mask_scale, T* __restrict__ y, int B, int H, int W, int C, int act, int pool) {
+    constexpr int VEC = 16 / sizeof(T);
     const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (i >= (size_t)B * Ho * Wo * C) return;
-    const int c = i % C;
+    const int c0 = i % C;
     const size_t po = i / C;
     const int wo = po % Wo, ho = (po / Wo) % Ho, b = po / ((size_t)Wo * Ho);
-    const float sc = scale[c], sh = shift[c];
-    const float rsc = rscale ? rscale[c] : 1.f, rsh = rshift ? rshift[c] : 0.f;
-    float best = -3.0e38f;
+    float sc[VEC], sh[VEC], rsc[VEC], rsh[VEC], best[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        sc[k] = scale[c0 + k]; sh[k] = shift[c0 + k];
+        rsc[k] = rscale ? rscale[c0 + k] : 1.f; rsh[k] = rshift ? rshift[c0 + k] : 0.f;
+        best[k] = -3.0e38f;
+    }
     const int n = pool ? 2 : 1;
     for (int dy = 0; dy < n; ++dy)
         for (int dx = 0; dx < n; ++dx) {
             const size_t p = ((size_t)b * H + (pool ? 2 * ho + dy : ho)) * W + (pool ? 2 * wo + dx : wo);
-            float v = ElemTraits<T>::to_float(x[p * C + c]) * sc + sh;
-            if (res) v += ElemTraits<T>::to_float(res[p * C + c]) * rsc + rsh;
-            best = fmaxf(best, v);
+            const uint4 vx = *reinterpret_cast<const uint4*>(x + p * C + c0);
+            uint4 vr = make_uint4(0, 0, 0, 0);
+            if (res) vr = *reinterpret_cast<const uint4*>(res + p * C + c0);
+            const T* tx = reinterpret_cast<const T*>(&vx);
+            const T* tr = reinterpret_cast<const T*>(&vr);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float v = ElemTraits<T>::to_float(tx[k]) * sc[k] + sh[k];
+                if (res) v += ElemTraits<T>::to_float(tr[k]) * rsc[k] + rsh[k];
+                best[k] = fmaxf(best[k], v);
+            }
         }
-    if (act) best = lrelu(best);
-    if (keep) best = keep[i] ? best * mask_scale : 0.f;
-    y[i] = ElemTraits<T>::from_float(best);
+    uint4 vo;
+    T* to = reinterpret_cast<T*>(&vo);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        float v = best[k];
+        if (act) v = lrelu(v);
+        if (keep) v = keep[i + k] ? v * mask_scale : 0.f;
+        to[k] = ElemTraits<T>::from_float(v);
+    }
+    *reinterpret_cast<uint4*>(y + i) = vo;
 }
 
 // ---------------------------------------------------------------- keep-mask helpers
@@ -199,18 +220,33 @@ __device__ __forceinline__ unsigned mix32(unsigned long long z) {
     z ^= z >> 33; z *= 0xff51afd7ed558ccdULL; z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ULL; z ^= z >> 33;
     return (unsigned)(z >> 11);
 }
-__global__ void random_keep_kernel(unsigned char* __restrict__ out, size_t n, unsigned long long seed, float p_drop,
-                                   unsigned int* __restrict__ kept_count) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned k = 0;
-    if (i < n) {
-        const float u = (mix32(seed * 0x9E3779B97F4A7C15ULL + i) & 0xFFFFFF) * (1.0f / 16777216.0f);
-        k = u >= p_drop ? 1u : 0u;
-        out[i] = (unsigned char)k;
+// element i keeps iff uniform(seed, i) >= p_drop.  16 elements per thread (one 16-byte store); the kept count goes through
+// a block reduction and ONE atomic per block (an atomic per wave on a single address serialises the whole kernel).
+__global__ __launch_bounds__(256) void random_keep_kernel(unsigned char* __restrict__ out, size_t n, unsigned long long seed,
+                                                          float p_drop, unsigned int* __restrict__ kept_count) {
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    unsigned kept = 0;
+    if (i0 < n) {
+        unsigned char b[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float u = (mix32(seed * 0x9E3779B97F4A7C15ULL + i0 + k) & 0xFFFFFF) * (1.0f / 16777216.0f);
+            b[k] = (i0 + k < n && u >= p_drop) ? 1 : 0;
+            kept += b[k];
+        }
+        if (i0 + 16 <= n && (reinterpret_cast<size_t>(out) & 15) == 0) {
+            *reinterpret_cast<uint4*>(out + i0) = *reinterpret_cast<const uint4*>(b);
+        } else {
+            for (int k = 0; k < 16 && i0 + k < n; ++k) out[i0 + k] = b[k];
+        }
     }
     if (kept_count) {
-        const unsigned long long b = __ballot(k);
-        if ((threadIdx.x & 63) == 0) atomicAdd(kept_count, (unsigned)__popcll(b));
+        __shared__ unsigned wsum[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = kept;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(kept_count, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
     }
 }
 
@@ -313,12 +349,13 @@ extern "C" int subreg_bn_apply(const void* x, const float* scale, const float* s
     SUBREG_CHECK_ARG(x && scale && shift && y && B > 0 && H > 0 && W > 0 && C > 0);
     const int act = (flags & SUBREG_CONV_LRELU) ? 1 : 0, pool = (flags & SUBREG_CONV_POOL2) ? 1 : 0;
     SUBREG_CHECK_ARG(!pool || (H >= 2 && W >= 2));
+    SUBREG_CHECK_ARG(C % (dtype == SUBREG_BF16 ? 8 : 4) == 0);      // 16-byte vectors along the channel axis
     const size_t n = (size_t)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * C;
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn_apply_kernel<float>, ew_blocks(n), EW_THREADS, 0, s, (const float*)x, scale, shift,
+               hipLaunchKernelGGL(bn_apply_kernel<float>, ew_blocks(n / 4), EW_THREADS, 0, s, (const float*)x, scale, shift,
                                   (const float*)residual, res_scale, res_shift, keep_mask, mask_scale, (float*)y, B, H, W, C, act, pool),
-               hipLaunchKernelGGL(bn_apply_kernel<__bf16>, ew_blocks(n), EW_THREADS, 0, s, (const __bf16*)x, scale, shift,
+               hipLaunchKernelGGL(bn_apply_kernel<__bf16>, ew_blocks(n / 8), EW_THREADS, 0, s, (const __bf16*)x, scale, shift,
                                   (const __bf16*)residual, res_scale, res_shift, keep_mask, mask_scale, (__bf16*)y, B, H, W, C, act, pool));
     return launch_status();
 }
@@ -335,8 +372,8 @@ extern "C" int subreg_mask_nchw_to_nhwc(const float* mask_nchw, unsigned char* k
 extern "C" int subreg_random_keep_mask(unsigned char* keep, long long n, unsigned long long seed, float p_drop,
                                        unsigned int* kept_count, void* stream) {
     SUBREG_CHECK_ARG(keep && n > 0 && p_drop >= 0.f && p_drop < 1.f);
-    hipLaunchKernelGGL(random_keep_kernel, ew_blocks((size_t)n), EW_THREADS, 0, (hipStream_t)stream, keep, (size_t)n, seed,
-                       p_drop, kept_count);
+    hipLaunchKernelGGL(random_keep_kernel, dim3((unsigned)(((size_t)n + 4095) / 4096)), dim3(256), 0, (hipStream_t)stream, keep,
+                       (size_t)n, seed, p_drop, kept_count);
     return launch_status();
 }
 

@@ -34,6 +34,30 @@ template <> struct ElemTraits<__bf16> {
     static __device__ __forceinline__ __bf16 from_float(float v) { return (__bf16)v; }
 };
 
+// one 1-KiB LDS-DMA piece: 64 lanes x 16 B from `base + voff` (wave-uniform 64-bit base in SGPRs, per-lane 32-bit byte
+// offset), LDS image lane-linear from the wave-uniform LDS byte address `lds_addr`.
+// Issued from inline asm ON PURPOSE: for the builtin form hipcc (ROCm 7.2) inserts `s_waitcnt vmcnt(0)` in front of
+// the next ds_read of ANY LDS address, which drains the prefetch every step; asm DMAs are invisible to that pass, so
+// the counted `s_waitcnt vmcnt(N)` + `s_barrier` at the end of each step are the only (hand-placed) waits on them.
+// M0 (the DMA's LDS base) is compiler-reserved: save / set / restore inside the one statement.
+__device__ __forceinline__ void dma16(const char* base_in, unsigned voff, unsigned lds_addr) {
+    // the base is wave-uniform by construction; say so where the compiler's uniformity analysis cannot see it
+    const unsigned long long bu = (unsigned long long)(size_t)base_in;
+    const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bu);
+    const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bu >> 32));
+    const char* base = (const char*)(size_t)(((unsigned long long)bhi << 32) | blo);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(base), "s"(lds_addr)
+        : "memory");
+}
+
 __device__ __forceinline__ float lrelu(float v) { return v >= 0.f ? v : v * 0.1f; }   // nn.LeakyReLU(0.1)
 
 }  // namespace subreg

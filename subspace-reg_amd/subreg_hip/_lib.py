@@ -87,7 +87,8 @@ SIGNATURES = {
     "subreg_bn_train_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "subreg_pack_conv_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "subreg_conv_wgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "subreg_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "subreg_conv_wgrad_splits": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "subreg_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_bn_bwd_slices": (_I, [_L]),
     "subreg_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "subreg_block_tail_bwd": (_I, [_P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -30,6 +30,7 @@ class TrainStash:
             return t
 
         h, w, cmax, amax, pmax = H, W, 0, B * H * W * 32, 0
+        gw_need, gw_users = 0, []
         self.grads = {}                      # state_dict key -> fp32 gradient tensor
         self.dgrad = []                      # (conv name, cout, cin, k, packed tensor)
         for bi, (name, cin, cout, stride, ds, _db) in enumerate(hb.blocks):
@@ -53,7 +54,9 @@ class TrainStash:
                     setattr(tc, f, self.named[(bi, slot, f)].data_ptr())
                 kin = 32 if ci == 3 else ci
                 kk = 1 if ci == 3 else k
-                tc.gw_packed = buf(cout * kk * kk * kin, f32).data_ptr()
+                nsplit = lib.subreg_conv_wgrad_splits(B, h, w, kin, cout, kk, hb.dtype)
+                gw_need = max(gw_need, nsplit * cout * kk * kk * kin)
+                gw_users.append(tc)
                 gw = torch.zeros(cout, ci, k, k, dtype=f32, device=dev)
                 gg, gb = torch.zeros(cout, dtype=f32, device=dev), torch.zeros(cout, dtype=f32, device=dev)
                 self.grads[cname + ".weight"], self.grads[bname + ".weight"], self.grads[bname + ".bias"] = gw, gg, gb
@@ -71,6 +74,9 @@ class TrainStash:
             self.desc.g[i] = buf(amax).data_ptr()
         for f in ("dv", "dr", "dt", "dr2"):
             setattr(self.desc, f, buf(amax).data_ptr())
+        gw_shared = buf(gw_need, f32)           # one scratch for every conv's per-split partial dW (used one conv at a time)
+        for tc in gw_users:
+            tc.gw_packed = gw_shared.data_ptr()
         self.desc.pad_x = buf(pmax).data_ptr() if hb.dtype == _lib.BF16 else None
         self.desc.pad_dy = buf(pmax).data_ptr() if hb.dtype == _lib.BF16 else None
         self.desc.bn_partial = buf(lib.subreg_bn_bwd_slices(B * H * W) * cmax * 2, torch.float64).data_ptr()

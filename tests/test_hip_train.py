@@ -28,7 +28,8 @@ def _td(dtype):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 21, 21, 64, 96, 3), (3, 10, 10, 160, 64, 1), (2, 9, 7, 32, 32, 3), (4, 5, 5, 320, 320, 3),
-                                   (2, 42, 42, 160, 160, 3), (3, 84, 84, 32, 64, 1), (2, 84, 84, 64, 64, 3), (3, 10, 10, 640, 320, 1)])
+                                   (2, 42, 42, 160, 160, 3), (3, 84, 84, 32, 64, 1), (2, 84, 84, 64, 64, 3), (3, 10, 10, 640, 320, 1),
+                                   (1, 3, 3, 32, 32, 3), (5, 21, 10, 96, 32, 3), (64, 5, 5, 64, 64, 3)])
 def test_conv_wgrad_and_dgrad(shape, dtype):
     B, H, W, Cin, Cout, k = shape
     lib = _lib.load()
@@ -41,12 +42,14 @@ def test_conv_wgrad_and_dgrad(shape, dtype):
     dx_ref, dw_ref = br.conv_backward(rr._nhwc(x), w, rr._nhwc(dy))
     dt = _lib.dtype_code(dtype)
     xd, dyd = _nhwc_dev(x, dtype), _nhwc_dev(dy, dtype)
-    gw = torch.empty(Cout * k * k * Cin, dtype=torch.float32, device=_dev())
+    nsplit = lib.subreg_conv_wgrad_splits(B, H, W, Cin, Cout, k, dt)
+    assert nsplit >= 1 and (nsplit == 1 or (dtype == "bf16" and k == 3))
+    gw = torch.full((nsplit * Cout * k * k * Cin,), float("nan"), dtype=torch.float32, device=_dev())   # every copy must be written
     grad = torch.empty(Cout, Cin, k, k, dtype=torch.float32, device=_dev())
     pads = [torch.empty(B * (H + 2) * (W + 2) * c, dtype=_td(dtype), device=_dev()) for c in (Cin, Cout)] if dtype == "bf16" else [None, None]
     _lib.check(lib.subreg_conv_wgrad(_lib.ptr(xd), _lib.ptr(dyd), _lib.ptr(gw), _lib.ptr(pads[0]), _lib.ptr(pads[1]), B, H, W, Cin, Cout,
                                      k, dt, _lib.stream_ptr()))
-    _lib.check(lib.subreg_unpack_wgrad(_lib.ptr(gw), _lib.ptr(grad), Cout, Cin, k, 0, _lib.stream_ptr()))
+    _lib.check(lib.subreg_unpack_wgrad(_lib.ptr(gw), _lib.ptr(grad), Cout, Cin, k, 0, nsplit, _lib.stream_ptr()))
     torch.cuda.synchronize()
     _cmp("dW", grad.cpu().numpy(), dw_ref, 1e-3 * np.abs(dw_ref).max(), 1e-4)
     # dX = forward kernel on dY with the flipped / transposed weights
