@@ -103,9 +103,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-// block = 16 channels x 16 slice lanes: the slices of a channel are summed by 16 threads (fixed order, fp64), not by one
+// block = 16 channels x 16 slice lanes: the slices of a channel are summed by 16 threads (fixed order, fp64), not by one.
+// Also emits the three per-channel coefficients of the apply pass:
+//   dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N) = k1*g + k2*raw + k3,
+//   k1 = gamma*invstd, k2 = -k1*invstd*dgamma/N, k3 = k1*(mean*invstd*dgamma - dbeta)/N.
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int slices, int C,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, double inv_n,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef) {
     __shared__ double red[2][16][17];
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
     double t1 = 0.0, t2 = 0.0;
@@ -122,16 +128,18 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
         for (int l = 0; l < 16; ++l) { t1 += red[0][l][cl]; t2 += red[1][l][cl]; }
         dbeta[c] = (float)t1;
         dgamma[c] = (float)t2;
+        const double is = invstd[c], k1 = (double)gamma[c] * is;
+        coef[c] = (float)k1;
+        coef[C + c] = (float)(-k1 * is * t2 * inv_n);
+        coef[2 * C + c] = (float)(k1 * ((double)mean[c] * is * t2 - t1) * inv_n);
     }
 }
 
-// dx = gamma*invstd * (g - dbeta/N - xhat*dgamma/N)
-// One thread = 16 bytes (8 bf16 / 4 f32 channels of one pixel): the pass is HBM-bound (3 tensors read, 1 written).
+// dx = k1*g + k2*raw + k3 with g = dy*lrelu'(act).  One thread = 16 bytes (8 bf16 / 4 f32 channels of one pixel): the pass
+// is HBM-bound (3 tensors read, 1 written); the coefficients come in as float4 vectors.
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ act, const T* __restrict__ raw,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const float* __restrict__ gamma, const float* __restrict__ dgamma,
-                                    const float* __restrict__ dbeta, T* __restrict__ dx, long long npix, int C) {
+                                    const float* __restrict__ coef, T* __restrict__ dx, long long npix, int C) {
     constexpr int VEC = 16 / sizeof(T);
     const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t e = v * VEC;
@@ -140,19 +148,23 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
     const uint4 vd = *reinterpret_cast<const uint4*>(dy + e), vr = *reinterpret_cast<const uint4*>(raw + e);
     uint4 va = make_uint4(0, 0, 0, 0);
     if (act) va = *reinterpret_cast<const uint4*>(act + e);
+    float k1[VEC], k2[VEC], k3[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k += 4) {
+        *reinterpret_cast<float4*>(k1 + k) = *reinterpret_cast<const float4*>(coef + c0 + k);
+        *reinterpret_cast<float4*>(k2 + k) = *reinterpret_cast<const float4*>(coef + C + c0 + k);
+        *reinterpret_cast<float4*>(k3 + k) = *reinterpret_cast<const float4*>(coef + 2 * C + c0 + k);
+    }
     const T* td = reinterpret_cast<const T*>(&vd);
     const T* tr = reinterpret_cast<const T*>(&vr);
     const T* ta = reinterpret_cast<const T*>(&va);
-    const float inv_n = 1.0f / (float)npix;
     uint4 vo;
     T* to = reinterpret_cast<T*>(&vo);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-        const int c = c0 + k;
         float g = ElemTraits<T>::to_float(td[k]);
         if (act) g *= lrelu_grad(ElemTraits<T>::to_float(ta[k]));
-        const float is = invstd[c], xh = (ElemTraits<T>::to_float(tr[k]) - mean[c]) * is;
-        to[k] = ElemTraits<T>::from_float(gamma[c] * is * (g - dbeta[c] * inv_n - xh * (dgamma[c] * inv_n)));
+        to[k] = ElemTraits<T>::from_float(k1[k] * g + (k2[k] * ElemTraits<T>::to_float(tr[k]) + k3[k]));
     }
     *reinterpret_cast<uint4*>(dx + e) = vo;
 }
@@ -465,15 +477,24 @@ static bool wgrad_stream_ok(long long Q, int W, int Cin, int Cout) {
 }
 
 // packed fp32 [splits][Cout][taps][Cin_k] -> Conv2d.weight.grad OIHW, summing the K splits (mode 1: first-layer K=32
-// layout, see pack_weight_kernel).  One thread per PACKED element: the (large) reads are coalesced, the writes scatter.
-__global__ void unpack_wgrad_kernel(const float* __restrict__ gw, float* __restrict__ grad, int Cout, int Cin, int ks, int mode,
-                                    int splits) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// layout, see pack_weight_kernel).  Block = 32 consecutive PACKED elements x 8 split lanes: coalesced 128-byte reads,
+// every element's splits summed by 8 threads in a fixed order (deterministic), one scattered write per element.
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ gw, float* __restrict__ grad, int Cout, int Cin,
+                                                           int ks, int mode, int splits) {
+    __shared__ float red[8][33];
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const size_t i = (size_t)blockIdx.x * 32 + el;
     const int taps = ks * ks;
     const size_t n = mode == 0 ? (size_t)Cout * taps * Cin : (size_t)Cout * 32;
-    if (i >= n) return;
     float v = 0.f;
-    for (int sp = 0; sp < splits; ++sp) v += gw[(size_t)sp * n + i];
+    if (i < n)
+        for (int sp = sl; sp < splits; sp += 8) v += gw[(size_t)sp * n + i];
+    red[sl][el] = v;
+    __syncthreads();
+    if (sl != 0 || i >= n) return;
+    v = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) v += red[l][el];
     if (mode == 0) {
         const int c = i % Cin, t = (i / Cin) % taps, o = i / ((size_t)Cin * taps);
         grad[((size_t)o * Cin + c) * taps + t] = v;
@@ -533,25 +554,29 @@ extern "C" int subreg_block_tail_bwd(const void* grad_out, const unsigned char* 
     return launch_status();
 }
 
-extern "C" int subreg_bn_bwd_slices(long long npix) { return (int)((npix + 255) / 256); }
+// slices of the reduce pass + one more slice-sized region of `partial` that holds the apply pass's coefficients
+static int bn_bwd_reduce_slices(long long npix) { return (int)((npix + 255) / 256); }
+extern "C" int subreg_bn_bwd_slices(long long npix) { return bn_bwd_reduce_slices(npix) + 1; }
 
 extern "C" int subreg_bn_bwd(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
                              const float* gamma, double* partial, float* dgamma, float* dbeta, void* dx, long long npix, int C,
                              int dtype, void* stream) {
     SUBREG_CHECK_ARG(dy && raw && mean && invstd && gamma && partial && dgamma && dbeta && dx && npix > 0 && C > 0);
     hipStream_t s = (hipStream_t)stream;
-    const int slices = subreg_bn_bwd_slices(npix);
+    const int slices = bn_bwd_reduce_slices(npix);
+    float* const coef = reinterpret_cast<float*>(partial + (size_t)slices * C * 2);     // 3*C floats in the extra slice (4*C)
     const int vec = dtype == SUBREG_BF16 ? 8 : 4;
     SUBREG_CHECK_ARG(C % vec == 0 && C / vec <= 256);
     const size_t lds = (size_t)(256 / (C / vec)) * C * 2 * sizeof(float);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, slices, 256, lds, s, (const float*)dy, (const float*)act, (const float*)raw, mean, invstd, partial, npix, C, 256),
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, slices, 256, lds, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, partial, npix, C, 256));
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, (C + 15) / 16, 256, 0, s, partial, slices, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, (C + 15) / 16, 256, 0, s, partial, slices, C, mean, invstd, gamma, 1.0 / (double)npix,
+                       dgamma, dbeta, coef);
     const size_t n = (size_t)npix * C;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, bw_blocks(n / 4), BW_THREADS, 0, s, (const float*)dy, (const float*)act, (const float*)raw, mean, invstd, gamma, dgamma, dbeta, (float*)dx, npix, C),
-               hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, bw_blocks(n / 8), BW_THREADS, 0, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, gamma, dgamma, dbeta, (__bf16*)dx, npix, C));
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, bw_blocks(n / 4), BW_THREADS, 0, s, (const float*)dy, (const float*)act, (const float*)raw, coef, (float*)dx, npix, C),
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, bw_blocks(n / 8), BW_THREADS, 0, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, coef, (__bf16*)dx, npix, C));
     return launch_status();
 }
 
@@ -637,8 +662,8 @@ extern "C" int subreg_unpack_wgrad(const float* gw_packed, float* grad_oihw, int
     SUBREG_CHECK_ARG(gw_packed && grad_oihw && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3) && splits >= 1);
     SUBREG_CHECK_ARG(mode == 0 || (mode == 1 && Cin == 3));
     const size_t n = mode == 0 ? (size_t)Cout * Cin * ksize * ksize : (size_t)Cout * 32;
-    hipLaunchKernelGGL(unpack_wgrad_kernel, bw_blocks(n), BW_THREADS, 0, (hipStream_t)stream, gw_packed, grad_oihw, Cout, Cin, ksize, mode,
-                       splits);
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, (hipStream_t)stream, gw_packed, grad_oihw,
+                       Cout, Cin, ksize, mode, splits);
     return launch_status();
 }
 

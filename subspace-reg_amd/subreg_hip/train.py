@@ -6,6 +6,7 @@ gradients of all conv weights and BN affine parameters with the gfx950 kernels o
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -30,7 +31,7 @@ class TrainStash:
             return t
 
         h, w, cmax, amax, pmax = H, W, 0, B * H * W * 32, 0
-        gw_need, gw_users = 0, []
+        gw_need, gw_users, grad_slots = 0, [], []
         self.grads = {}                      # state_dict key -> fp32 gradient tensor
         self.dgrad = []                      # (conv name, cout, cin, k, packed tensor)
         for bi, (name, cin, cout, stride, ds, _db) in enumerate(hb.blocks):
@@ -57,10 +58,7 @@ class TrainStash:
                 nsplit = lib.subreg_conv_wgrad_splits(B, h, w, kin, cout, kk, hb.dtype)
                 gw_need = max(gw_need, nsplit * cout * kk * kk * kin)
                 gw_users.append(tc)
-                gw = torch.zeros(cout, ci, k, k, dtype=f32, device=dev)
-                gg, gb = torch.zeros(cout, dtype=f32, device=dev), torch.zeros(cout, dtype=f32, device=dev)
-                self.grads[cname + ".weight"], self.grads[bname + ".weight"], self.grads[bname + ".bias"] = gw, gg, gb
-                tc.grad_w, tc.grad_gamma, tc.grad_beta = gw.data_ptr(), gg.data_ptr(), gb.data_ptr()
+                grad_slots.append((tc, cname + ".weight", (cout, ci, k, k), bname + ".weight", bname + ".bias", cout))
                 tc.w_dgrad = None
                 if bi > 0 or slot in ("conv2", "conv3"):      # no gradient w.r.t. the images: layer1.0 conv1/shortcut need none
                     wd = buf(cout * k * k * ci)
@@ -74,6 +72,18 @@ class TrainStash:
             self.desc.g[i] = buf(amax).data_ptr()
         for f in ("dv", "dr", "dt", "dr2"):
             setattr(self.desc, f, buf(amax).data_ptr())
+        # every parameter gradient lives in ONE flat buffer: backward hands autograd a single clone of it (views), not 66
+        total = sum(int(np.prod(shape)) + 2 * c for _tc, _n, shape, _g, _b, c in grad_slots)
+        self.flat_grads = torch.zeros(total, dtype=f32, device=dev)
+        self.grad_views = []                                   # (name, offset, shape)
+        off = 0
+        for tc, wname, shape, gname, bname_, c in grad_slots:
+            for name, shp, field in ((wname, shape, "grad_w"), (gname, (c,), "grad_gamma"), (bname_, (c,), "grad_beta")):
+                n = int(np.prod(shp))
+                self.grad_views.append((name, off, shp))
+                self.grads[name] = self.flat_grads[off:off + n].view(shp)
+                setattr(tc, field, self.grads[name].data_ptr())
+                off += n
         gw_shared = buf(gw_need, f32)           # one scratch for every conv's per-split partial dW (used one conv at a time)
         for tc in gw_users:
             tc.gw_packed = gw_shared.data_ptr()
@@ -123,8 +133,9 @@ class BackboneTrainFn(torch.autograd.Function):
         dfeat = dfeat.contiguous().float()
         _lib.check(hb.lib.subreg_backbone_backward(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(dfeat), B, H, W,
                                                    _lib.stream_ptr()), "backbone_backward")
-        grads = tuple(stash.grads[n].clone() for n in ctx.names)
-        return (None, None, None, None) + grads
+        flat = stash.flat_grads.clone()
+        views = {name: flat[off:off + int(np.prod(shp))].view(shp) for name, off, shp in stash.grad_views}
+        return (None, None, None, None) + tuple(views[n] for n in ctx.names)
 
 
 class SGD:
