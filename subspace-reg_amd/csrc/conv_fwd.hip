@@ -451,6 +451,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
     T* const y = reinterpret_cast<T*>(a.y);
     const T* const res = reinterpret_cast<const T*>(a.res);
     const bool full = m0 + TM <= g.M && n0 + TN <= a.Cout;            // no ragged edge in this tile
+    constexpr int TPB = 32 / TR;                                      // MFMA tiles per 32-row slab
+    constexpr bool SLAB_FITS = NW * 32 * (NJ * 32 * ELEM + 16) <= 2 * ABUF + NWB * BBUF;   // epilogue slabs reuse the staging LDS
+    const bool raw_slab = !POOL && SLAB_FITS && full;                 // raw tile written by the slab path below
     if (a.raw) {
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
                     const int m = mb + (r & 3) + 8 * (r >> 2);
                     if (full || (m < g.M && n < a.Cout)) {
                         const float v = acc[i][j][r];
-                        y[(unsigned)(m * a.Cout + n)] = ElemTraits<T>::from_float(v);
+                        if (!raw_slab) y[(unsigned)(m * a.Cout + n)] = ElemTraits<T>::from_float(v);
                         s1 += v;
                         s2 += v * v;
                     }
@@ -481,10 +484,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
                 dst[1] = s2;
             }
         }
-        return;
+        if (!raw_slab) return;
     }
-    constexpr int TPB = 32 / TR;                                      // MFMA tiles per 32-row slab
-    constexpr bool SLAB_FITS = NW * 32 * (NJ * 32 * ELEM + 16) <= 2 * ABUF + NWB * BBUF;   // epilogue slabs reuse the staging LDS
     if constexpr (!POOL && SLAB_FITS) if (full && !res) {
         // Full linear tile: stage each 32-row slab of this wave's tile through LDS ([row][channel], +16 B row pad) and
         // write it back as whole 16-byte vectors, consecutive lanes on consecutive addresses of a pixel row.  (The
@@ -495,8 +496,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
             const int n = n0 + (wave_n * MJ + j) * TR + lr;
-            shj[j] = a.shift[n];
-            scj[j] = a.scale ? a.scale[n] : 1.f;
+            shj[j] = a.raw ? 0.f : a.shift[n];
+            scj[j] = (a.raw || !a.scale) ? 1.f : a.scale[n];
         }
 #pragma unroll
         for (int ib = 0; ib < NI; ++ib) {
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
                         float v = acc[ib * TPB + ii][j][r] * scj[j] + shj[j];
-                        if (a.act) v = fmaxf(v, v * 0.1f);            // LeakyReLU(0.1)
+                        if (a.act && !a.raw) v = fmaxf(v, v * 0.1f);  // LeakyReLU(0.1)
                         const int row = ii * TR + (r & 3) + 8 * (r >> 2) + 4 * lh;
                         *reinterpret_cast<T*>(slab + row * RS + (j * TR + lr) * ELEM) = ElemTraits<T>::from_float(v);
                     }
@@ -661,11 +662,15 @@ static int launch_shape(const ConvArgs& a, bool pool, hipStream_t s) {
                 : launch_rows<T, NI, NJ, WM, WN, 1, 1, false, TM, AR_L, MINW>(a, s);
 }
 
-// rows of stats partials the raw mode writes for a given problem (caller sizes the buffer with this)
-static int stats_rows_for(int dtype, int M) {
-    const int wm = dtype == SUBREG_BF16 ? 4 : 2;
-    const int tm = wm * 2 * 32;
-    return ((M + tm - 1) / tm) * wm;
+// bf16, Cout % 160 == 0: 256-row tiles when they fill the chip (256 CUs x 2 resident workgroups), else 128-row tiles
+static bool wide_takes_256_rows(int M, int Cout) { return (long long)((M + 255) / 256) * (Cout / 160) >= 384; }
+
+// rows of stats partials the raw mode writes for a given problem = m-tiles x waves along M of the configuration that
+// subreg_conv_fwd picks for it (the caller sizes the buffer and calls subreg_bn_train_finalize with this)
+static int stats_rows_for(int dtype, int M, int Cout) {
+    if (dtype != SUBREG_BF16) return ((M + 127) / 128) * 2;          // f32: 128-row tiles, 2 waves along M
+    const int tm = (Cout % 160 == 0 && !wide_takes_256_rows(M, Cout)) ? 128 : 256;
+    return ((M + tm - 1) / tm) * 4;
 }
 
 }  // namespace subreg
@@ -673,8 +678,7 @@ static int stats_rows_for(int dtype, int M) {
 using namespace subreg;
 
 extern "C" int subreg_conv_stats_rows(int dtype, int B, int H, int W, int Cout) {
-    (void)Cout;
-    return stats_rows_for(dtype, B * H * W);
+    return stats_rows_for(dtype, B * H * W, Cout);
 }
 
 extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* shift,
@@ -716,9 +720,9 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
         // big maps: 512-row tiles, 8 waves, one workgroup per CU.  Same waves per SIMD as two 256-row workgroups, but
         // every weight tile staged from L2 feeds twice the rows (the L2 -> LDS weight stream is what the 256-row tiling
         // was bound by) and 3 taps per step = a third of the barriers.
-        if (!raw && ((a.g.M + 255) / 256) * nt >= 384) return launch_shape<__bf16, 2, 5, 8, 1, 3, 608, 704, 2>(a, pool, s);
+        if (!raw && wide_takes_256_rows(a.g.M, Cout)) return launch_shape<__bf16, 2, 5, 8, 1, 3, 608, 704, 2>(a, pool, s);
 #endif
-        if (raw || ((a.g.M + 255) / 256) * nt >= 384) {
+        if (wide_takes_256_rows(a.g.M, Cout)) {
             // patches of <= 352 rows (W <= 42 unpooled) leave room for the 3-deep weight ring at two workgroups per CU
             const int rc = launch_shape<__bf16, 2, 5, 4, 1, 1, 352, 432, 2>(a, pool, s);
             return rc != SUBREG_EUNSUPPORTED ? rc : launch_shape<__bf16, 2, 5, 4, 1, 1, 560, 560, 2>(a, pool, s);
