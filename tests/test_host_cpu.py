@@ -106,3 +106,37 @@ def test_synthetic_episode_layout():
     assert list(sy[:10]) == [70] * 5 + [71] * 5 and list(qy[:26]) == [70] * 25 + [71]
     from oracle.resnet_ref import conv_flops_per_image
     assert abs(conv_flops_per_image(84) / 8.1219e9 - 1) < 1e-3
+
+
+def test_checkpoint_round_trip_in_reference_format(tmp_path):
+    """train_supervised.py:181-202 writer / eval_incremental.py:86-123 reader: same dict keys, 133 model keys, bias rule."""
+    import argparse
+    import torch
+    from subreg_hip import checkpoint as ck
+    from subreg_hip.resnet_language import create_model
+    opt = argparse.Namespace(no_dropblock=True, linear_bias=False, model="resnet18", continual=True)
+    net = create_model("resnet18", 60, opt)
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in syn.make_state_dict(3).items()}
+    net.load_state_dict(sd)
+    basec = {int(c): i for i, c in enumerate(range(5, 65))}
+    names = ["class%d" % i for i in range(60)] + [""] * 40
+    last = ck.save_checkpoint(str(tmp_path / "m" / "resnet18_last.pth"), net, opt=opt, training_classes=basec, label2human=names)
+    per = ck.save_checkpoint(str(tmp_path / "m" / "ckpt_epoch_10.pth"), net, epoch=10)
+    c1, c2 = ck.load_checkpoint(last), ck.load_checkpoint(per)
+    assert sorted(c1.keys()) == ["label2human", "model", "opt", "training_classes"] and sorted(c2.keys()) == ["epoch", "model"]
+    assert c2["epoch"] == 10 and c1["opt"].model == "resnet18" and len(c1["model"]) == 133
+    assert ck.infer_linear_bias(c1) is False
+    fwd, rev = ck.base_class_maps(c1)
+    assert fwd == basec and all(fwd[rev[i]] == i for i in range(60))
+    opt2 = argparse.Namespace(no_dropblock=True, linear_bias=True)
+    net2 = ck.model_from_checkpoint(c1, "resnet18", 60, opt2)
+    assert opt2.linear_bias is False
+    for k, v in net2.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k]), k
+    # a plain torch state_dict written the way the reference writes it loads too (no HIP-side keys leak into the file)
+    torch.save({"opt": opt, "model": sd}, str(tmp_path / "ref_style.pth"))
+    net3 = ck.model_from_checkpoint(ck.load_checkpoint(str(tmp_path / "ref_style.pth")), "resnet18", 60, opt2)
+    assert torch.equal(net3.state_dict()["layer4.1.bn3.running_var"].cpu(), sd["layer4.1.bn3.running_var"])
+    with pytest.raises(KeyError):
+        torch.save({"opt": opt}, str(tmp_path / "bad.pth"))
+        ck.load_checkpoint(str(tmp_path / "bad.pth"))
