@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUBREG_ABI_VERSION 1
+#define SUBREG_ABI_VERSION 2
 
 #define SUBREG_OK 0
 #define SUBREG_EINVAL (-1)       /* bad argument (null pointer, shape not supported by contract) */
@@ -259,8 +259,19 @@ typedef struct subreg_step_desc {
     float* train_acc;        /* [max_epochs] support top-1 % */
     int max_epochs, min_epochs, stable_epochs, stable_mode;
     float target_loss, convergence_eps;
+    const float* pull_target; /* [n_classes - n_old][dim] CONSTANT pullers of this session's novel rows (semantic subspace
+                               * regularizer / linear mapping, LangPuller.forward :75-87), or NULL: project onto `basis` */
 } subreg_step_desc;
 
+/* LangPuller.forward, resnet_language.py:75-83 (semantic subspace regularizer): target[n_novel][dim] =
+ * softmax(novel_embeds[n_novel][embed_dim] base_embeds[n_base][embed_dim]^T / temperature, dim=1) @ base_weight[n_base][dim];
+ * mask_diagonal: scores.fill_diagonal_(-9999) first (:80-81).  probs [n_novel][n_base] (optional) feeds the backward
+ * grad_base_weight = probs^T @ grad_target. */
+int subreg_semantic_target(const float* novel_embeds, const float* base_embeds, const float* base_weight, int n_novel, int n_base,
+                           int embed_dim, int dim, float temperature, int mask_diagonal, float* probs, float* target,
+                           void* stream);
+int subreg_semantic_target_bwd(const float* probs, const float* grad_target, int n_novel, int n_base, int dim,
+                               float* grad_base_weight, void* stream);
 int subreg_loop_state_init(subreg_loop_state* state, void* stream);
 int subreg_finetune_step(const subreg_step_desc* d, void* stream);
 /* validate (:18-43) / eval_base (:46-69): correct[slot*n_sets_max + set_index] += #(argmax == label), slot =

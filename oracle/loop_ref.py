@@ -65,7 +65,7 @@ class _Bump:
 
 
 def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=None,
-                    masks=None, memory_picks=None, reuse_features=True, n_base=60):
+                    masks=None, memory_picks=None, reuse_features=True, n_base=60, embeds=None, names=None, mapping=None):
     """Run `len(sessions)` incremental sessions.  Returns a dict of everything the goldens pin."""
     f32 = np.float32
     bump = _Bump(net)
@@ -105,6 +105,17 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
         query_ids.append(qid)
         if base_support is not None:
             sid = np.concatenate([sid, np.asarray(base_support[1], np.int64)])  # :207-209
+        # constant pullers of the semantic / linear-mapping variants (:216-227): base embeddings of the 60 base names,
+        # novel embeddings of THIS session's class names; `names` = (label2human of the base loader, of the meta loader)
+        pull_target = None
+        if opt.label_pull is not None and getattr(opt, "attraction_override", None) != "distance2subspace":
+            vocab_base = [n for n in names[0] if n != ""]
+            e_novel = sr.get_embeds(embeds, [names[1][int(c)] for c in novel_ids], opt.word_embed_size)
+            if getattr(opt, "attraction_override", None) == "mapping_linear_label2image":
+                pull_target = sr.linear_map_target(e_novel, mapping[0], mapping[1]).astype(f32)
+            else:
+                e_base = sr.get_embeds(embeds, vocab_base, opt.word_embed_size)
+                pull_target = sr.semantic_target(e_novel, e_base, base_weight[:n_base], opt.temperature)[0].astype(f32)
         net.train()                                                             # :211
         W = np.concatenate([W, np.asarray(novel_inits[idx], f32)], 0)           # augment_base_classifier_, :214
         net.sd["classifier.weight"] = W
@@ -141,7 +152,10 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
                 loss = f32(loss + f32(l))
                 grad[n_base:n_base + k] += g
             if opt.label_pull is not None:                                       # :277-290
-                l, g = sr.loss1_and_grad(opt.label_pull, base_weight, W[n_old:])
+                if pull_target is not None:
+                    l, g = sr.loss1_to_target_and_grad(opt.label_pull, pull_target, W[n_old:])
+                else:
+                    l, g = sr.loss1_and_grad(opt.label_pull, base_weight, W[n_old:])
                 loss = f32(loss + f32(l))
                 grad[n_old:] += g
             # ---- SGD step (torch.optim.SGD: wd added to grad, momentum buffer), :293-295

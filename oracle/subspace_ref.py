@@ -3,6 +3,8 @@
 Follows /root/reference/models/resnet_language.py:
   LangPuller.get_projected_weight :92-97   thin QR of W_base^T, P = ((wQ)/||Q^T rows||) Q^T
   LangPuller.loss1                :89-90   pull * ||P - w||_F^2      (squared)
+  LangPuller.forward              :75-87   semantic target softmax(E_n E_b^T / temp) W_base, or LinearMap(E_n)
+  models/util.py get_embeds       :50-66   class-name embedding = mean of word vectors (with its unknown-word quirk)
   ResNet.regloss                  :229-233 lmbd * ||W[:nb] - W_base||_F   (NOT squared)
   ResNet.reglossnovel             :235-240 lmbd * ||W[nc:nc+k] - W_prev||_F (NOT squared)
 Gradients are what torch autograd produces for those expressions (the gradient of
@@ -43,6 +45,40 @@ def loss1_to_target_and_grad(pull, target, weights):
     """pull*||target - w||^2 for a CONSTANT target (semantic / linear-mapping variants, :75-90)."""
     r = np.asarray(weights, np.float64) - np.asarray(target, np.float64)
     return pull * float((r * r).sum()), 2.0 * pull * r
+
+
+def get_embeds(table, vocab, dim=500):
+    """models/util.py:50-66: per class name the mean of its words' vectors.  Restated with the reference's quirk: an
+    unknown word RESETS the running sum to zeros (words after it are still added) and the divisor stays len(words)."""
+    out = []
+    for token in vocab:
+        words = token.split(" ")
+        acc = 0
+        for w in words:
+            if w in table:
+                acc = acc + np.asarray(table[w])
+            else:
+                acc = np.zeros(dim)
+        out.append(np.asarray(acc, np.float64) / len(words))
+    return np.stack(out, 0).astype(np.float32)             # .float() at resnet_language.py:32,47
+
+
+def semantic_target(novel_embeds, base_embeds, base_weight, temp=1.0, mask=False):
+    """LangPuller.forward, resnet_language.py:75-83: softmax(E_n E_b^T / temp [diag := -9999]) @ W_base.  Returns
+    (target, probs) in float64."""
+    scores = np.asarray(novel_embeds, np.float64) @ np.asarray(base_embeds, np.float64).T
+    if mask:
+        np.fill_diagonal(scores, -9999.0)
+    z = scores / temp
+    z = z - z.max(axis=1, keepdims=True)
+    p = np.exp(z)
+    p /= p.sum(axis=1, keepdims=True)
+    return p @ np.asarray(base_weight, np.float64), p
+
+
+def linear_map_target(novel_embeds, map_weight, map_bias):
+    """LangPuller.forward with a mapping model (:84-87): LinearMap(novel_embeds) = E_n W^T + b."""
+    return np.asarray(novel_embeds, np.float64) @ np.asarray(map_weight, np.float64).T + np.asarray(map_bias, np.float64)
 
 
 def frob_reg_and_grad(lmbd, w_rows, anchor):

@@ -45,6 +45,22 @@ __device__ __forceinline__ F block_sum(F v, F* red /* >= 17 entries of LDS */) {
     return red[16];
 }
 
+__device__ __forceinline__ float block_max(float v, float* red /* >= 17 entries of LDS */) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = red[0];
+        for (int w = 1; w < nw; ++w) t = fmaxf(t, red[w]);
+        red[16] = t;
+    }
+    __syncthreads();
+    return red[16];
+}
+
 // ---------------------------------------------------------------- logits for one row b (block = 256 threads)
 // wave w computes classes n = w, w+4, ...: lanes stride the feature dim (coalesced W rows), wave-reduce.
 __device__ __forceinline__ void row_logits(const float* __restrict__ f, const float* __restrict__ W,
@@ -233,6 +249,7 @@ struct StepArgs {
     int* rowcorrect;        // [Bs+Bm] argmax == label
     float* norms;           // [2] ||W[:nb]-Wbase||, ||W[nb:nb+np]-Wprev||
     float* rowl1;           // [N] pull*||P_n - w_n||^2 for the novel rows, 0 elsewhere
+    const float* target;    // [N - n_old][D] constant pullers (semantic / mapping variants) or null (projection onto Q)
     subreg_loop_state* st;
     float* losses;          // [max_epochs] per-epoch loss
     float* train_acc;       // [max_epochs]
@@ -300,8 +317,8 @@ __global__ __launch_bounds__(256) void step_update_kernel(const StepArgs a) {
     for (int b = threadIdx.x; b < Bt; b += blockDim.x) s_dl[b] = a.dlogits[(size_t)b * a.N + n];
     __syncthreads();
     float* wr = a.W + (size_t)n * D;
-    const bool novel = a.use_pull && a.Q && n >= a.n_old;
-    if (novel) project_row(wr, a.Q, a.n_base, D, s_c);
+    const bool novel = a.use_pull && (a.Q || a.target) && n >= a.n_old;
+    if (novel && !a.target) project_row(wr, a.Q, a.n_base, D, s_c);
     float kb = 0.f, kp = 0.f;
     if (a.use_base && n < a.n_base) kb = a.norms[0] > 0.f ? a.lmbd_base / a.norms[0] : 0.f;
     if (a.use_prev && n >= a.n_base && n < a.n_base + a.n_prev) kp = a.norms[1] > 0.f ? a.lmbd_prev / a.norms[1] : 0.f;
@@ -313,9 +330,14 @@ __global__ __launch_bounds__(256) void step_update_kernel(const StepArgs a) {
         if (kb != 0.f) g += kb * (w - a.Wbase[(size_t)n * D + d]);
         if (kp != 0.f) g += kp * (w - a.Wprev[(size_t)(n - a.n_base) * D + d]);
         if (novel) {
-            float p = 0.f;
-            for (int j = 0; j < a.n_base; ++j) p = fmaf(s_c[j], a.Q[(size_t)j * D + d], p);
-            const float r = p - w;
+            float r;
+            if (a.target) {                            // constant puller (semantic / linear-mapping variants): only d/dw
+                r = a.target[(size_t)(n - a.n_old) * D + d] - w;
+            } else {                                   // P(w) - w with P the projection onto span(W_base): both paths
+                float p = 0.f;
+                for (int j = 0; j < a.n_base; ++j) p = fmaf(s_c[j], a.Q[(size_t)j * D + d], p);
+                r = p - w;
+            }
             l1 += (double)r * r;
             g -= 2.f * a.pull * r;
         }
@@ -402,6 +424,58 @@ __global__ void validate_mark_kernel(subreg_loop_state* st) {
     if (threadIdx.x == 0 && blockIdx.x == 0) st->val_epoch = st->epoch;
 }
 
+// ---------------------------------------------------------------- semantic subspace regularizer target
+// LangPuller.forward, models/resnet_language.py:75-83: scores = E_novel E_base^T (optionally diagonal := -9999),
+// probs = softmax(scores / temp, dim=1), target = probs @ W_base.  One block per novel row; n_base <= 1024.
+__global__ __launch_bounds__(256) void semantic_target_kernel(const float* __restrict__ en, const float* __restrict__ eb,
+                                                              const float* __restrict__ wb, int n_base, int edim, int D,
+                                                              float temp, int mask_diag, float* __restrict__ probs,
+                                                              float* __restrict__ target) {
+    __shared__ float s_p[1024];
+    __shared__ float red[17];
+    const int r = blockIdx.x;
+    const float* e = en + (size_t)r * edim;
+    for (int j = threadIdx.x; j < n_base; j += blockDim.x) {
+        float acc = 0.f;
+        for (int k = 0; k < edim; ++k) acc = fmaf(e[k], eb[(size_t)j * edim + k], acc);
+        if (mask_diag && j == r) acc = -9999.f;                      // scores.fill_diagonal_(-9999), :80-81
+        s_p[j] = acc / temp;
+    }
+    __syncthreads();
+    float mx = -3.0e38f;
+    for (int j = threadIdx.x; j < n_base; j += blockDim.x) mx = fmaxf(mx, s_p[j]);
+    mx = block_max(mx, red);
+    float sum = 0.f;
+    for (int j = threadIdx.x; j < n_base; j += blockDim.x) {
+        const float ex = expf(s_p[j] - mx);
+        s_p[j] = ex;
+        sum += ex;
+    }
+    sum = block_sum(sum, red);
+    __syncthreads();
+    for (int j = threadIdx.x; j < n_base; j += blockDim.x) {
+        s_p[j] /= sum;
+        if (probs) probs[(size_t)r * n_base + j] = s_p[j];
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float acc = 0.f;
+        for (int j = 0; j < n_base; ++j) acc = fmaf(s_p[j], wb[(size_t)j * D + d], acc);
+        target[(size_t)r * D + d] = acc;
+    }
+}
+
+// d W_base = probs^T @ d target (the scores do not depend on W_base)
+__global__ void semantic_target_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ dt, int n_novel, int n_base,
+                                           int D, float* __restrict__ dwb) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_base * D) return;
+    const int d = i % D, j = i / D;
+    float acc = 0.f;
+    for (int r = 0; r < n_novel; ++r) acc = fmaf(probs[(size_t)r * n_base + j], dt[(size_t)r * D + d], acc);
+    dwb[i] = acc;
+}
+
 __global__ void loop_state_init_kernel(subreg_loop_state* st) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         st->epoch = 0; st->stop = 0; st->stable = 0; st->val_epoch = -1; st->train_loss = 15.f;   // language_eval.py:234-239
@@ -462,6 +536,25 @@ extern "C" int subreg_frob(const float* a, const float* b, long long n, float lm
     return launch_status();
 }
 
+extern "C" int subreg_semantic_target(const float* novel_embeds, const float* base_embeds, const float* base_weight, int n_novel,
+                                      int n_base, int embed_dim, int dim, float temperature, int mask_diagonal, float* probs,
+                                      float* target, void* stream) {
+    SUBREG_CHECK_ARG(novel_embeds && base_embeds && base_weight && target);
+    SUBREG_CHECK_ARG(n_novel > 0 && n_base > 0 && n_base <= 1024 && embed_dim > 0 && dim > 0 && temperature != 0.f);
+    hipLaunchKernelGGL(semantic_target_kernel, n_novel, 256, 0, (hipStream_t)stream, novel_embeds, base_embeds, base_weight, n_base,
+                       embed_dim, dim, temperature, mask_diagonal, probs, target);
+    return launch_status();
+}
+
+extern "C" int subreg_semantic_target_bwd(const float* probs, const float* grad_target, int n_novel, int n_base, int dim,
+                                          float* grad_base_weight, void* stream) {
+    SUBREG_CHECK_ARG(probs && grad_target && grad_base_weight && n_novel > 0 && n_base > 0 && dim > 0);
+    const size_t n = (size_t)n_base * dim;
+    hipLaunchKernelGGL(semantic_target_bwd_kernel, (unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream, probs, grad_target,
+                       n_novel, n_base, dim, grad_base_weight);
+    return launch_status();
+}
+
 extern "C" int subreg_loop_state_init(subreg_loop_state* state, void* stream) {
     SUBREG_CHECK_ARG(state);
     hipLaunchKernelGGL(loop_state_init_kernel, 1, 64, 0, (hipStream_t)stream, state);
@@ -475,10 +568,10 @@ extern "C" int subreg_finetune_step(const subreg_step_desc* d, void* stream) {
     SUBREG_CHECK_ARG(d->n_support + d->n_memory <= 2048 && d->n_base <= 256);
     SUBREG_CHECK_ARG(!d->use_base_reg || d->w_base);
     SUBREG_CHECK_ARG(!d->use_prev_reg || (d->w_prev && d->n_prev > 0));
-    SUBREG_CHECK_ARG(!d->use_pull || d->basis);
+    SUBREG_CHECK_ARG(!d->use_pull || d->basis || d->pull_target);
     StepArgs a;
     a.feat = d->feat; a.labels = d->labels; a.Bs = d->n_support; a.Bm = d->n_memory; a.N = d->n_classes; a.D = d->dim;
-    a.W = d->weight; a.mom = d->momentum_buf; a.Wbase = d->w_base; a.Wprev = d->w_prev; a.Q = d->basis;
+    a.W = d->weight; a.mom = d->momentum_buf; a.Wbase = d->w_base; a.Wprev = d->w_prev; a.Q = d->basis; a.target = d->pull_target;
     a.n_base = d->n_base; a.n_prev = d->n_prev; a.n_old = d->n_old;
     a.lr = d->lr; a.momentum = d->momentum; a.wd = d->weight_decay;
     a.lmbd_base = d->lmbd_base; a.lmbd_prev = d->lmbd_prev; a.pull = d->pull;

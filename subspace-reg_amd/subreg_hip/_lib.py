@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libsubreg_hip.so")
 F32, BF16 = 0, 1
 CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
 FWD_TRAIN = 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_void_p, c_int, c_float, c_longlong = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
@@ -67,7 +67,7 @@ class StepDesc(C.Structure):
                 ("dlogits", c_void_p), ("rowloss", c_void_p), ("rowcorrect", c_void_p), ("norms", c_void_p),
                 ("rowl1", c_void_p), ("state", c_void_p), ("losses", c_void_p), ("train_acc", c_void_p),
                 ("max_epochs", c_int), ("min_epochs", c_int), ("stable_epochs", c_int), ("stable_mode", c_int),
-                ("target_loss", c_float), ("convergence_eps", c_float)]
+                ("target_loss", c_float), ("convergence_eps", c_float), ("pull_target", c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/subreg_hip.h declares
@@ -88,6 +88,8 @@ SIGNATURES = {
     "subreg_pack_conv_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "subreg_conv_wgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "subreg_conv_wgrad_splits": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "subreg_semantic_target": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P]),
+    "subreg_semantic_target_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "subreg_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_bn_bwd_slices": (_I, [_L]),
     "subreg_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),

@@ -86,6 +86,36 @@ def subspace_basis(base_weight):
     return q, info
 
 
+class SemanticTargetFn(torch.autograd.Function):
+    """softmax(E_novel E_base^T / temp [diag := -9999]) @ W_base - LangPuller.forward, :75-83 (gradient to W_base)."""
+
+    @staticmethod
+    def forward(ctx, base_weight, novel_embeds, base_embeds, temp, mask):
+        lib = _lib.load()
+        wb, en, eb = _f32c(base_weight), _f32c(novel_embeds), _f32c(base_embeds)
+        assert en.shape[1] == eb.shape[1] and eb.shape[0] == wb.shape[0]
+        probs = torch.empty(en.shape[0], eb.shape[0], dtype=torch.float32, device=wb.device)
+        out = torch.empty(en.shape[0], wb.shape[1], dtype=torch.float32, device=wb.device)
+        _lib.check(lib.subreg_semantic_target(_lib.ptr(en), _lib.ptr(eb), _lib.ptr(wb), en.shape[0], eb.shape[0], en.shape[1],
+                                              wb.shape[1], float(temp), int(bool(mask)), _lib.ptr(probs), _lib.ptr(out),
+                                              _lib.stream_ptr()), "semantic_target")
+        ctx.save_for_backward(probs)
+        ctx.shape = tuple(wb.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (probs,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        lib = _lib.load()
+        g = _f32c(g)
+        gw = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        _lib.check(lib.subreg_semantic_target_bwd(_lib.ptr(probs), _lib.ptr(g), probs.shape[0], probs.shape[1], ctx.shape[1],
+                                                  _lib.ptr(gw), _lib.stream_ptr()), "semantic_target(bwd)")
+        return gw, None, None, None, None
+
+
 class SqDiffFn(torch.autograd.Function):
     """pull * ||inspired - weights||_F^2 - LangPuller.loss1, :89-90 (gradient to both arguments)."""
 

@@ -67,12 +67,17 @@ class IncrementalRunner:
     incremental EPISODE, the unit of BASELINE.json's metric; finish() = the final report (:451-454)."""
 
     def __init__(self, net, meta_valloader, base_val_loader, opt, base_support_loader=None, novel_inits=None,
-                 memory_picks=None, epochs_per_sync=8, reuse_features=False, verbose=True, profile=False, use_graph=True):
+                 memory_picks=None, epochs_per_sync=8, reuse_features=False, verbose=True, profile=False, use_graph=True,
+                 ckpt=None):
         if getattr(opt, "track_weights", False) or getattr(opt, "save_preds_0", False):
             raise NotImplementedError("CSV tracking is outside the hot path (SURVEY.md section 8)")
-        if getattr(opt, "label_pull", None) is not None and getattr(opt, "attraction_override", None) != "distance2subspace":
-            raise NotImplementedError("fused loop implements the distance2subspace regularizer "
-                                      "(scripts/continual/slurm_subspace_reg.sh); use the module surface for the others")
+        ao = getattr(opt, "attraction_override", None)
+        if getattr(opt, "label_pull", None) is not None and ao not in (None, "distance2subspace", "mapping_linear_label2image"):
+            raise NotImplementedError("attraction_override %r: the reference's loop knows None (semantic subspace reg), "
+                                      "'distance2subspace' and 'mapping_linear_label2image'" % (ao,))
+        if ao == "mapping_linear_label2image" and (ckpt is None or ao not in ckpt):
+            raise ValueError("mapping_linear_label2image needs ckpt['mapping_linear_label2image'] (language_eval.py:225-226)")
+        self.ckpt = ckpt
         if net.classifier.bias is not None:
             raise NotImplementedError("fused loop assumes --no_linear_bias backbones (slurm_run_backbone.sh:39)")
         if getattr(opt, "adam", False):
@@ -120,7 +125,13 @@ class IncrementalRunner:
         self.D = net.classifier.weight.shape[1]
         self.base_weight = net.classifier.weight.detach().clone()                # :106-107
         self.n_base = self.base_weight.shape[0]
-        self.basis, self.basis_info = (HF.subspace_basis(self.base_weight) if opt.label_pull is not None else (None, None))
+        # regularizer of the novel rows (:216-227, :277-290): projection onto span(W_base) ('distance2subspace', basis of the
+        # constant W_base computed once) or a per-session constant target from the word embeddings (LangPuller.forward)
+        self.pull_mode = None
+        if opt.label_pull is not None and getattr(opt, "pulling", "regularize") == "regularize":
+            self.pull_mode = "subspace" if getattr(opt, "attraction_override", None) == "distance2subspace" else "target"
+        self.basis, self.basis_info = (HF.subspace_basis(self.base_weight) if self.pull_mode == "subspace" else (None, None))
+        self.lang_puller, self.pullers = None, None
         self.meta_it = itertools.cycle(iter(self.meta_valloader))
         self.base_support_xs = self.base_support_ys = None
         if self.base_support_loader is not None:                                 # :112-116
@@ -153,6 +164,16 @@ class IncrementalRunner:
             vocab_base = prev_vb + prev_vn                                     # :166-167
         self.vocab_base, self.vocab_novel = vocab_base, vocab_novel
         n_old = len(vocab_base)
+        if self.pull_mode == "target":                                         # :218-227
+            from .resnet_language import LangPuller
+            if idx == 0:
+                self.lang_puller = LangPuller(opt, vocab_base, vocab_novel)
+            else:
+                self.lang_puller.update_novel_embeds(vocab_novel)
+            if getattr(opt, "attraction_override", None) == "mapping_linear_label2image":
+                self.lang_puller.create_pulling_mapping(self.ckpt[opt.attraction_override])
+            with torch.no_grad():
+                self.pullers = self.lang_puller(self.base_weight[:self.n_base]).contiguous()
         W = net.classifier.weight.detach()
         if idx == 1:                                                           # :172-185
             self.reserve = W[-opt.n_ways:].clone()
@@ -193,13 +214,14 @@ class IncrementalRunner:
         use_prev = opt.lmbd_reg_novel is not None and idx > 0
         d.w_prev = reserve.data_ptr() if use_prev else None
         d.basis = self.basis.data_ptr() if self.basis is not None else None
+        d.pull_target = self.pullers.data_ptr() if self.pull_mode == "target" else None
         d.n_base, d.n_prev, d.n_old = self.n_base, (reserve.shape[0] if use_prev else 0), n_old
         d.lr, d.momentum, d.weight_decay = opt.learning_rate, opt.momentum, opt.weight_decay
         d.lmbd_base = opt.lmbd_reg_transform_w or 0.0
         d.lmbd_prev = opt.lmbd_reg_novel or 0.0
         d.pull = opt.label_pull or 0.0
         d.use_base_reg = int(opt.lmbd_reg_transform_w is not None)
-        d.use_prev_reg, d.use_pull = int(use_prev), int(opt.label_pull is not None)
+        d.use_prev_reg, d.use_pull = int(use_prev), int(self.pull_mode is not None)
         d.dlogits, d.rowloss, d.rowcorrect = ses.dlogits.data_ptr(), ses.rowloss.data_ptr(), ses.rowcorrect.data_ptr()
         d.norms, d.rowl1, d.state = ses.norms.data_ptr(), ses.rowl1.data_ptr(), ses.state.data_ptr()
         d.losses, d.train_acc = ses.losses.data_ptr(), ses.train_acc.data_ptr()
@@ -316,12 +338,12 @@ def few_shot_finetune_incremental_test(net, ckpt, criterion, meta_valloader, bas
       memory_picks    list of np.random.choice(n_shots, memory_replay) results (else drawn from np.random)
       epochs_per_sync epochs queued per host synchronisation
       reuse_features  opt-in: compute the (constant) eval-mode features once per session
-    `ckpt` and `criterion` are accepted for signature compatibility (CrossEntropyLoss is fused into the step; the
-    non-continual branch never reads ckpt).  Returns (acc_novel.avg, acc_base.avg); details in net.last_run."""
+    `criterion` is accepted for signature compatibility (CrossEntropyLoss is fused into the step); `ckpt` is read only
+    for ckpt['mapping_linear_label2image'] (the LinearMap state_dict, language_eval.py:225-226).  Returns (acc_novel.avg, acc_base.avg); details in net.last_run."""
     if vis:
         raise NotImplementedError("visualisation is outside the hot path (SURVEY.md section 8)")
     r = IncrementalRunner(net, meta_valloader, base_val_loader, opt, base_support_loader, novel_inits, memory_picks,
-                          epochs_per_sync, reuse_features, verbose).start()
+                          epochs_per_sync, reuse_features, verbose, ckpt=ckpt).start()
     for idx in range(r.iter_num):
         r.run_session(idx)
     return r.finish()

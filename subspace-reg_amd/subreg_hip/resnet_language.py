@@ -91,15 +91,11 @@ class LangPuller(nn.Module):
         self.mapping_model = self.mapping_model.cuda()
 
     def forward(self, base_weight, mask=False):
-        """Semantic subspace regularizer target (:75-87).  SURVEY.md section 8f rank 3 ("next"): tiny
-        [5,60]x[60,640] products, still on torch ops."""
+        """Semantic subspace regularizer target (:75-87): one fused kernel (scores, softmax, @ W_base), or the linear
+        mapping of the novel embeddings (HIP linear kernel) when create_pulling_mapping was called."""
         self._load_embeds()
         if self.mapping_model is None:
-            scores = self.novel_embeds @ torch.transpose(self.base_embeds, 0, 1)
-            if mask:
-                scores.fill_diagonal_(-9999)
-            scores = torch.softmax(scores / self.temp, dim=1)
-            return scores @ base_weight
+            return HF.SemanticTargetFn.apply(base_weight, self.novel_embeds, self.base_embeds, self.temp, mask)
         with torch.no_grad():
             return self.mapping_model(self.novel_embeds)
 

@@ -132,3 +132,9 @@ def make_novel_inits(seed, n_sessions, n_ways=5, dim=640):
     rs = np.random.RandomState(seed + 900000)
     b = 1.0 / np.sqrt(dim)
     return [rs.uniform(-b, b, (n_ways, dim)).astype(np.float32) for _ in range(n_sessions)]
+
+
+def make_linear_map(seed, indim=500, outdim=640, scale=0.002):
+    """A synthetic LinearMap state (learn_mapping.py's product, ckpt['mapping_linear_label2image']): (map.weight, map.bias)."""
+    rs = np.random.RandomState(seed)
+    return (rs.standard_normal((outdim, indim)) * scale).astype(np.float32), (rs.standard_normal((outdim,)) * scale).astype(np.float32)

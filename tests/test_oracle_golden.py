@@ -148,16 +148,34 @@ def _loop_setup(g):
     base = syn.make_base_batch(seed, int(g["n_base_batch"]), hw, class_signal=signal)
     bsup = syn.make_base_support(seed, hw, class_signal=signal) if memory else None
     inits = syn.make_novel_inits(seed, ns)
+    if "attraction_override" in g.files:
+        ao = str(g["attraction_override"])
+        opt.attraction_override = None if ao == "None" else ao
+    else:
+        opt.attraction_override = "distance2subspace"
+    opt.word_embed_size = 500
+    opt.temperature = float(getattr(opt, "temperature", 1))
     return sd, opt, sessions, base, bsup, inits, int(g["mask_seed"]), [p for p in g["picks"]]
 
 
-@pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop"])
+def _embed_kwargs(g):
+    """embeds / names / mapping arguments of the semantic and linear-mapping loop goldens."""
+    if "embed.words" not in g.files:
+        return {}
+    kw = dict(embeds={str(w): v for w, v in zip(g["embed.words"], g["embed.vecs"])},
+              names=([str(n) for n in g["names_base"]], [str(n) for n in g["names_novel"]]))
+    if "mapping_seed" in g.files:
+        kw["mapping"] = syn.make_linear_map(int(g["mapping_seed"]))
+    return kw
+
+
+@pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw32_sem", "hw32_map"])
 def test_loop_against_reference(tag):
     g = _load("loop_%s.npz" % tag)
     sd, opt, sessions, base, bsup, inits, mseed, picks = _loop_setup(g)
     net = ResNetRef(sd)
     out = loop_ref.run_incremental(net, sessions, base, opt, inits, base_support=bsup,
-                                   masks=MaskSource(mseed), memory_picks=picks)
+                                   masks=MaskSource(mseed), memory_picks=picks, **_embed_kwargs(g))
     for s in range(len(sessions)):
         assert out["epochs"][s] == int(g["s%d.epochs" % s]), (s, out["epochs"], g["s%d.epochs" % s])
         _close(out["loss"][s], g["s%d.loss" % s], 2e-4, 2e-4, "loss s%d" % s)
@@ -207,3 +225,32 @@ def test_train_step_backward(hw):
     w = sd["classifier.weight"]
     p, _ = br.sgd_momentum_step(w.astype(np.float64), grads["classifier.weight"], None, 0.05, 0.9, 5e-4)
     _close(p, g[key + ".after_step.classifier.weight"], 1e-6, 1e-5, "sgd step")
+
+
+def test_semantic_regularizer_against_reference():
+    """LangPuller.forward (:75-87) in both modes, get_embeds (models/util.py:50-66), update_novel_embeds, loss1 on the result."""
+    g = _load("semantic.npz")
+    table = {str(w): v for w, v in zip(g["embed.words"], g["embed.vecs"])}
+    vb = [str(n) for n in g["vocab_base"]]
+    v0, v1 = [str(n) for n in g["vocab_novel0"]], [str(n) for n in g["vocab_novel1"]]
+    assert any(" " in n for n in vb + v0 + v1)                       # multi-word names exercise the mean
+    for temp in (1.0, 3.0):
+        key = "t%g" % temp
+        eb, e0, e1 = sr.get_embeds(table, vb), sr.get_embeds(table, v0), sr.get_embeds(table, v1)
+        _close(eb, g[key + ".E_base"], 1e-6, 1e-6, "E_base")
+        _close(e0, g[key + ".E_novel0"], 1e-6, 1e-6, "E_novel0")
+        _close(e1, g[key + ".E_novel1"], 1e-6, 1e-6, "E_novel1")
+        t0, p0 = sr.semantic_target(e0, eb, g["w_base"], temp)
+        _close(t0, g[key + ".pullers0"], 1e-5, 1e-5, "pullers0")
+        _close(p0.T @ g[key + ".grad_out"].astype(np.float64), g[key + ".grad_w_base"], 1e-5, 1e-5, "d W_base")
+        _close(sr.semantic_target(e0, eb, g["w_base"], temp, mask=True)[0], g[key + ".pullers0_masked"], 1e-5, 1e-5, "masked")
+        _close(sr.semantic_target(e1, eb, g["w_base"], temp)[0], g[key + ".pullers1"], 1e-5, 1e-5, "pullers1")
+        loss, grad = sr.loss1_to_target_and_grad(0.7, t0, g[key + ".w"])
+        _close(loss, g[key + ".loss1"], 1e-5, 1e-5, "loss1")
+        _close(grad, g[key + ".loss1_grad"], 1e-5, 1e-5, "loss1 grad")
+    _close(sr.linear_map_target(sr.get_embeds(table, v0), g["map.weight"], g["map.bias"]), g["map.pullers0"], 1e-5, 1e-5, "mapping")
+    # the unknown-word quirk of get_embeds: the running sum is reset, later words still count, divisor = all words
+    known = sorted(table)[0]
+    e = sr.get_embeds(table, ["%s notaword %s" % (known, known), "notaword"])
+    _close(e[0], table[known] / 3.0, 1e-6, 1e-6, "unknown word resets the sum")
+    assert not e[1].any()

@@ -266,7 +266,72 @@ def ncm_classifier(net, hw, signal, per_class=8):
     return w.astype(np.float32)
 
 
-def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, **optkw):
+def embed_table():
+    """The reference's own word vectors (word_embeds/miniImageNet_dim500.pickle, read-only data file)."""
+    import pickle
+    with open(os.path.join(REF, "word_embeds", "miniImageNet_dim500.pickle"), "rb") as f:
+        return pickle.load(f)
+
+
+def class_names(seed):
+    """Synthetic label2human lists over the reference's vocabulary: 60 base names (+40 blanks, like the base loader of
+    mini_imagenet.py:127-136) and 100 novel names, one to three words each."""
+    words = sorted(embed_table().keys())
+    rs = np.random.RandomState(seed)
+
+    def name():
+        return " ".join(rs.choice(words, size=rs.randint(1, 4), replace=False))
+    return [name() for _ in range(60)] + [""] * 40, [name() for _ in range(100)]
+
+
+def table_arrays(out):
+    t = embed_table()
+    words = sorted(t.keys())
+    out["embed.words"] = np.array(words)
+    out["embed.vecs"] = np.stack([np.asarray(t[w], np.float32) for w in words], 0)
+
+
+def gen_semantic():
+    """LangPuller.forward in its two modes + update_novel_embeds + loss1 on the result (resnet_language.py:20-90)."""
+    rs = np.random.RandomState(91)
+    out = {}
+    table_arrays(out)
+    names_base, names_novel = class_names(92)
+    vocab_base = [n for n in names_base if n != ""]
+    sess = [names_novel[0:5], names_novel[5:10]]
+    out["vocab_base"], out["vocab_novel0"], out["vocab_novel1"] = np.array(vocab_base), np.array(sess[0]), np.array(sess[1])
+    wb = (rs.standard_normal((60, 640)) * 0.05).astype(np.float32)
+    out["w_base"] = wb
+    for temp in (1.0, 3.0):
+        opt = ref_opt(attraction_override=None, temperature=temp)
+        puller = rl.LangPuller(opt, vocab_base, sess[0])
+        key = "t%g" % temp
+        out[key + ".E_base"], out[key + ".E_novel0"] = t2n(puller.base_embeds), t2n(puller.novel_embeds)
+        wbt = torch.from_numpy(wb).requires_grad_(True)
+        pl = puller(wbt)
+        out[key + ".pullers0"] = t2n(pl)
+        go = torch.from_numpy(rs.standard_normal((5, 640)).astype(np.float32))
+        pl.backward(go)
+        out[key + ".grad_out"], out[key + ".grad_w_base"] = t2n(go), t2n(wbt.grad)
+        out[key + ".pullers0_masked"] = t2n(puller(torch.from_numpy(wb), mask=True))
+        w = torch.from_numpy((rs.standard_normal((5, 640)) * 0.04).astype(np.float32)).requires_grad_(True)
+        loss = puller.loss1(0.7, puller(torch.from_numpy(wb)), w)
+        loss.backward()
+        out[key + ".w"], out[key + ".loss1"], out[key + ".loss1_grad"] = t2n(w), t2n(loss), t2n(w.grad)
+        puller.update_novel_embeds(sess[1])
+        out[key + ".E_novel1"], out[key + ".pullers1"] = t2n(puller.novel_embeds), t2n(puller(torch.from_numpy(wb)))
+    # linear-mapping variant
+    opt = ref_opt(attraction_override="mapping_linear_label2image")
+    puller = rl.LangPuller(opt, vocab_base, sess[0])
+    mw = (rs.standard_normal((640, 500)) * 0.02).astype(np.float32)
+    mb = (rs.standard_normal((640,)) * 0.02).astype(np.float32)
+    puller.create_pulling_mapping({"map.weight": torch.from_numpy(mw), "map.bias": torch.from_numpy(mb)})
+    out["map.weight"], out["map.bias"], out["map.pullers0"] = mw, mb, t2n(puller(torch.from_numpy(wb)))
+    np.savez_compressed(os.path.join(GOLD, "semantic.npz"), **out)
+    print("semantic.npz", sum(v.nbytes for v in out.values()) / 1e6, "MB")
+
+
+def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False, mapping_seed=None, **optkw):
     opt = ref_opt(set_seed=seed, neval_episodes=n_sessions, memory_replay=1 if memory else 0, **optkw)
     signal = 3.0
     sd = syn.make_state_dict(21 + seed)
@@ -281,6 +346,12 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, **optkw):
     inits = syn.make_novel_inits(seed, n_sessions)
     names_base = ["b%d" % i for i in range(60)] + [""] * 40
     names_novel = ["n%d" % i for i in range(100)]
+    ckpt = {}
+    if real_names:                               # semantic / mapping variants read the class names' word vectors
+        names_base, names_novel = class_names(200 + seed)
+    if mapping_seed is not None:
+        mw, mb = syn.make_linear_map(mapping_seed)
+        ckpt = {"mapping_linear_label2image": {"map.weight": torch.from_numpy(mw), "map.bias": torch.from_numpy(mb)}}
     base_loader = _Loader([(torch.from_numpy(base_x), torch.from_numpy(base_y), torch.arange(len(base_y)))], names_base)
     meta = _Loader([(torch.from_numpy(s["support_xs"])[None], torch.from_numpy(s["support_ys"])[None],
                      torch.from_numpy(s["query_xs"])[None], torch.from_numpy(s["query_ys"])[None]) for s in sessions],
@@ -324,7 +395,7 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, **optkw):
     set_masks(61 + seed)
     t0 = time.time()
     try:
-        novel_avg, base_avg = le.few_shot_finetune_incremental_test(net, {}, crit, meta, base_loader, opt,
+        novel_avg, base_avg = le.few_shot_finetune_incremental_test(net, ckpt, crit, meta, base_loader, opt,
                                                                     vis=False, base_support_loader=bsl)
     finally:
         le.validate, np.random.choice, torch.Tensor.backward = orig_validate, orig_choice, orig_backward
@@ -335,7 +406,14 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, **optkw):
                final_classifier=t2n(net.classifier.weight), novel_avg=np.array(novel_avg), base_avg=np.array(base_avg),
                picks=np.array([p.reshape(-1) for p in rec["picks"]]) if rec["picks"] else np.zeros((0, 1), np.int64))
     for k, v in optkw.items():
-        out["opt." + k] = np.array(v)
+        if v is not None:
+            out["opt." + k] = np.array(v)
+    out["attraction_override"] = np.array(str(opt.attraction_override))
+    if real_names:
+        table_arrays(out)
+        out["names_base"], out["names_novel"] = np.array(names_base), np.array(names_novel)
+    if mapping_seed is not None:
+        out["mapping_seed"] = np.array(mapping_seed)          # weights = subreg_hip.synthetic.make_linear_map(seed)
     for k, v in bn0.items():
         out["bn0." + k] = v
     for s in range(n_sessions):
@@ -394,7 +472,7 @@ def gen_train_step():
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["blocks", "backbone", "reg", "train", "loop32", "loop84"]
+    what = sys.argv[1:] or ["blocks", "backbone", "reg", "train", "loop32", "semantic", "loop84"]
     if "blocks" in what:
         gen_blocks()
     if "backbone" in what:
@@ -409,6 +487,12 @@ def main():
         # data-dependent stop: loose epsilon + short stable window so the stable rule fires before the cap
         gen_loop("hw32_stop", 32, 2, True, 40, seed=3, max_novel_epochs=40, stable_epochs=3,
                  convergence_epsilon=2e-2)
+    if "semantic" in what:
+        gen_semantic()
+        gen_loop("hw32_sem", 32, 3, True, 40, seed=5, max_novel_epochs=4, real_names=True, attraction_override=None,
+                 temperature=3.0)
+        gen_loop("hw32_map", 32, 2, False, 40, seed=6, max_novel_epochs=4, real_names=True, mapping_seed=77,
+                 attraction_override="mapping_linear_label2image")
     if "loop84" in what:
         gen_loop("hw84_M", 84, 3, True, 40, seed=4, max_novel_epochs=4)
 
