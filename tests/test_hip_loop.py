@@ -44,12 +44,27 @@ def make_opt(**kw):
     return o
 
 
-def build_case(g, dtype):
+def write_embed_pickle(g, dirpath):
+    """The word vectors a semantic / mapping golden was generated with, as the pickle LangPuller reads
+    (<word_embed_path>/<dataset>_dim<size>.pickle, resnet_language.py:31)."""
+    import pickle
+    os.makedirs(dirpath, exist_ok=True)
+    with open(os.path.join(dirpath, "miniImageNet_dim500.pickle"), "wb") as f:
+        pickle.dump({str(w): np.asarray(v) for w, v in zip(g["embed.words"], g["embed.vecs"])}, f)
+    return dirpath
+
+
+def build_case(g, dtype, embed_dir=None):
     """Model + loaders of a loop golden (inputs regenerated from seeds, BN stats / classifier from the fixture)."""
     from subreg_hip.resnet_language import create_model
     hw, ns, seed = int(g["hw"]), int(g["n_sessions"]), int(g["seed"])
     signal, memory = float(g["signal"]), bool(int(g["memory"]))
     kw = {k[4:]: g[k].item() for k in g.files if k.startswith("opt.")}
+    if "attraction_override" in g.files:
+        ao = str(g["attraction_override"])
+        kw["attraction_override"] = None if ao == "None" else ao
+    if "embed.words" in g.files:
+        kw["word_embed_path"] = write_embed_pickle(g, embed_dir)
     opt = make_opt(set_seed=seed, neval_episodes=ns, memory_replay=1 if memory else 0, hip_dtype=dtype, **kw)
     sd = syn.make_state_dict(int(g["sd_seed"]))
     for k in g.files:
@@ -64,6 +79,8 @@ def build_case(g, dtype):
     bx, by = syn.make_base_batch(seed, int(g["n_base_batch"]), hw, class_signal=signal)
     names_base = ["b%d" % i for i in range(60)] + [""] * 40
     names_novel = ["n%d" % i for i in range(100)]
+    if "names_base" in g.files:
+        names_base, names_novel = [str(n) for n in g["names_base"]], [str(n) for n in g["names_novel"]]
     base_loader = _Loader([(torch.from_numpy(bx), torch.from_numpy(by), torch.arange(len(by)))], names_base)
     meta = _Loader([(torch.from_numpy(s["support_xs"])[None], torch.from_numpy(s["support_ys"])[None],
                      torch.from_numpy(s["query_xs"])[None], torch.from_numpy(s["query_ys"])[None]) for s in sessions],
@@ -79,12 +96,16 @@ def build_case(g, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw84_M"])
-def test_fused_loop_against_reference_golden(tag, dtype):
+@pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw84_M", "hw32_sem", "hw32_map"])
+def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
     from subreg_hip.incremental import few_shot_finetune_incremental_test
     g = np.load(os.path.join(GOLDEN, "loop_%s.npz" % tag))
-    net, opt, meta, base_loader, bsl, inits, picks = build_case(g, dtype)
-    novel_avg, base_avg = few_shot_finetune_incremental_test(net, {}, None, meta, base_loader, opt, base_support_loader=bsl,
+    net, opt, meta, base_loader, bsl, inits, picks = build_case(g, dtype, str(tmp_path / "word_embeds"))
+    ckpt = {}
+    if "mapping_seed" in g.files:                    # ckpt['mapping_linear_label2image'] = LinearMap state_dict (:225-226)
+        mw, mb = syn.make_linear_map(int(g["mapping_seed"]))
+        ckpt = {"mapping_linear_label2image": {"map.weight": torch.from_numpy(mw), "map.bias": torch.from_numpy(mb)}}
+    novel_avg, base_avg = few_shot_finetune_incremental_test(net, ckpt, None, meta, base_loader, opt, base_support_loader=bsl,
                                                              novel_inits=inits, memory_picks=picks, epochs_per_sync=4,
                                                              verbose=False)
     run = net.last_run
@@ -165,3 +186,34 @@ def test_module_surface_runs_reference_loop_body():
             accs.append((out.argmax(1) == query_ys_id).float().sum().item() * (100.0 / len(query_ys_id)))
     _cmp("module-surface loss", losses, g["s0.loss"], 2e-4, 2e-4)
     _cmp("module-surface acc", round(accs[-1], 2), np.round(g["s0.last_val"], 2)[0], 1e-6, 0)
+
+
+def test_semantic_regularizer_module_against_reference_golden(tmp_path):
+    """LangPuller.forward on the fused HIP kernel (+ autograd to W_base), update_novel_embeds, the mapping variant, loss1."""
+    from subreg_hip.resnet_language import LangPuller
+    g = np.load(os.path.join(GOLDEN, "semantic.npz"))
+    path = write_embed_pickle(g, str(tmp_path / "word_embeds"))
+    vb = [str(n) for n in g["vocab_base"]]
+    v0, v1 = [str(n) for n in g["vocab_novel0"]], [str(n) for n in g["vocab_novel1"]]
+    wb = torch.from_numpy(g["w_base"]).cuda()
+    for temp in (1.0, 3.0):
+        key = "t%g" % temp
+        opt = make_opt(attraction_override=None, temperature=temp, word_embed_path=path)
+        puller = LangPuller(opt, vb, v0)
+        wbt = wb.clone().requires_grad_(True)
+        pl = puller(wbt)
+        _cmp("pullers0", pl.detach().cpu().numpy(), g[key + ".pullers0"], 1e-5, 1e-4)
+        pl.backward(torch.from_numpy(g[key + ".grad_out"]).cuda())
+        _cmp("d W_base", wbt.grad.cpu().numpy(), g[key + ".grad_w_base"], 1e-5, 1e-4)
+        _cmp("masked", puller(wb, mask=True).cpu().numpy(), g[key + ".pullers0_masked"], 1e-5, 1e-4)
+        w = torch.from_numpy(g[key + ".w"]).cuda().requires_grad_(True)
+        loss = puller.loss1(0.7, puller(wb), w)
+        loss.backward()
+        _cmp("loss1", loss.item(), g[key + ".loss1"], 1e-5, 1e-4)
+        _cmp("loss1 grad", w.grad.cpu().numpy(), g[key + ".loss1_grad"], 1e-5, 1e-4)
+        puller.update_novel_embeds(v1)
+        _cmp("pullers1", puller(wb).cpu().numpy(), g[key + ".pullers1"], 1e-5, 1e-4)
+    opt = make_opt(attraction_override="mapping_linear_label2image", word_embed_path=path)
+    puller = LangPuller(opt, vb, v0)
+    puller.create_pulling_mapping({"map.weight": torch.from_numpy(g["map.weight"]), "map.bias": torch.from_numpy(g["map.bias"])})
+    _cmp("mapping pullers", puller(wb).cpu().numpy(), g["map.pullers0"], 1e-5, 1e-4)
