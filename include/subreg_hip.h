@@ -263,6 +263,11 @@ typedef struct subreg_step_desc {
                                * regularizer / linear mapping, LangPuller.forward :75-87), or NULL: project onto `basis` */
 } subreg_step_desc;
 
+/* nn.CrossEntropyLoss() (mean) + eval/util.py:26-40 accuracy counters of one batch: rowloss[B] (scratch, required with
+ * loss), loss[1] = mean, dlogits[B][N] = (softmax - onehot)/B, correct[0] += #(label is the argmax),
+ * correct[1] += #(label within the topk largest).  Every output pointer may be NULL. */
+int subreg_softmax_ce(const float* logits, const long long* labels, int B, int N, int topk, float* rowloss, float* loss,
+                      float* dlogits, int* correct, void* stream);
 /* LangPuller.forward, resnet_language.py:75-83 (semantic subspace regularizer): target[n_novel][dim] =
  * softmax(novel_embeds[n_novel][embed_dim] base_embeds[n_base][embed_dim]^T / temperature, dim=1) @ base_weight[n_base][dim];
  * mask_diagonal: scores.fill_diagonal_(-9999) first (:80-81).  probs [n_novel][n_base] (optional) feeds the backward

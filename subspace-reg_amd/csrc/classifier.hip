@@ -424,6 +424,51 @@ __global__ void validate_mark_kernel(subreg_loop_state* st) {
     if (threadIdx.x == 0 && blockIdx.x == 0) st->val_epoch = st->epoch;
 }
 
+// ---------------------------------------------------------------- CrossEntropyLoss(mean) + top-1 / top-k counters
+// One wave per row: row loss, dlogits = (softmax - onehot) / B, and whether the label is the argmax / within the k largest
+// (eval/util.py:26-40 `accuracy`: rank = logits strictly greater, ties broken towards the lower index).
+__global__ __launch_bounds__(64) void softmax_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ labels, int B,
+                                                        int N, int k, float* __restrict__ rowloss, float* __restrict__ dlogits,
+                                                        int* __restrict__ correct) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* z = logits + (size_t)b * N;
+    const int y = (int)labels[b];
+    float mx = -3.0e38f;
+    for (int n = lane; n < N; n += 64) mx = fmaxf(mx, z[n]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float se = 0.f;
+    int rank = 0;
+    const float zy = z[y];
+    for (int n = lane; n < N; n += 64) {
+        se += expf(z[n] - mx);
+        rank += (z[n] > zy || (z[n] == zy && n < y)) ? 1 : 0;
+    }
+    se = wave_sum(se);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rank += __shfl_xor(rank, o);
+    const float lse = logf(se);
+    if (dlogits) {
+        const float inv = 1.f / (float)B;
+        for (int n = lane; n < N; n += 64) dlogits[(size_t)b * N + n] = (expf(z[n] - mx - lse) - (n == y ? 1.f : 0.f)) * inv;
+    }
+    if (lane == 0) {
+        if (rowloss) rowloss[b] = -(zy - mx - lse);
+        if (correct) {
+            if (rank == 0) atomicAdd(&correct[0], 1);
+            if (rank < k) atomicAdd(&correct[1], 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+    __shared__ double red[17];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)x[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = (float)(s / (double)n);
+}
+
 // ---------------------------------------------------------------- semantic subspace regularizer target
 // LangPuller.forward, models/resnet_language.py:75-83: scores = E_novel E_base^T (optionally diagonal := -9999),
 // probs = softmax(scores / temp, dim=1), target = probs @ W_base.  One block per novel row; n_base <= 1024.
@@ -533,6 +578,15 @@ extern "C" int subreg_frob(const float* a, const float* b, long long n, float lm
                            float* grad_a, void* stream) {
     SUBREG_CHECK_ARG(a && b && n > 0);
     hipLaunchKernelGGL(frob_kernel, 1, 1024, 0, (hipStream_t)stream, a, b, n, lmbd, loss, grad_out, grad_a);
+    return launch_status();
+}
+
+extern "C" int subreg_softmax_ce(const float* logits, const long long* labels, int B, int N, int topk, float* rowloss, float* loss,
+                                 float* dlogits, int* correct, void* stream) {
+    SUBREG_CHECK_ARG(logits && labels && B > 0 && N > 0 && topk >= 1 && (!loss || rowloss));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(softmax_ce_kernel, B, 64, 0, s, logits, labels, B, N, topk, rowloss, dlogits, correct);
+    if (loss) hipLaunchKernelGGL(mean_kernel, 1, 256, 0, s, rowloss, B, loss);
     return launch_status();
 }
 

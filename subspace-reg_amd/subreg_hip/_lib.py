@@ -88,6 +88,7 @@ SIGNATURES = {
     "subreg_pack_conv_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "subreg_conv_wgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "subreg_conv_wgrad_splits": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "subreg_softmax_ce": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "subreg_semantic_target": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P]),
     "subreg_semantic_target_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "subreg_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

@@ -86,6 +86,34 @@ def subspace_basis(base_weight):
     return q, info
 
 
+class CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss() with mean reduction (train_supervised.py:138, language_eval.py:252); `counters` (optional
+    int32[2] tensor) receives the batch's top-1 / top-5 hit counts in the same launch."""
+
+    @staticmethod
+    def forward(ctx, logits, target, counters=None, topk=5):
+        lib = _lib.load()
+        z = _f32c(logits)
+        t = target.to(torch.int64).contiguous()
+        B, N = z.shape
+        rowloss = torch.empty(B, dtype=torch.float32, device=z.device)
+        loss = torch.empty(1, dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z)
+        _lib.check(lib.subreg_softmax_ce(_lib.ptr(z), _lib.ptr(t), B, N, int(topk), _lib.ptr(rowloss), _lib.ptr(loss), _lib.ptr(dz),
+                                         _lib.ptr(counters), _lib.stream_ptr()), "softmax_ce")
+        ctx.save_for_backward(dz)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return dz * g, None, None, None
+
+
+def cross_entropy(logits, target, counters=None, topk=5):
+    return CrossEntropyFn.apply(logits, target, counters, topk)
+
+
 class SemanticTargetFn(torch.autograd.Function):
     """softmax(E_novel E_base^T / temp [diag := -9999]) @ W_base - LangPuller.forward, :75-83 (gradient to W_base)."""
 

@@ -143,8 +143,18 @@ class SGD:
 
     def __init__(self, params, lr, momentum=0.0, weight_decay=0.0):
         self.params = [p for p in params]
-        self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        self.momentum, self.weight_decay = momentum, weight_decay
+        # one param group, torch-style: adjust_learning_rate (util.py:45-51) writes param_groups[i]['lr']
+        self.param_groups = [{"params": self.params, "lr": lr}]
         self.bufs = [None] * len(self.params)
+
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, v):
+        self.param_groups[0]["lr"] = v
 
     def zero_grad(self):
         for p in self.params:

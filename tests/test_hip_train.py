@@ -7,6 +7,7 @@ B*H*W pixels in fp32), BN/activation gradients 2e-4; bf16 mode - 5e-2 of the ten
 gradient tensors are rounded to bf16 between layers) on the gradient norms and the sampled tensors.
 """
 import os
+from types import SimpleNamespace
 
 import numpy as np
 import pytest
@@ -188,3 +189,59 @@ def test_train_step_against_reference_autograd(hw, dtype):
         _cmp("sgd classifier", net.classifier.weight.detach().cpu().numpy(), g[key + ".after_step.classifier.weight"], 2e-5, 1e-4)
         _cmp("sgd conv1", dict(net.named_parameters())["layer1.0.conv1.weight"].detach().cpu().numpy(),
              g[key + ".after_step.layer1.0.conv1.weight"], 1e-3, 1e-3)    # lr 0.05 x the kink-event gradient perturbation
+
+
+def test_softmax_ce_kernel_matches_torch_and_reference_accuracy():
+    """nn.CrossEntropyLoss() (mean) + eval/util.py:26-40 top-1/top-5 in one launch, and its autograd."""
+    from subreg_hip import functional as HF
+    rs = np.random.RandomState(5)
+    for B, N in ((64, 60), (7, 100), (128, 351), (3, 5)):
+        z = torch.from_numpy(rs.standard_normal((B, N)).astype(np.float32) * 3).cuda().requires_grad_(True)
+        y = torch.from_numpy(rs.randint(0, N, size=B)).cuda()
+        cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+        loss = HF.cross_entropy(z, y, cnt, 5)
+        (loss * 1.7).backward()
+        zr = z.detach().clone().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(zr, y)
+        (ref * 1.7).backward()
+        _cmp("ce loss", loss.item(), ref.item(), 1e-5, 1e-5)
+        _cmp("ce grad", z.grad.cpu().numpy(), zr.grad.cpu().numpy(), 1e-6, 1e-4)
+        _, pred = zr.detach().topk(min(5, N), 1, True, True)                  # the reference's accuracy()
+        correct = pred.t().eq(y.view(1, -1).expand_as(pred.t()))
+        assert cnt.tolist() == [int(correct[:1].sum()), int(correct[:5].sum())], (B, N, cnt.tolist())
+
+
+def test_pretrain_driver_runs_the_reference_routine(tmp_path):
+    """train_supervised.py:150-202 over the HIP train step: LR schedule applied, loss falls on a small fixed batch set,
+    periodic + last checkpoints are written in the reference's format and reload into an identical model."""
+    import argparse
+    from subreg_hip import checkpoint as ck, pretrain as pt
+    from subreg_hip.resnet_language import create_model
+    opt = argparse.Namespace(no_dropblock=True, linear_bias=False, hip_dtype="bf16", model="resnet18", learning_rate=0.004,
+                             momentum=0.9, weight_decay=5e-4, lr_decay_epochs=[4], lr_decay_rate=0.1, epochs=5, cosine=False,
+                             print_freq=100, save_freq=2, model_path=str(tmp_path / "models"), continual=True, adam=False,
+                             label_pull=None, eval_only=False, dataset="miniImageNet")
+    torch.manual_seed(0)
+    net = create_model("resnet18", 10, opt)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in syn.make_state_dict(3, n_cls=10, randomize_bn=False).items()})
+    net = net.cuda()
+    rs = np.random.RandomState(2)
+    ys = [torch.from_numpy(rs.randint(0, 10, size=16)) for _ in range(3)]
+    batches = [(torch.from_numpy((rs.standard_normal((16, 3, 32, 32)) + y.numpy()[:, None, None, None] * 0.5).astype(np.float32)), y,
+                torch.arange(16)) for y in ys]
+
+    class _DS(list):
+        dataset = SimpleNamespace(basec_map={i: i for i in range(10)}, label2human=["c%d" % i for i in range(10)])
+    loader = _DS(batches)
+    hist = pt.fit(net, opt, loader, val_loader=loader, log=lambda *a: None)
+    assert [round(h["lr"], 6) for h in hist] == [0.004] * 4 + [0.0004]          # milestone 4 passes at epoch 5 (strictly greater)
+    assert all(np.isfinite(h["train_loss"]) and np.isfinite(h["test_loss"]) for h in hist)
+    assert hist[-1]["train_loss"] < hist[0]["train_loss"]
+    assert 0.0 <= hist[-1]["test_acc"] <= hist[-1]["test_acc_top5"] <= 100.0
+    files = sorted(os.listdir(opt.model_path))
+    assert files == ["ckpt_epoch_2.pth", "ckpt_epoch_4.pth", "resnet18_last.pth"]
+    last = ck.load_checkpoint(os.path.join(opt.model_path, "resnet18_last.pth"))
+    assert sorted(last.keys()) == ["label2human", "model", "opt", "training_classes"]
+    net2 = ck.model_from_checkpoint(last, "resnet18", 10, argparse.Namespace(no_dropblock=True, hip_dtype="bf16")).cuda()
+    for (k, a), (_k, b) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert torch.equal(a, b), k

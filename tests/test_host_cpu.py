@@ -140,3 +140,32 @@ def test_checkpoint_round_trip_in_reference_format(tmp_path):
     with pytest.raises(KeyError):
         torch.save({"opt": opt}, str(tmp_path / "bad.pth"))
         ck.load_checkpoint(str(tmp_path / "bad.pth"))
+
+
+def test_pretrain_lr_schedules_match_torch_and_reference_rule():
+    """util.py:45-51 step decay and train_supervised.py:146-157 cosine schedule (torch's CosineAnnealingLR, stepped first)."""
+    import torch
+    from types import SimpleNamespace
+    from subreg_hip import pretrain as pt
+    opt = SimpleNamespace(learning_rate=0.05, lr_decay_rate=0.1, lr_decay_epochs=[60, 80], epochs=100, cosine=False)
+    o = SimpleNamespace(param_groups=[{"lr": 0.05}])
+    lrs = []
+    for e in range(1, 101):
+        pt.set_epoch_lr(e, opt, o)
+        lrs.append(o.param_groups[0]["lr"])
+    assert lrs[59] == 0.05 and abs(lrs[60] - 0.005) < 1e-12 and abs(lrs[79] - 0.005) < 1e-12 and abs(lrs[80] - 0.0005) < 1e-12
+    opt.cosine = True
+    p = torch.nn.Parameter(torch.zeros(1))
+    ref_opt = torch.optim.SGD([p], lr=opt.learning_rate)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(ref_opt, opt.epochs, opt.learning_rate * opt.lr_decay_rate ** 3, -1)
+    for e in range(1, 101):
+        ref_opt.step()
+        sched.step()
+        pt.set_epoch_lr(e, opt, o)
+        assert abs(o.param_groups[0]["lr"] - ref_opt.param_groups[0]["lr"]) < 1e-9, e
+    m = pt.AverageMeter()
+    m.update(2.0, 3)
+    m.update(4.0, 1)
+    assert m.avg == 2.5 and m.val == 4.0 and m.count == 4
+    x, y = torch.arange(10)[:, None], torch.arange(10)
+    assert [pt.shard_batch(x, y, r, 4)[1].tolist() for r in range(4)] == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9]]

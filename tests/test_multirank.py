@@ -48,3 +48,41 @@ def test_seed_assignment_and_makespan():
     assert [len(x) for x in a] == [2, 2, 1, 1, 1, 1, 1, 1]
     assert sweep.makespan_units(10, 8) == 2 and sweep.makespan_units(10, 1) == 10 and sweep.makespan_units(8, 8) == 1
     assert sweep.max_over_ranks(3.5) == 3.5 and sweep.gather_results("x") == ["x"]   # single-process degenerate forms
+
+
+def _grad_worker(rank, world, port, q):
+    """Pretraining's data-parallel step on 2 ranks: the backbone's gradients are views of ONE flat buffer (as
+    train.BackboneTrainFn.backward hands them to autograd), the classifier's is a tensor of its own."""
+    from subreg_hip import pretrain as pt
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    ps = [torch.nn.Parameter(torch.zeros(2, 3)), torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(5))]
+    ps[0].grad, ps[1].grad = flat[0:6].view(2, 3), flat[6:10].view(4)
+    ps[2].grad = torch.full((5,), float(rank))
+    frozen = torch.nn.Parameter(torch.zeros(3))               # no gradient: skipped
+    sync = pt.GradientAverager()
+    sync(ps + [frozen])
+    x, y = pt.shard_batch(torch.arange(8)[:, None], torch.arange(8), rank, world)
+    if rank == 0:
+        q.put((sync.calls, ps[0].grad.tolist(), ps[1].grad.tolist(), ps[2].grad.tolist(), y.tolist()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_averaging_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    calls, g0, g1, g2, y = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert calls == 2                                         # one collective for the flat buffer, one for the classifier
+    assert g0 == [[0.0, 1.5, 3.0], [4.5, 6.0, 7.5]] and g1 == [9.0, 10.5, 12.0, 13.5]     # mean of 1x and 2x arange
+    assert g2 == [0.5] * 5 and y == [0, 1, 2, 3]
