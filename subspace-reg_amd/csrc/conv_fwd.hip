@@ -44,6 +44,11 @@
 #define SUBREG_WRING3 0          // 1: weight tiles staged two steps ahead (3 buffers): 0 % on 64x160 wave tiles, -15 % on
                                  // the 128-row tiles (one workgroup fewer per CU)
 #endif
+#ifndef SUBREG_MIXED_TILES
+#define SUBREG_MIXED_TILES 0     // 1: split a wide layer into a 256-row-tile launch + a 128-row-tile launch for the tail rows
+                                 // (per-CU tile-count model of the tail): -3 % - the dispatcher already back-fills uneven
+                                 // rounds and the second launch waits for the first to drain
+#endif
 #ifndef SUBREG_TM512
 #define SUBREG_TM512 0           // 1: 512-row, 8-wave workgroups for the big wide layers: -10..20 % at 42x42 / 21x21
 #endif
@@ -78,6 +83,7 @@ struct ConvArgs {
     int Cin, Cin2, Cout;
     int act;             // LeakyReLU(0.1) after scale/shift/residual
     int raw;             // write the un-normalised conv + stats partials
+    int m_base, m_rows;  // this launch covers GEMM rows [m_base, m_base + m_rows) (a layer may be split over two tilings)
 };
 
 // Depth of the weight-tile ring.  The L2 -> LDS latency of a tile under load (1300+ cycles by in-kernel stamps) exceeds
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
         vtile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
     }
     const int mtile = vtile / ntn;
-    const int m0 = mtile * TM, n0 = (vtile % ntn) * TN;
+    const int m0 = a.m_base + mtile * TM, n0 = (vtile % ntn) * TN;
 
     int plo, phi;
     patch_range<POOL>(g, m0, TM, &plo, &phi);
@@ -607,9 +613,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
 
 // ---------------------------------------------------------------------------- host side
 template <bool POOL>
-static int worst_patch_rows(const ConvGeom& g, int TM) {
+static int worst_patch_rows(const ConvGeom& g, int TM, int m_base, int m_rows) {
     int worst = 0;
-    for (int m0 = 0; m0 < g.M; m0 += TM) {
+    for (int m0 = m_base; m0 < m_base + m_rows; m0 += TM) {
         int lo, hi;
         patch_range<POOL>(g, m0, TM, &lo, &hi);
         if (hi - lo > worst) worst = hi - lo;
@@ -631,7 +637,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
             return SUBREG_EHIP;
         attr_done = true;
     }
-    dim3 grid(((a.g.M + TM - 1) / TM) * ((a.Cout + TN - 1) / TN));      // 1-D: the kernel decodes (m-tile, n-tile) itself
+    dim3 grid(((a.m_rows + TM - 1) / TM) * ((a.Cout + TN - 1) / TN));   // 1-D: the kernel decodes (m-tile, n-tile) itself
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, a);
     return launch_status();
 }
@@ -640,7 +646,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
 template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AR_S, int AR_L, int MINW>
 static int launch_rows(const ConvArgs& a, hipStream_t s) {
     if ((long long)a.g.M * a.Cout >= (1LL << 31) || (long long)a.g.npix * a.Cout >= (1LL << 31)) return SUBREG_EUNSUPPORTED;
-    const int worst = worst_patch_rows<POOL>(a.g, WM * NI * 32);
+    const int worst = worst_patch_rows<POOL>(a.g, WM * NI * 32, a.m_base, a.m_rows);
     if (worst <= AR_S) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_S, MINW>(a, s);
     if (worst <= AR_L) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_L, MINW>(a, s);
     return SUBREG_EUNSUPPORTED;      // image too wide for the LDS patch
@@ -699,6 +705,7 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
     a.Cin = Cin; a.Cout = Cout;
     a.act = (flags & SUBREG_CONV_LRELU) ? 1 : 0;
     a.raw = raw ? 1 : 0;
+    a.m_base = 0; a.m_rows = a.g.M;
     hipStream_t s = (hipStream_t)stream;
     const bool wide = (Cout % 160 == 0);
     // LDS per block = 2 patch buffers + 2 weight buffers, sized so that >= 2 workgroups fit a CU (160 KiB).
@@ -719,15 +726,43 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
         // was bound by) and 3 taps per step = a third of the barriers.
         if (!raw && wide_takes_256_rows(a.g.M, Cout)) return launch_shape<__bf16, 2, 5, 8, 1, 3, 608, 704, 2>(a, pool, s);
 #endif
-        if (wide_takes_256_rows(a.g.M, Cout)) {
-            // patches of <= 352 rows (W <= 42 unpooled) leave room for the 3-deep weight ring at two workgroups per CU
-            const int rc = launch_shape<__bf16, 2, 5, 4, 1, 1, 352, 432, 2>(a, pool, s);
-            return rc != SUBREG_EUNSUPPORTED ? rc : launch_shape<__bf16, 2, 5, 4, 1, 1, 560, 560, 2>(a, pool, s);
+        auto tiles256 = [&](const ConvArgs& b) {
+            // patches of <= 352 rows (W <= 42 unpooled) keep the LDS footprint at two workgroups per CU with room to spare
+            const int rc = launch_shape<__bf16, 2, 5, 4, 1, 1, 352, 432, 2>(b, pool, s);
+            return rc != SUBREG_EUNSUPPORTED ? rc : launch_shape<__bf16, 2, 5, 4, 1, 1, 560, 560, 2>(b, pool, s);
+        };
+        auto tiles128 = [&](const ConvArgs& b) {
+            // 128-row tiles.  If they all fit one per CU (<= 256 workgroups) stage 3 taps per step (84 KB LDS, covers the
+            // LDS-DMA latency at that occupancy); otherwise 1 tap per step and 3 workgroups per CU.
+            if (((b.m_rows + 127) / 128) * nt > 256) {
+                const int rc = launch_shape<__bf16, 1, 5, 4, 1, 1, 192, 224, 2>(b, pool, s);     // 224: 42x42 maps, still 3 per CU
+                return rc != SUBREG_EUNSUPPORTED ? rc : launch_shape<__bf16, 1, 5, 4, 1, 1, 432, 432, 2>(b, pool, s);
+            }
+            return launch_shape<__bf16, 1, 5, 4, 1, 3, 192, 432, 2>(b, pool, s);
+        };
+        if (raw || !SUBREG_MIXED_TILES) return wide_takes_256_rows(a.g.M, Cout) ? tiles256(a) : tiles128(a);
+        // Tail quantisation: a CU works through ceil(tiles / 256) tiles, so e.g. 882 tiles of 256 rows cost 4 tile-times
+        // where 3.45 are needed.  Cover the first k tiles per CU with 256-row tiles and the remaining rows with 128-row
+        // tiles (half the work each, ~10 % less efficient: 0.55 tile-times): two launches over disjoint row ranges.
+        const int M = a.g.M, mt = (M + 255) / 256;
+        const long long T = (long long)mt * nt;
+        double best = (double)((T + 255) / 256);
+        int best_mt1 = mt;                                            // m-tiles given to the 256-row launch
+        const long long k0 = T / 256;
+        for (long long k = k0; k >= 0 && k >= k0 - 1; --k) {
+            long long mt1 = k * 256 / nt;
+            if (mt1 * 256 > M) mt1 = M / 256;
+            const long long rows2 = M - mt1 * 256, t128 = ((rows2 + 127) / 128) * nt;
+            const double cost = (double)((mt1 * nt + 255) / 256) + 0.55 * (double)((t128 + 255) / 256);
+            if (cost < best - 1e-9) { best = cost; best_mt1 = (int)mt1; }
         }
-        // small maps (10x10, 5x5): 128-row tiles.  If they all fit one per CU (<= 256 workgroups) stage 3 taps per step
-        // (84 KB LDS, covers the LDS-DMA latency at that occupancy); otherwise 1 tap per step and 3 workgroups per CU.
-        if (((a.g.M + 127) / 128) * nt > 256) return launch_shape<__bf16, 1, 5, 4, 1, 1, 192, 432, 2>(a, pool, s);
-        return launch_shape<__bf16, 1, 5, 4, 1, 3, 192, 432, 2>(a, pool, s);
+        if (best_mt1 >= mt) return tiles256(a);
+        if (best_mt1 == 0) return tiles128(a);
+        ConvArgs a1 = a, a2 = a;
+        a1.m_rows = best_mt1 * 256;
+        a2.m_base = a1.m_rows; a2.m_rows = M - a1.m_rows;
+        const int rc = tiles256(a1);
+        return rc != SUBREG_OK ? rc : tiles128(a2);
     }
     return wide ? launch_shape<float, 2, 5, 2, 1, 1, 304, 408, 1>(a, pool, s) : launch_shape<float, 2, 2, 2, 1, 1, 304, 408, 1>(a, pool, s);
 }
