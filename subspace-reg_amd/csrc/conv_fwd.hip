@@ -174,36 +174,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
         *reinterpret_cast<uint4*>(smem + b * ABUF + AROWS * ROWB + q * 16) = make_uint4(0, 0, 0, 0);
     }
 
-    // per-lane LDS addresses of this lane's A rows for every tap (k-step 0; k-step s is addr ^ 16*LG*s): logical slot
-    // LG*s + lh of the row, physical slot = logical ^ swz.  Kept as 16-bit halves (every patch buffer is < 64 KiB):
-    // the 16x16 MFMA shape needs MI = 4 row addresses per tap and the accumulators leave no room for 36 registers.
-    static_assert(ABUF < 65536, "packed A addresses are 16-bit");
-    constexpr int NAP = (MI * TAPS + 1) / 2;
-    unsigned apk[NAP];
-#pragma unroll
-    for (int k = 0; k < NAP; ++k) apk[k] = 0;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + (wave_m * MI + i) * TR + lr;
-        const bool mv = m < g.M;
-        const Pix px = row_to_pixel<POOL>(g, mv ? m : 0);
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-            const int dy = TAPS == 9 ? t / 3 - 1 : 0, dx = TAPS == 9 ? t % 3 - 1 : 0;
-            const bool ok = mv && tap_valid(g, px.h, px.w, dy, dx);
-            const int row = px.p + dy * g.W + dx - plo;
-            const unsigned ad = ok ? row * ROWB + 16 * (lh ^ swz_tr<SLOTS, TR>(row)) : AROWS * ROWB + 16 * lh;
-            apk[(i * TAPS + t) >> 1] |= ad << (16 * ((i * TAPS + t) & 1));
-        }
-    }
-    auto aaddr = [&](int i, int t) -> int {
-        const int idx = i * TAPS + t;
-        return (idx & 1) ? (int)(apk[idx >> 1] >> 16) : (int)(apk[idx >> 1] & 0xffffu);
-    };
-    // B rows are the tile's consecutive output channels: tile j sits j*TR rows further (a multiple of the swizzle period)
-    const int baddr0 = B_BASE + (wave_n * MJ * TR + lr) * ROWB + 16 * (lh ^ swz_tr<SLOTS, TR>(lr));
-    static_assert(TR % 16 == 0, "swizzle period");
-
     acc_t acc[MI][MJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -276,6 +246,37 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
             advance(sc, stg);
         }
     }
+    // per-lane LDS addresses of this lane's A rows for every tap (k-step 0; k-step s is addr ^ 16*LG*s): logical slot
+    // LG*s + lh of the row, physical slot = logical ^ swz.  Kept as 16-bit halves (every patch buffer is < 64 KiB):
+    // the 16x16 MFMA shape needs MI = 4 row addresses per tap and the accumulators leave no room for 36 registers.
+    static_assert(ABUF < 65536, "packed A addresses are 16-bit");
+    constexpr int NAP = (MI * TAPS + 1) / 2;
+    unsigned apk[NAP];
+#pragma unroll
+    for (int k = 0; k < NAP; ++k) apk[k] = 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + (wave_m * MI + i) * TR + lr;
+        const bool mv = m < g.M;
+        const Pix px = row_to_pixel<POOL>(g, mv ? m : 0);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int dy = TAPS == 9 ? t / 3 - 1 : 0, dx = TAPS == 9 ? t % 3 - 1 : 0;
+            const bool ok = mv && tap_valid(g, px.h, px.w, dy, dx);
+            const int row = px.p + dy * g.W + dx - plo;
+            const unsigned ad = ok ? row * ROWB + 16 * (lh ^ swz_tr<SLOTS, TR>(row)) : AROWS * ROWB + 16 * lh;
+            apk[(i * TAPS + t) >> 1] |= ad << (16 * ((i * TAPS + t) & 1));
+        }
+    }
+    auto aaddr = [&](int i, int t) -> int {
+        const int idx = i * TAPS + t;
+        return (idx & 1) ? (int)(apk[idx >> 1] >> 16) : (int)(apk[idx >> 1] & 0xffffu);
+    };
+    // B rows are the tile's consecutive output channels: tile j sits j*TR rows further (a multiple of the swizzle period)
+    const int baddr0 = B_BASE + (wave_n * MJ * TR + lr) * ROWB + 16 * (lh ^ swz_tr<SLOTS, TR>(lr));
+    static_assert(TR % 16 == 0, "swizzle period");
+    // (computed HERE, between issuing the prologue's DMAs and waiting for them: ~1000 cycles of integer divisions that would
+    // otherwise precede the first global access of a short-K workgroup)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's DMA landed ...
     __syncthreads();                                                  // ... everyone's did; zero rows visible
     // Patch of chunk c+1 is prefetched during chunk c, PA piece groups per step (none in the chunk's last step when
