@@ -17,33 +17,43 @@ static inline int ew_blocks(size_t n, int per_thread = 1) {
 
 // ---------------------------------------------------------------- first-layer im2col (Cin = 3 -> K = 32)
 // x NCHW f32 [B,3,H,W] -> col [B*H*W][32] T with k = 3*tap + c (tap = 3*ky+kx), k >= 27 zero.
-// One workgroup = one image row (b, h): the three input rows h-1..h+1 of the three channels go through LDS with coalesced
-// loads (zero-padded at the borders), then one thread = one 16-byte piece of an im2col row (8 bf16 / 4 f32 values of k), so
-// consecutive lanes store consecutive addresses.  (Gathering the 27 taps straight from global memory was load-issue
-// bound: 85 us for 350 images where the HBM traffic needs ~35.)
+// One workgroup = PACK_ROWS image rows of one image: the PACK_ROWS + 2 input rows of the three channels go through LDS with
+// coalesced loads (zero-padded at the borders), then one thread = one 16-byte piece of an im2col row (8 bf16 / 4 f32 values
+// of k), so consecutive lanes store consecutive addresses.  Several rows per workgroup so that one load -> barrier ->
+// store latency chain moves ~38 KB (one row per workgroup left the kernel latency-bound at 2 TB/s; 7 rows: 4.2 TB/s,
+// 44 us for 350 images where the per-pixel gather took 88).
+constexpr int PACK_ROWS = 7;
 template <typename T>
-__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, T* __restrict__ col, int B, int H, int W) {
+__global__ __launch_bounds__(1024) void pack_input_kernel(const float* __restrict__ x, T* __restrict__ col, int B, int H, int W) {
     constexpr int VEC = 16 / sizeof(T), PER = 32 / VEC;             // values per thread, threads per pixel
-    extern __shared__ float s_in[];                                  // [3 rows dy][3 channels][W + 2]
-    const int b = blockIdx.x / H, h = blockIdx.x % H, W2 = W + 2, hw = H * W;
+    extern __shared__ float s_in[];                                  // [PACK_ROWS + 2 rows][3 channels][W + 2]
+    const int hblocks = (H + PACK_ROWS - 1) / PACK_ROWS;
+    const int b = blockIdx.x / hblocks, h0 = (blockIdx.x % hblocks) * PACK_ROWS, W2 = W + 2, hw = H * W;
     const float* xb = x + (size_t)b * 3 * hw;
-    for (int i = threadIdx.x; i < 9 * W2; i += blockDim.x) {
+    for (int i = threadIdx.x; i < (PACK_ROWS + 2) * 3 * W2; i += blockDim.x) {
         const int dy = i / (3 * W2), c = (i / W2) % 3, wc = i % W2;  // wc = w + 1
-        const int hh = h + dy - 1, ww = wc - 1;
+        const int hh = h0 + dy - 1, ww = wc - 1;
         s_in[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xb[(size_t)c * hw + hh * W + ww] : 0.f;
     }
     __syncthreads();
-    T* const row = col + ((size_t)b * hw + (size_t)h * W) * 32;
-    for (int i = threadIdx.x; i < W * PER; i += blockDim.x) {
-        const int w = i / PER, q = i % PER;
-        uint4 v;
-        T* out = reinterpret_cast<T*>(&v);
+    const int rows = H - h0 < PACK_ROWS ? H - h0 : PACK_ROWS;
+    T* const out0 = col + ((size_t)b * hw + (size_t)h0 * W) * 32;   // the rows of one image are contiguous
+    // a thread keeps its (pixel column w, 16-byte piece q) and walks down the rows: the tap offsets are computed once
+    for (int item = threadIdx.x; item < W * PER; item += blockDim.x) {
+        const int w = item / PER, q = item % PER;
+        int off[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const int k = q * VEC + j, t = k / 3, c = k % 3;         // k = 3*tap + c
-            out[j] = ElemTraits<T>::from_float(k < 27 ? s_in[((t / 3) * 3 + c) * W2 + w + t % 3] : 0.f);
+            off[j] = k < 27 ? ((t / 3) * 3 + c) * W2 + w + t % 3 : -1;
         }
-        *reinterpret_cast<uint4*>(row + (size_t)w * 32 + q * VEC) = v;
+        for (int r = 0; r < rows; ++r) {
+            uint4 v;
+            T* out = reinterpret_cast<T*>(&v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) out[j] = ElemTraits<T>::from_float(off[j] >= 0 ? s_in[off[j] + r * 3 * W2] : 0.f);
+            *reinterpret_cast<uint4*>(out0 + ((size_t)r * W + w) * 32 + q * VEC) = v;
+        }
     }
 }
 
@@ -283,9 +293,13 @@ extern "C" int subreg_pack_input(const float* x_nchw, void* col, int B, int H, i
     SUBREG_CHECK_ARG(x_nchw && col && B > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
     SUBREG_CHECK_ARG(W <= 1024 && (long long)B * H < (1LL << 31));
-    const size_t lds = (size_t)9 * (W + 2) * sizeof(float);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_input_kernel<float>, B * H, 256, lds, s, x_nchw, (float*)col, B, H, W),
-               hipLaunchKernelGGL(pack_input_kernel<__bf16>, B * H, 256, lds, s, x_nchw, (__bf16*)col, B, H, W));
+    const size_t lds = (size_t)(PACK_ROWS + 2) * 3 * (W + 2) * sizeof(float);
+    const int grid = B * ((H + PACK_ROWS - 1) / PACK_ROWS);
+    const int per = dtype == SUBREG_BF16 ? 4 : 8;                    // 16-byte pieces per im2col row
+    int threads = ((W * per + 63) / 64) * 64;
+    if (threads > 1024) threads = 1024;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_input_kernel<float>, grid, threads, lds, s, x_nchw, (float*)col, B, H, W),
+               hipLaunchKernelGGL(pack_input_kernel<__bf16>, grid, threads, lds, s, x_nchw, (__bf16*)col, B, H, W));
     return launch_status();
 }
 
