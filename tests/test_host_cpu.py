@@ -169,3 +169,42 @@ def test_pretrain_lr_schedules_match_torch_and_reference_rule():
     assert m.avg == 2.5 and m.val == 4.0 and m.count == 4
     x, y = torch.arange(10)[:, None], torch.arange(10)
     assert [pt.shard_batch(x, y, r, 4)[1].tolist() for r in range(4)] == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9]]
+
+
+def test_episode_sampler_matches_reference_dataset_classes():
+    """subreg_hip.episodes vs the reference's ImageNet / MetaImageNet run on a synthetic all.pickle (tests/golden/episodes.npz):
+    class split, base test split, replay-memory episode, eight disjoint novel sessions with x5 tiled support."""
+    from conftest import GOLDEN
+    from subreg_hip import episodes as ep
+    g = np.load(os.path.join(GOLDEN, "episodes.npz"))
+    labels = g["labels"].tolist()
+    for seed in (1, 7):
+        key = "seed%d" % seed
+        sp = ep.continual_split(labels, seed)
+        assert np.array_equal(sp["basec"], g[key + ".basec"]) and len(sp["valc"]) == 40
+        assert int(g[key + ".label2human_nonempty"]) == 60
+        bt = ep.BaseSplit(labels, seed, "test")
+        assert len(bt) == int(g[key + ".base_test_len"]) == 60 * 50
+        got = np.array([bt.item(i) for i in range(0, len(bt), 37)])
+        assert np.array_equal(got, g[key + ".base_test_items"])
+        btr = ep.BaseSplit(labels, seed, "train")
+        assert len(btr) == 60 * 500 and len(ep.BaseSplit(labels, seed, "val")) == 60 * 50
+        for item in (0, 3):
+            pos, ys = ep.base_support_episode(btr.labels, item, 1, 0)
+            assert np.array_equal(btr.indices[pos], g["%s.base_support%d.pos" % (key, item)])
+            assert np.array_equal(ys, g["%s.base_support%d.ys" % (key, item)])
+        ns = ep.NovelSessions(labels, seed)
+        assert len(ns) == 8
+        seen = set()
+        for item in range(8):
+            s_pos, s_ys, q_pos, q_ys = ns.next_session(item)
+            assert np.array_equal(ns.indices[s_pos], g["%s.s%d.sup" % (key, item)])
+            assert np.array_equal(s_ys, g["%s.s%d.sup_ys" % (key, item)])
+            assert np.array_equal(ns.indices[q_pos], g["%s.s%d.qry" % (key, item)])
+            assert np.array_equal(q_ys, g["%s.s%d.qry_ys" % (key, item)])
+            assert s_pos.shape == (125,) and q_pos.shape == (125,) and not set(s_pos) & set(q_pos)
+            cls = set(np.unique(q_ys).tolist())
+            assert len(cls) == 5 and not cls & seen and cls <= set(sp["valc"].tolist())      # disjoint sessions of novel classes
+            seen |= cls
+    with pytest.raises(ValueError):
+        ep.BaseSplit(labels, 1, "nope")

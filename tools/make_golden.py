@@ -427,6 +427,62 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False
     print("loop_%s.npz" % tag, {k: v for k, v in out.items() if k.endswith("epochs")})
 
 
+# ------------------------------------------------------------------ G6: episode sampler (dataset/mini_imagenet.py)
+def gen_episodes():
+    """Which images feed which session: runs the reference's ImageNet / MetaImageNet classes themselves on a synthetic
+    all.pickle (100 classes x 600 two-by-two 'images' whose pixels spell their own index) and records the indices.
+    dataset/mini_imagenet.py imports torchvision.transforms (absent in this image) at module level; the module object below
+    only lets that import succeed - its names are never CALLED, because explicit transforms (index decoders) are passed to
+    every dataset.  The fixture therefore pins the numpy index sampling only, not the image augmentation."""
+    import pickle
+    import tempfile
+    tv, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+    for name in ("Normalize", "Compose", "RandomCrop", "ColorJitter", "RandomHorizontalFlip", "ToTensor"):
+        setattr(tvt, name, lambda *a, **k: None)
+    tv.transforms = tvt
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tvt)
+    import dataset.mini_imagenet as mi                                   # the reference
+    rs = np.random.RandomState(123)
+    labels = rs.permutation(np.repeat(np.arange(100), 600))
+    n = labels.shape[0]
+    idx = np.arange(n)
+    imgs = np.zeros((n, 2, 2, 3), np.uint8)
+    imgs[:, 0, 0, 0], imgs[:, 0, 0, 1], imgs[:, 0, 0, 2] = idx & 255, (idx >> 8) & 255, (idx >> 16) & 255
+    decode = lambda x: torch.tensor(float(int(x[0, 0, 0]) | (int(x[0, 0, 1]) << 8) | (int(x[0, 0, 2]) << 16)))   # noqa: E731
+    out = {"labels": labels.astype(np.int64)}
+    with tempfile.TemporaryDirectory() as root:
+        with open(os.path.join(root, "all.pickle"), "wb") as f:
+            pickle.dump({"data": imgs, "labels": labels.tolist(), "catname2label": {"n%04d" % c: c for c in range(100)}}, f)
+        with open(os.path.join(root, "class_labels.txt"), "w") as f:
+            f.write("".join("n%04d class_%d\n" % (c, c) for c in range(100)))
+        for seed in (1, 7):
+            args = SimpleNamespace(data_aug=True, set_seed=seed, continual=True, data_root=root, n_ways=5, n_shots=5, n_queries=25,
+                                   n_test_runs=8, eval_mode="few-shot-incremental-fine-tune", n_aug_support_samples=5,
+                                   n_base_aug_support_samples=0, n_base_support_samples=1)
+            key = "seed%d" % seed
+            base_test = mi.ImageNet(args=args, split="train", phase="test", transform=decode)
+            out[key + ".basec"] = np.array(sorted(base_test.basec_map.keys()))
+            out[key + ".base_test_len"] = np.array(len(base_test))
+            items = [base_test[i] for i in range(0, len(base_test), 37)]
+            out[key + ".base_test_items"] = np.array([[int(x), int(t), int(i)] for x, t, i in items])
+            out[key + ".label2human_nonempty"] = np.array(sum(1 for h in base_test.label2human if h != ""))
+            base_sup = mi.MetaImageNet(args=args, split="train", phase="train", train_transform=decode, test_transform=decode,
+                                       fix_seed=True, use_episodes=False)
+            for item in (0, 3):
+                sx, sy, _qx, _qy = base_sup[item]
+                out["%s.base_support%d.pos" % (key, item)] = sx.numpy().astype(np.int64)
+                out["%s.base_support%d.ys" % (key, item)] = np.asarray(sy).astype(np.int64)
+            meta = mi.MetaImageNet(args=args, split="val", train_transform=decode, test_transform=decode, fix_seed=True,
+                                   use_episodes=False, disjoint_classes=True)
+            for item in range(8):
+                sx, sy, qx, qy = meta[item]
+                for nm, v in (("sup", sx.numpy()), ("sup_ys", sy), ("qry", qx.numpy()), ("qry_ys", qy)):
+                    out["%s.s%d.%s" % (key, item, nm)] = np.asarray(v).astype(np.int64)
+    np.savez_compressed(os.path.join(GOLD, "episodes.npz"), **out)
+    print("episodes.npz", sum(v.nbytes for v in out.values()) / 1e6, "MB")
+
+
 # ------------------------------------------------------------------ G5: one pretraining step (train_supervised.py:205-268)
 TRAIN_SLICES = {"layer1.0.conv1.weight": None, "layer1.0.downsample.0.weight": None, "layer1.0.conv2.weight": 8,
                 "layer2.0.conv2.weight": 8, "layer2.0.downsample.0.weight": 16, "layer3.0.conv1.weight": 4,
@@ -472,7 +528,7 @@ def gen_train_step():
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["blocks", "backbone", "reg", "train", "loop32", "semantic", "loop84"]
+    what = sys.argv[1:] or ["blocks", "backbone", "reg", "train", "loop32", "semantic", "episodes", "loop84"]
     if "blocks" in what:
         gen_blocks()
     if "backbone" in what:
@@ -493,6 +549,8 @@ def main():
                  temperature=3.0)
         gen_loop("hw32_map", 32, 2, False, 40, seed=6, max_novel_epochs=4, real_names=True, mapping_seed=77,
                  attraction_override="mapping_linear_label2image")
+    if "episodes" in what:
+        gen_episodes()
     if "loop84" in what:
         gen_loop("hw84_M", 84, 3, True, 40, seed=4, max_novel_epochs=4)
 
