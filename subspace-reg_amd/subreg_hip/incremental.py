@@ -68,7 +68,7 @@ class IncrementalRunner:
 
     def __init__(self, net, meta_valloader, base_val_loader, opt, base_support_loader=None, novel_inits=None,
                  memory_picks=None, epochs_per_sync=8, reuse_features=False, verbose=True, profile=False, use_graph=True,
-                 ckpt=None):
+                 ckpt=None, row_shard=None):
         if getattr(opt, "track_weights", False) or getattr(opt, "save_preds_0", False):
             raise NotImplementedError("CSV tracking is outside the hot path (SURVEY.md section 8)")
         ao = getattr(opt, "attraction_override", None)
@@ -78,6 +78,9 @@ class IncrementalRunner:
         if ao == "mapping_linear_label2image" and (ckpt is None or ao not in ckpt):
             raise ValueError("mapping_linear_label2image needs ckpt['mapping_linear_label2image'] (language_eval.py:225-226)")
         self.ckpt = ckpt
+        # intra-seed data parallelism (sweep.RowShard): eval-mode forwards are split over the ranks of a group that hold the
+        # same backbone, features exchanged with one all-gather per forward; None / size 1 = this rank does everything
+        self.dp = row_shard if (row_shard is not None and row_shard.size > 1) else None
         if net.classifier.bias is not None:
             raise NotImplementedError("fused loop assumes --no_linear_bias backbones (slurm_run_backbone.sh:39)")
         if getattr(opt, "adam", False):
@@ -106,9 +109,33 @@ class IncrementalRunner:
         self.images_forwarded += x.shape[0]
         return r
 
+    def _forward_eval(self, x, out=None, gather_buf=None, local_buf=None, forward=None):
+        """Eval-mode forward of x [B,...] -> features [B, D]: locally, or this rank's row slice + all-gather.
+        `forward(x_slice, out_rows)` overrides the launch (the hipGraph replay of an identical earlier call)."""
+        if self.dp is None:
+            if forward is not None:
+                forward(x, out)
+                return out
+            return self._forward(x, out=out, check_params=False)
+        B = x.shape[0]
+        lo, hi, per = self.dp.rows(B)
+        if local_buf is None:
+            local_buf = torch.zeros(per, self.D, dtype=torch.float32, device=self.dev)
+        if hi > lo:
+            if forward is not None:
+                forward(x[lo:hi], local_buf[:hi - lo])
+            else:
+                self._forward(x[lo:hi], out=local_buf[:hi - lo], check_params=False)
+        full = self.dp.gather(local_buf, B, out=gather_buf)
+        if out is not None and out.data_ptr() != full.data_ptr():
+            out.copy_(full)
+            return out
+        return full
+
     def _eval_base(self):                                                        # :46-69
         self.net.eval()
-        feat = self._forward(self.base_x)
+        self.hb.refresh()
+        feat = self._forward_eval(self.base_x)
         cnt = torch.zeros(1, dtype=torch.int32, device=self.dev)
         W = self.net.classifier.weight.detach()
         _lib.check(self.lib.subreg_validate(_lib.ptr(feat), _lib.ptr(self.base_y), _lib.ptr(W), feat.shape[0], W.shape[0],
@@ -204,7 +231,14 @@ class IncrementalRunner:
         _lib.check(lib.subreg_loop_state_init(_lib.ptr(ses.state), s()), "loop_state_init")
         labels = sid if mem_x is None else torch.cat([sid, mem_y])
         all_x = torch.cat([sx] + ([mem_x] if mem_x is not None else []) + query_x, 0)
-        feats = torch.empty(all_x.shape[0], D, dtype=torch.float32, device=dev)
+        if self.dp is None:
+            feats = torch.empty(all_x.shape[0], D, dtype=torch.float32, device=dev)
+            gather_buf = local_buf = None
+        else:                                  # feats = the first rows of the all-gather's output buffer (no copy per epoch)
+            lo_all, hi_all, per_all = self.dp.rows(all_x.shape[0])
+            gather_buf = torch.zeros(self.dp.size * per_all, D, dtype=torch.float32, device=dev)
+            local_buf = torch.zeros(per_all, D, dtype=torch.float32, device=dev)
+            feats = gather_buf[:all_x.shape[0]]
         q_off = [Bs + Bm + sum(q.shape[0] for q in query_x[:j]) for j in range(n_sets)]
         d = _lib.StepDesc()
         d.feat, d.labels = feats.data_ptr(), labels.data_ptr()
@@ -244,7 +278,8 @@ class IncrementalRunner:
         for m in net._bns:
             m.num_batches_tracked += 1 + (1 if Bm else 0)
         net.eval()                                                             # validate() flips the mode for good, :19
-        self._forward(all_x[Bs + Bm:], out=feats[Bs + Bm:])
+        hb.refresh()                                                           # BN running statistics moved: fold once
+        self._forward_eval(all_x[Bs + Bm:], out=feats[Bs + Bm:])
         for i in range(len(hb.nbt)):
             hb.nbt[i] += n_sets - 1
         step_and_validate()
@@ -252,6 +287,11 @@ class IncrementalRunner:
         #      backbone, constant inputs): after one eager pass its launch sequence is captured into a hipGraph and
         #      replayed - every epoch still executes all 22 convolutions, only the host-side launches are saved.
         graph, eager_done = None, 0
+        # what THIS rank forwards per epoch: everything, or its row slice of all_x (features all-gathered afterwards)
+        if self.dp is None:
+            x_loc, out_loc = all_x, feats
+        else:
+            x_loc, out_loc = all_x[lo_all:hi_all], local_buf[:hi_all - lo_all]
         while True:
             st = ses.state.cpu()
             done, stop = int(st[0]), bool(st[1])
@@ -261,27 +301,31 @@ class IncrementalRunner:
             executed = 0
             for e in range(k):
                 if not self.reuse_features or (done == 1 and e == 0):
-                    if graph is not None:
+                    if x_loc.shape[0] == 0:
+                        pass                                                    # more ranks than rows: nothing to forward here
+                    elif graph is not None:
                         if self.profile:
                             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                             e0.record()
                         graph.replay()
                         if self.profile:
                             e1.record()
-                            self.fwd_events.append((e0, e1, all_x.shape[0]))
-                        self.images_forwarded += all_x.shape[0]
+                            self.fwd_events.append((e0, e1, x_loc.shape[0]))
+                        self.images_forwarded += x_loc.shape[0]
                         for i in range(len(hb.nbt)):
                             hb.nbt[i] += 1
                     else:
-                        self._forward(all_x, out=feats, check_params=False)     # frozen backbone, nothing changed
+                        self._forward(x_loc, out=out_loc, check_params=False)   # frozen backbone, nothing changed
                         eager_done += 1
                         if self.use_graph and not self.reuse_features and eager_done == 1 and max_e - done > 4:
                             nbt_keep = list(hb.nbt)
                             torch.cuda.synchronize()
                             graph = torch.cuda.CUDAGraph()
                             with torch.cuda.graph(graph):
-                                hb.forward(all_x, out=feats, check_params=False)
+                                hb.forward(x_loc, out=out_loc, check_params=False)
                             hb.nbt = nbt_keep                                   # the capture pass launches nothing
+                    if self.dp is not None:
+                        self.dp.gather(local_buf, all_x.shape[0], out=gather_buf)   # feats = gather_buf[:rows]
                     executed += 1
                 step_and_validate()
             ran = int(ses.state.cpu()[0]) - done   # epochs that really advanced the loop

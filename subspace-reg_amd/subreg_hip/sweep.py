@@ -42,3 +42,86 @@ def gather_results(obj):
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, obj)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Level 2: intra-seed data parallelism for the sweep's tail (10 seeds on 8 GPUs leave 2 seeds for a second round; without
+# it the makespan is 2 seed-runs = 5x over one GPU).  The backbone is frozen, eval-mode images are independent, so a group
+# of ranks holding the same backbone each forward a contiguous slice of every epoch's image batch and exchange the
+# [rows, 640] fp32 features with ONE all-gather (1.8 MB per epoch at 700 images); the classifier step and the validation
+# run redundantly on every rank of the group, so no further communication is needed and all ranks take identical stop
+# decisions.  The only other collective is the one-time broadcast of the seed's backbone to its group.
+class RowShard:
+    """Contiguous row slices of a batch over the ranks of a process group + the feature all-gather."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo"   # CPU tests / single-GPU checks
+
+    def rows(self, n):
+        """(lo, hi, per): this rank forwards rows [lo, hi) of n; every rank's slot in the gathered buffer has `per` rows."""
+        per = (n + self.size - 1) // self.size
+        lo = min(self.rank * per, n)
+        return lo, min(lo + per, n), per
+
+    def gather(self, local, n, out=None):
+        """local [per, D] (rows beyond this rank's slice are padding) -> [n, D] on every rank.  `out`, if given, must have
+        size*per rows; the result is its first n rows (no copy)."""
+        per, d = local.shape
+        if out is None:
+            out = torch.empty(self.size * per, d, dtype=local.dtype, device=local.device)
+        if self.size == 1:
+            out[:per].copy_(local)
+        elif self.host_staged:
+            tmp = torch.empty(self.size * per, d, dtype=local.dtype)
+            dist.all_gather_into_tensor(tmp, local.cpu().contiguous(), group=self.group)
+            out.copy_(tmp)
+        else:
+            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)      # RCCL over xGMI
+        return out[:n]
+
+
+def broadcast_module(module, src, group=None):
+    """The sweep's one data-path collective besides the feature gather: the seed's backbone + classifier from the group
+    leader (global rank `src`) to the ranks that will help with it."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    staged = dist.get_backend(group) == "gloo"
+    for _name, t in sorted(module.state_dict().items()):
+        if staged and t.is_cuda:
+            h = t.detach().cpu()
+            dist.broadcast(h, src, group=group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src, group=group)
+
+
+def plan_sweep(seeds, world):
+    """Rounds of (seed, ranks): full rounds give every rank its own seed; the last, partial round splits all ranks evenly
+    over the seeds that are left (10 seeds, 8 ranks -> 8 x 1 rank, then 2 seeds x 4 ranks)."""
+    seeds = list(seeds)
+    rounds = []
+    while len(seeds) >= world:
+        rounds.append([(seeds[r], [r]) for r in range(world)])
+        seeds = seeds[world:]
+    if seeds:
+        k = len(seeds)
+        base, extra = divmod(world, k)
+        groups, start = [], 0
+        for i in range(k):
+            n = base + (1 if i < extra else 0)
+            groups.append((seeds[i], list(range(start, start + n))))
+            start += n
+        rounds.append(groups)
+    return rounds
+
+
+def sweep_speedup(n_seeds, world, dp_efficiency=0.9):
+    """Speed-up over one GPU of `plan_sweep`: a seed shared by g ranks takes 1 / (1 + (g - 1) * dp_efficiency) seed-times
+    (the backbone forward is >= 94 % of a run and shards perfectly; the redundant classifier step and the gather do not)."""
+    t = 0.0
+    for rnd in plan_sweep(range(n_seeds), world):
+        t += max(1.0 / (1.0 + (len(ranks) - 1) * dp_efficiency) for _seed, ranks in rnd)
+    return n_seeds / t

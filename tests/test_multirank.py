@@ -86,3 +86,52 @@ def test_two_rank_gradient_averaging_gloo():
     assert calls == 2                                         # one collective for the flat buffer, one for the classifier
     assert g0 == [[0.0, 1.5, 3.0], [4.5, 6.0, 7.5]] and g1 == [9.0, 10.5, 12.0, 13.5]     # mean of 1x and 2x arange
     assert g2 == [0.5] * 5 and y == [0, 1, 2, 3]
+
+
+def _shard_worker(rank, world, port, q):
+    """Level-2 helpers: row slices + feature gather (uneven rows), backbone broadcast."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = sweep.RowShard()
+    x = torch.arange(7 * 3, dtype=torch.float32).view(7, 3)
+    fwd = lambda t: t @ torch.tensor([[1.0, 2.0], [0.5, -1.0], [3.0, 0.0]])          # noqa: E731  (stand-in "backbone")
+    lo, hi, per = sh.rows(7)
+    local = torch.zeros(per, 2)
+    local[:hi - lo] = fwd(x[lo:hi])
+    buf = torch.zeros(world * per, 2)
+    full = sh.gather(local, 7, out=buf)
+    lin = torch.nn.Linear(4, 3)
+    with torch.no_grad():
+        lin.weight.fill_(float(rank + 1))
+    sweep.broadcast_module(lin, 0)
+    if rank == 1:
+        q.put(((lo, hi, per), torch.equal(full, fwd(x)), full.data_ptr() == buf.data_ptr(), float(lin.weight[0, 0])))
+    dist.destroy_process_group()
+
+
+def test_two_rank_row_shard_and_broadcast_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    rows, equal, in_place, w = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert rows == (4, 7, 4) and equal and in_place and w == 1.0
+
+
+def test_sweep_plan_reaches_the_scaling_target():
+    plan = sweep.plan_sweep(range(1, 11), 8)
+    assert [len(r) for r in plan] == [8, 2]
+    assert plan[0][3] == (4, [3]) and plan[1] == [(9, [0, 1, 2, 3]), (10, [4, 5, 6, 7])]
+    assert sweep.plan_sweep(range(3), 8)[0] == [(0, [0, 1, 2]), (1, [3, 4, 5]), (2, [6, 7])]
+    assert sweep.plan_sweep(range(16), 8) == [[(s, [s % 8]) for s in range(8)], [(s, [s % 8]) for s in range(8, 16)]]
+    assert 10 / sweep.makespan_units(10, 8) == 5.0                   # seed sharding alone
+    assert sweep.sweep_speedup(10, 8) > 6.0                          # + intra-seed data parallelism for the last two seeds
+    assert abs(sweep.sweep_speedup(8, 8) - 8.0) < 1e-9 and abs(sweep.sweep_speedup(10, 1) - 1.0) < 1e-9
