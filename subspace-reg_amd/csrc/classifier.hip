@@ -434,6 +434,41 @@ __global__ __launch_bounds__(256) void validate_kernel(const float* __restrict__
     (void)is_last_set;
 }
 
+// the same for ALL query sets of a session in one launch (the rows of set j follow those of set j-1; one launch per set
+// cost ~19 us each for 125-row sets, i.e. up to 8 x per epoch): block b finds its set from the prefix sums
+struct ValidateSets {
+    int n_sets;
+    int end[SUBREG_MAX_QUERY_SETS];      // exclusive prefix sums of the sets' row counts
+};
+__global__ __launch_bounds__(256) void validate_sets_kernel(const float* __restrict__ feat, const long long* __restrict__ labels,
+                                                             const float* __restrict__ W, int N, int D, subreg_loop_state* st,
+                                                             int* __restrict__ correct, int n_sets_max, const ValidateSets vs) {
+    __shared__ float s_logit[MAX_CLS];
+    int slot = 0;
+    if (st) {
+        if (st->val_epoch == st->epoch) return;
+        slot = st->epoch;
+    }
+    const int b = blockIdx.x;
+    int set = 0;
+    while (set + 1 < vs.n_sets && b >= vs.end[set]) ++set;
+    row_logits(feat + (size_t)b * D, W, nullptr, N, D, s_logit);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        float mx = -3.0e38f;
+        int arg = 0;
+        for (int n = lane; n < N; n += 64) if (s_logit[n] > mx) { mx = s_logit[n]; arg = n; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float om = __shfl_xor(mx, o);
+            const int oa = __shfl_xor(arg, o);
+            if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
+        }
+        if (lane == 0 && arg == (int)labels[b]) atomicAdd(&correct[(size_t)slot * n_sets_max + set], 1);
+    }
+}
+
 __global__ void validate_mark_kernel(subreg_loop_state* st) {
     if (threadIdx.x == 0 && blockIdx.x == 0) st->val_epoch = st->epoch;
 }
@@ -592,6 +627,25 @@ extern "C" int subreg_frob(const float* a, const float* b, long long n, float lm
                            float* grad_a, void* stream) {
     SUBREG_CHECK_ARG(a && b && n > 0);
     hipLaunchKernelGGL(frob_kernel, 1, 1024, 0, (hipStream_t)stream, a, b, n, lmbd, loss, grad_out, grad_a);
+    return launch_status();
+}
+
+extern "C" int subreg_validate_sets(const float* feat, const long long* labels, const float* weight, const int* set_rows, int n_sets,
+                                    int N, int D, subreg_loop_state* state, int* correct, int n_sets_max, int mark_done,
+                                    void* stream) {
+    SUBREG_CHECK_ARG(feat && labels && weight && correct && set_rows && N > 0 && N <= MAX_CLS && D > 0);
+    SUBREG_CHECK_ARG(n_sets >= 1 && n_sets <= SUBREG_MAX_QUERY_SETS && n_sets <= n_sets_max);
+    ValidateSets vs;
+    vs.n_sets = n_sets;
+    int total = 0;
+    for (int j = 0; j < n_sets; ++j) {
+        SUBREG_CHECK_ARG(set_rows[j] > 0);
+        total += set_rows[j];
+        vs.end[j] = total;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(validate_sets_kernel, total, 256, 0, s, feat, labels, weight, N, D, state, correct, n_sets_max, vs);
+    if (mark_done && state) hipLaunchKernelGGL(validate_mark_kernel, 1, 64, 0, s, state);
     return launch_status();
 }
 

@@ -240,6 +240,8 @@ class IncrementalRunner:
             local_buf = torch.zeros(per_all, D, dtype=torch.float32, device=dev)
             feats = gather_buf[:all_x.shape[0]]
         q_off = [Bs + Bm + sum(q.shape[0] for q in query_x[:j]) for j in range(n_sets)]
+        query_labels = torch.cat(query_id, 0).contiguous()
+        set_rows = (C.c_int * n_sets)(*[int(q.shape[0]) for q in query_x])
         d = _lib.StepDesc()
         d.feat, d.labels = feats.data_ptr(), labels.data_ptr()
         d.n_support, d.n_memory, d.n_classes, d.dim = Bs, Bm, N, D
@@ -266,6 +268,11 @@ class IncrementalRunner:
 
         def step_and_validate():
             _lib.check(lib.subreg_finetune_step(C.byref(d), s()), "finetune_step")
+            if n_sets <= _lib.MAX_QUERY_SETS:          # all query sets in one launch (rows and labels are consecutive)
+                _lib.check(lib.subreg_validate_sets(_lib.ptr(feats[q_off[0]:]), _lib.ptr(query_labels), _lib.ptr(W), set_rows,
+                                                    n_sets, N, D, _lib.ptr(ses.state), _lib.ptr(ses.correct), n_sets, 1, s()),
+                           "validate_sets")
+                return
             for j in range(n_sets):
                 _lib.check(lib.subreg_validate(_lib.ptr(feats[q_off[j]:]), _lib.ptr(query_id[j]), _lib.ptr(W),
                                                query_x[j].shape[0], N, D, _lib.ptr(ses.state), _lib.ptr(ses.correct), j,
