@@ -184,12 +184,21 @@ __global__ __launch_bounds__(1024) void subspace_basis_kernel(const float* __res
 __device__ __forceinline__ void project_row(const float* __restrict__ w, const float* __restrict__ Q, int nb, int D,
                                             float* s_c) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int j = wid; j < nb; j += nw) {
-        const float* q = Q + (size_t)j * D;
-        float acc = 0.f;
-        for (int d = lane; d < D; d += 64) acc = fmaf(w[d], q[d], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) s_c[j] = acc;
+    constexpr int U = 4;                                   // four basis rows per pass (independent loads), like row_logits
+    for (int j0 = wid * U; j0 < nb; j0 += nw * U) {
+        float acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            const float wv = w[d];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = fmaf(wv, Q[(size_t)(j0 + u < nb ? j0 + u : nb - 1) * D + d], acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float t = wave_sum(acc[u]);
+            if (lane == 0 && j0 + u < nb) s_c[j0 + u] = t;
+        }
     }
     __syncthreads();
 }
@@ -284,8 +293,19 @@ __global__ __launch_bounds__(256) void step_rows_kernel(const StepArgs a) {
         const float* y = which == 0 ? a.Wbase : a.Wprev;
         const long long n = which == 0 ? (long long)a.n_base * a.D : (long long)a.n_prev * a.D;
         double s = 0.0;
-        if (y && ((which == 0 && a.use_base) || (which == 1 && a.use_prev)))
-            for (long long i = threadIdx.x; i < n; i += blockDim.x) { const float d = x[i] - y[i]; s += (double)d * d; }
+        if (y && ((which == 0 && a.use_base) || (which == 1 && a.use_prev))) {
+            // these two blocks are the launch's critical path (38400 elements on 256 threads): four independent strided
+            // chains per thread keep four load pairs in flight; fixed summation order
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            const long long st = blockDim.x;
+            long long i = threadIdx.x;
+            for (; i + 3 * st < n; i += 4 * st) {
+                const float d0 = x[i] - y[i], d1 = x[i + st] - y[i + st], d2 = x[i + 2 * st] - y[i + 2 * st], d3 = x[i + 3 * st] - y[i + 3 * st];
+                s0 += (double)d0 * d0; s1 += (double)d1 * d1; s2 += (double)d2 * d2; s3 += (double)d3 * d3;
+            }
+            for (; i < n; i += st) { const float d = x[i] - y[i]; s0 += (double)d * d; }
+            s = (s0 + s1) + (s2 + s3);
+        }
         s = block_sum(s, red);
         if (threadIdx.x == 0) a.norms[which] = (float)sqrt(s);
         return;
@@ -338,8 +358,20 @@ __global__ __launch_bounds__(256) void step_update_kernel(const StepArgs a) {
     if (a.use_prev && n >= a.n_base && n < a.n_base + a.n_prev) kp = a.norms[1] > 0.f ? a.lmbd_prev / a.norms[1] : 0.f;
     double l1 = 0.0;
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        float g = 0.f;
-        for (int b = 0; b < Bt; ++b) g = fmaf(s_dl[b], a.feat[(size_t)b * D + d], g);
+        // dW[n][d] = sum_b dlogits[b][n] * feat[b][d]: four rows per pass so that four loads are in flight; the partial sums
+        // are added in a fixed order (deterministic)
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+        int b = 0;
+        for (; b + 3 < Bt; b += 4) {
+            const float f0 = a.feat[(size_t)b * D + d], f1 = a.feat[(size_t)(b + 1) * D + d];
+            const float f2 = a.feat[(size_t)(b + 2) * D + d], f3 = a.feat[(size_t)(b + 3) * D + d];
+            g0 = fmaf(s_dl[b], f0, g0);
+            g1 = fmaf(s_dl[b + 1], f1, g1);
+            g2 = fmaf(s_dl[b + 2], f2, g2);
+            g3 = fmaf(s_dl[b + 3], f3, g3);
+        }
+        for (; b < Bt; ++b) g0 = fmaf(s_dl[b], a.feat[(size_t)b * D + d], g0);
+        float g = (g0 + g1) + (g2 + g3);
         const float w = wr[d];
         if (kb != 0.f) g += kb * (w - a.Wbase[(size_t)n * D + d]);
         if (kp != 0.f) g += kp * (w - a.Wprev[(size_t)(n - a.n_base) * D + d]);
