@@ -443,11 +443,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
         }
     }
 
+    struct EpilogueStamp {                  // DIAG=3: cycles from the end of the main loop to the kernel's last instruction
+        float* dst;
+        unsigned long long t0;
+        __device__ ~EpilogueStamp() { if (dst) *dst = (float)(__builtin_amdgcn_s_memtime() - t0); }
+    } epi_stamp{nullptr, 0};
     if (STAMPS && a.stats && !a.raw && lane == 0) {
         const unsigned long long n = __builtin_amdgcn_s_memtime(), rn = __builtin_amdgcn_s_memrealtime();
         float* d = a.stats + ((size_t)blockIdx.x * NW + wid) * 8;
         d[0] = (float)(t_loop - t_begin); d[1] = (float)(n - t_loop); d[2] = (float)t_issue; d[3] = (float)t_mma;
-        d[4] = (float)t_wait; d[5] = (float)t_bar; d[6] = (float)(rn - r_begin); d[7] = (float)step;
+        d[4] = (float)t_wait; d[5] = (float)t_bar; d[6] = (float)(rn - r_begin);
+        epi_stamp.dst = d + 7;              // (slot 7 held the step count before)
+        epi_stamp.t0 = n;
     }
     // ------------------------------------------------------------------ epilogue
     // C layout of a TR x TR tile: column = lane % TR; register r holds row (r&3) + 8*(r>>2) + 4*(lane / TR)

@@ -3,8 +3,8 @@
 
   python tools/diag_conv.py [--batch 256] [--only L3.0.conv2]
 For every layer of tools/bench_conv.py prints the median over waves of: prologue, loop, and inside the loop the cycles
-spent issuing DMAs, in LDS reads + MFMAs, in the end-of-step vmcnt wait and in the barrier, plus the shader clock
-(s_memtime / s_memrealtime x 100 MHz).
+spent issuing DMAs, in LDS reads + MFMAs, in the end-of-step vmcnt wait and in the barrier, the shader clock
+(s_memtime / s_memrealtime x 100 MHz) and the epilogue (end of loop -> last store issued).
 """
 import argparse
 import os
@@ -29,7 +29,7 @@ def main():
     dev = torch.device("cuda:0")
     dt, td = _lib.dtype_code("bf16"), torch.bfloat16
     B = a.batch
-    print("%-24s %8s %8s | %7s %7s %7s %7s | %5s %5s" % ("layer", "prolog", "loop", "issue", "mma", "wait", "barrier", "GHz", "steps"))
+    print("%-24s %8s %8s | %7s %7s %7s %7s | %5s %5s" % ("layer", "prolog", "loop", "issue", "mma", "wait", "barrier", "GHz", "epilog"))
     for name, H, Cin, Cout, k, pool, cin2, count in LAYERS:
         if a.only and a.only not in name:
             continue
@@ -55,7 +55,7 @@ def main():
             run()
         torch.cuda.synchronize()
         st = stamps.view(-1, 8)
-        st = st[st[:, 7] > 0]
+        st = st[st[:, 1] > 0]
         med = st.median(dim=0).values.tolist()
         ghz = (st[:, 0] + st[:, 1]).sum().item() / max(st[:, 6].sum().item(), 1.0) * 0.1
         print("%-24s %8.0f %8.0f | %7.0f %7.0f %7.0f %7.0f | %5.2f %5.0f" % (name[:24], med[0], med[1], med[2], med[3], med[4], med[5], ghz, med[7]))
