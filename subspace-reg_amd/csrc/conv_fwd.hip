@@ -168,6 +168,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
     const int prow = phi - plo;
     const int apieces = (prow + RPP - 1) / RPP;
 
+    // this tile's BN shift / scale into LDS now: fetched at the start of the epilogue they cost a full global-load
+    // latency (several thousand cycles with the memory pipe busy) on every workgroup's critical path
+    float* const s_shift = reinterpret_cast<float*>(smem + 2 * ABUF + NWB * BBUF);
+    float* const s_scale = s_shift + TN;
+    for (int t = tid; t < TN; t += NW * 64) {
+        const int n = n0 + t < a.Cout ? n0 + t : a.Cout - 1;
+        s_shift[t] = (a.raw || !a.shift) ? 0.f : a.shift[n];
+        s_scale[t] = (a.raw || !a.scale) ? 1.f : a.scale[n];
+    }
     // zero rows (index AROWS of each patch buffer) for taps outside the image / rows beyond M
     if (tid < 2 * (ROWB / 16)) {
         const int b = tid / (ROWB / 16), q = tid % (ROWB / 16);
@@ -506,9 +515,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
         float shj[MJ], scj[MJ];
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
-            const int n = n0 + (wave_n * MJ + j) * TR + lr;
-            shj[j] = a.raw ? 0.f : a.shift[n];
-            scj[j] = (a.raw || !a.scale) ? 1.f : a.scale[n];
+            const int nl = (wave_n * MJ + j) * TR + lr;
+            shj[j] = s_shift[nl];
+            scj[j] = s_scale[nl];
         }
 #pragma unroll
         for (int ib = 0; ib < NI; ++ib) {
@@ -548,8 +557,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
             for (int ii = 0; ii < TPB; ++ii)
 #pragma unroll
                 for (int j = 0; j < MJ; ++j) {
-                    const int n = n0 + (wave_n * MJ + j) * TR + lr;
-                    const float sh = a.shift[n], sc = a.scale ? a.scale[n] : 1.f;
+                    const int nl = (wave_n * MJ + j) * TR + lr;
+                    const float sh = s_shift[nl], sc = s_scale[nl];
                     const acc_t& c = acc[ib * TPB + ii][j];
 #pragma unroll
                     for (int q = 0; q < NR / 4; ++q) {
@@ -578,7 +587,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
     for (int j = 0; j < MJ; ++j) {
         const int n = n0 + (wave_n * MJ + j) * TR + lr;
         const bool nv = full || n < a.Cout;
-        const float sc = (a.scale && nv) ? a.scale[n] : 1.f, sh = nv ? a.shift[n] : 0.f;
+        const float sc = s_scale[(wave_n * MJ + j) * TR + lr], sh = s_shift[(wave_n * MJ + j) * TR + lr];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int mb = m0 + (wave_m * MI + i) * TR + 4 * lh;
@@ -636,7 +645,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     using K = KT<T>;
     constexpr int TM = WM * NI * 32, TN = WN * NJ * 32;
     constexpr int ABUF = (AROWS + 1) * K::ROWB, BBUF = TPS * TN * K::ROWB;
-    const size_t lds = 2 * (size_t)ABUF + (size_t)weight_buffers(ABUF, BBUF) * BBUF;
+    const size_t lds = 2 * (size_t)ABUF + (size_t)weight_buffers(ABUF, BBUF) * BBUF + 2 * TN * sizeof(float);   // + shift/scale
     auto kern = conv_fwd_kernel<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AROWS, MINW>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
