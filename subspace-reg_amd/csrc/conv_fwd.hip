@@ -45,9 +45,9 @@
                                  // the 128-row tiles (one workgroup fewer per CU)
 #endif
 #ifndef SUBREG_MIXED_TILES
-#define SUBREG_MIXED_TILES 0     // 1: split a wide layer into a 256-row-tile launch + a 128-row-tile launch for the tail rows
-                                 // (per-CU tile-count model of the tail): -3 % - the dispatcher already back-fills uneven
-                                 // rounds and the second launch waits for the first to drain
+#define SUBREG_MIXED_TILES 0     // 1: the rows of a wide layer's partial last round go to the 128-row kernel on a helper
+                                 // stream, concurrently with the 256-row kernel: -4 % (the event fork/join costs ~20 us per
+                                 // layer; serialised on one stream it was -3 %): the tail is not worth a second launch
 #endif
 #ifndef SUBREG_TM512
 #define SUBREG_TM512 0           // 1: 512-row, 8-wave workgroups for the big wide layers: -10..20 % at 42x42 / 21x21
@@ -743,43 +743,53 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
         // was bound by) and 3 taps per step = a third of the barriers.
         if (!raw && wide_takes_256_rows(a.g.M, Cout)) return launch_shape<__bf16, 2, 5, 8, 1, 3, 608, 704, 2>(a, pool, s);
 #endif
-        auto tiles256 = [&](const ConvArgs& b) {
+        auto tiles256 = [&](const ConvArgs& b, hipStream_t st) {
             // patches of <= 352 rows (W <= 42 unpooled) keep the LDS footprint at two workgroups per CU with room to spare
-            const int rc = launch_shape<__bf16, 2, 5, 4, 1, 1, 352, 432, 2>(b, pool, s);
-            return rc != SUBREG_EUNSUPPORTED ? rc : launch_shape<__bf16, 2, 5, 4, 1, 1, 560, 560, 2>(b, pool, s);
+            const int rc = launch_shape<__bf16, 2, 5, 4, 1, 1, 352, 432, 2>(b, pool, st);
+            return rc != SUBREG_EUNSUPPORTED ? rc : launch_shape<__bf16, 2, 5, 4, 1, 1, 560, 560, 2>(b, pool, st);
         };
-        auto tiles128 = [&](const ConvArgs& b) {
+        auto tiles128 = [&](const ConvArgs& b, hipStream_t st) {
             // 128-row tiles.  If they all fit one per CU (<= 256 workgroups) stage 3 taps per step (84 KB LDS, covers the
             // LDS-DMA latency at that occupancy); otherwise 1 tap per step and 3 workgroups per CU.
             if (((b.m_rows + 127) / 128) * nt > 256) {
-                const int rc = launch_shape<__bf16, 1, 5, 4, 1, 1, 192, 224, 2>(b, pool, s);     // 224: 42x42 maps, still 3 per CU
-                return rc != SUBREG_EUNSUPPORTED ? rc : launch_shape<__bf16, 1, 5, 4, 1, 1, 432, 432, 2>(b, pool, s);
+                const int rc = launch_shape<__bf16, 1, 5, 4, 1, 1, 192, 224, 2>(b, pool, st);    // 224: 42x42 maps, still 3 per CU
+                return rc != SUBREG_EUNSUPPORTED ? rc : launch_shape<__bf16, 1, 5, 4, 1, 1, 432, 432, 2>(b, pool, st);
             }
-            return launch_shape<__bf16, 1, 5, 4, 1, 3, 192, 432, 2>(b, pool, s);
+            return launch_shape<__bf16, 1, 5, 4, 1, 3, 192, 432, 2>(b, pool, st);
         };
-        if (raw || !SUBREG_MIXED_TILES) return wide_takes_256_rows(a.g.M, Cout) ? tiles256(a) : tiles128(a);
-        // Tail quantisation: a CU works through ceil(tiles / 256) tiles, so e.g. 882 tiles of 256 rows cost 4 tile-times
-        // where 3.45 are needed.  Cover the first k tiles per CU with 256-row tiles and the remaining rows with 128-row
-        // tiles (half the work each, ~10 % less efficient: 0.55 tile-times): two launches over disjoint row ranges.
-        const int M = a.g.M, mt = (M + 255) / 256;
-        const long long T = (long long)mt * nt;
-        double best = (double)((T + 255) / 256);
-        int best_mt1 = mt;                                            // m-tiles given to the 256-row launch
-        const long long k0 = T / 256;
-        for (long long k = k0; k >= 0 && k >= k0 - 1; --k) {
-            long long mt1 = k * 256 / nt;
-            if (mt1 * 256 > M) mt1 = M / 256;
-            const long long rows2 = M - mt1 * 256, t128 = ((rows2 + 127) / 128) * nt;
-            const double cost = (double)((mt1 * nt + 255) / 256) + 0.55 * (double)((t128 + 255) / 256);
-            if (cost < best - 1e-9) { best = cost; best_mt1 = (int)mt1; }
+        if (!wide_takes_256_rows(a.g.M, Cout)) return tiles128(a, s);
+#if SUBREG_MIXED_TILES
+        // Tail quantisation: T tiles of 256 rows on 512 resident slots run ceil(T / 512) rounds (882 tiles: 2 rounds for
+        // 1.72 rounds of work).  Give the whole rounds to the 256-row kernel and the rows of the partial round to the
+        // 128-row kernel, launched on a helper stream so that its workgroups fill the slots the first kernel's last
+        // round leaves free (event fork / join around it: ordered with the caller's stream, no host synchronisation).
+        if (!raw) {
+            const int M = a.g.M, mt = (M + 255) / 256;
+            const long long T = (long long)mt * nt, rem = T % 512;
+            const long long mt1 = (T / 512) * 512 / nt;               // whole m-tiles of the full rounds
+            if (rem != 0 && rem <= 448 && mt1 > 0 && mt1 < mt) {
+                static hipStream_t side = nullptr;
+                static hipEvent_t fork = nullptr, join = nullptr;
+                if (!side) {
+                    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
+                        hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess)
+                        return SUBREG_EHIP;
+                }
+                ConvArgs a1 = a, a2 = a;
+                a1.m_rows = (int)mt1 * 256;
+                a2.m_base = a1.m_rows; a2.m_rows = M - a1.m_rows;
+                if (hipEventRecord(fork, s) != hipSuccess || hipStreamWaitEvent(side, fork, 0) != hipSuccess) return SUBREG_EHIP;
+                int rc = tiles256(a1, s);
+                if (rc != SUBREG_OK) return rc;
+                rc = tiles128(a2, side);
+                if (rc != SUBREG_OK) return rc;
+                if (hipEventRecord(join, side) != hipSuccess || hipStreamWaitEvent(s, join, 0) != hipSuccess) return SUBREG_EHIP;
+                return SUBREG_OK;
+            }
         }
-        if (best_mt1 >= mt) return tiles256(a);
-        if (best_mt1 == 0) return tiles128(a);
-        ConvArgs a1 = a, a2 = a;
-        a1.m_rows = best_mt1 * 256;
-        a2.m_base = a1.m_rows; a2.m_rows = M - a1.m_rows;
-        const int rc = tiles256(a1);
-        return rc != SUBREG_OK ? rc : tiles128(a2);
+#endif
+        return tiles256(a, s);
     }
     return wide ? launch_shape<float, 2, 5, 2, 1, 1, 304, 408, 1>(a, pool, s) : launch_shape<float, 2, 2, 2, 1, 1, 304, 408, 1>(a, pool, s);
 }
