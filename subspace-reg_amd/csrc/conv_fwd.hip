@@ -682,14 +682,22 @@ static int launch_shape(const ConvArgs& a, bool pool, hipStream_t s) {
                 : launch_rows<T, NI, NJ, WM, WN, 1, 1, false, TM, AR_L, MINW>(a, s);
 }
 
-// bf16, Cout % 160 == 0: 256-row tiles when they fill the chip (256 CUs x 2 resident workgroups), else 128-row tiles
-static bool wide_takes_256_rows(int M, int Cout) { return (long long)((M + 255) / 256) * (Cout / 160) >= 384; }
+// bf16, Cout % 160 == 0: 256-row tiles (2 workgroups per CU: 512 slots) or 128-row tiles (3 per CU: 768 slots).
+// Measured over batch 64..1125 (tools/bench_conv.py with either tiling forced): on the 21x21 and smaller maps a round of
+// 128-row tiles costs ~0.62 of a round of 256-row tiles, so the cheaper of ceil(T256/512) and 0.62*ceil(T128/768) wins
+// (e.g. 548 tiles of 256 rows = 2 rounds lose to 1094 tiles of 128 rows = 2 x 0.62); on 42x42 maps the halo (2 x 43 rows
+// per tile) makes the small tile as slow or slower (pooled: 1.2x), so those keep 256 rows whenever they fill the chip.
+static bool wide_takes_256_rows(int M, int Cout, int W) {
+    const long long nt = Cout / 160, t256 = (long long)((M + 255) / 256) * nt, t128 = (long long)((M + 127) / 128) * nt;
+    if (W > 21) return t256 >= 384;
+    return (double)((t256 + 511) / 512) <= 0.62 * (double)((t128 + 767) / 768);
+}
 
 // rows of stats partials the raw mode writes for a given problem = m-tiles x waves along M of the configuration that
 // subreg_conv_fwd picks for it (the caller sizes the buffer and calls subreg_bn_train_finalize with this)
-static int stats_rows_for(int dtype, int M, int Cout) {
+static int stats_rows_for(int dtype, int M, int Cout, int W) {
     if (dtype != SUBREG_BF16) return ((M + 127) / 128) * 2;          // f32: 128-row tiles, 2 waves along M
-    const int tm = (Cout % 160 == 0 && !wide_takes_256_rows(M, Cout)) ? 128 : 256;
+    const int tm = (Cout % 160 == 0 && !wide_takes_256_rows(M, Cout, W)) ? 128 : 256;
     return ((M + tm - 1) / tm) * 4;
 }
 
@@ -698,7 +706,7 @@ static int stats_rows_for(int dtype, int M, int Cout) {
 using namespace subreg;
 
 extern "C" int subreg_conv_stats_rows(int dtype, int B, int H, int W, int Cout) {
-    return stats_rows_for(dtype, B * H * W, Cout);
+    return stats_rows_for(dtype, B * H * W, Cout, W);
 }
 
 extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* shift,
@@ -741,7 +749,7 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
         // big maps: 512-row tiles, 8 waves, one workgroup per CU.  Same waves per SIMD as two 256-row workgroups, but
         // every weight tile staged from L2 feeds twice the rows (the L2 -> LDS weight stream is what the 256-row tiling
         // was bound by) and 3 taps per step = a third of the barriers.
-        if (!raw && wide_takes_256_rows(a.g.M, Cout)) return launch_shape<__bf16, 2, 5, 8, 1, 3, 608, 704, 2>(a, pool, s);
+        if (!raw && wide_takes_256_rows(a.g.M, Cout, W)) return launch_shape<__bf16, 2, 5, 8, 1, 3, 608, 704, 2>(a, pool, s);
 #endif
         auto tiles256 = [&](const ConvArgs& b, hipStream_t st) {
             // patches of <= 352 rows (W <= 42 unpooled) keep the LDS footprint at two workgroups per CU with room to spare
@@ -757,7 +765,7 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
             }
             return launch_shape<__bf16, 1, 5, 4, 1, 3, 192, 432, 2>(b, pool, st);
         };
-        if (!wide_takes_256_rows(a.g.M, Cout)) return tiles128(a, s);
+        if (!wide_takes_256_rows(a.g.M, Cout, W)) return tiles128(a, s);
 #if SUBREG_MIXED_TILES
         // Tail quantisation: T tiles of 256 rows on 512 resident slots run ceil(T / 512) rounds (882 tiles: 2 rounds for
         // 1.72 rounds of work).  Give the whole rounds to the 256-row kernel and the rows of the partial round to the
