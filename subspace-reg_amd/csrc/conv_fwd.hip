@@ -739,6 +739,9 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
     if (dtype == SUBREG_BF16) {
         if (!wide) {
             // Cout = 64 (layer 1): the unpooled convs stage 3 taps per step (64x64 wave tiles are barrier-bound at one)
+            // 1x1 (the K=32 first layer): a streaming GEMM, 128-row tiles keep more workgroups in flight (-6 % vs 256 rows);
+            // train mode keeps 256 rows (subreg_conv_stats_rows does not know the kernel size)
+            if (a.g.taps == 1 && !raw) return launch_shape<__bf16, 1, 2, 4, 1, 1, 432, 560, 2>(a, pool, s);
             if (a.g.taps == 1) return launch_shape<__bf16, 2, 2, 4, 1, 1, 432, 560, 2>(a, pool, s);
             if (!pool || raw) return launch_rows<__bf16, 2, 2, 4, 1, 9, 3, false, 432, 560, 2>(a, s);
             // pooled conv3 (+ fused K=32 shortcut): 256-row tiles with ONE tap per step measured 16-19 % faster than the
