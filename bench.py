@@ -114,7 +114,12 @@ def cpu_baseline(args, n_base):
         n = min(512, max(n * 2, int(n * args.cpu_seconds / max(t, 1e-3) * 0.8)))
     img_s = n / t
     avg_imgs = np.mean([images_per_episode(s, args.epochs, n_base) for s in range(8)]) + n_base / 8.0   # + run-start base eval
-    return {"value": img_s / avg_imgs, "unit": "episodes/s", "cores": os.cpu_count(), "kind": "port",
+    try:                                                      # threads the oracle's BLAS calls actually ran on
+        from threadpoolctl import threadpool_info
+        threads = max([int(p.get("num_threads", 1)) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    return {"value": img_s / avg_imgs, "unit": "episodes/s", "cores": threads, "kind": "port",
             "sample": "NumPy oracle eval-mode forward of %d 84x84 images in %.1f s (%.1f img/s), scaled by the mean "
                       "%.0f image-forwards per episode" % (n, t, img_s, avg_imgs)}
 
