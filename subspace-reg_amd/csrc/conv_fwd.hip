@@ -49,6 +49,9 @@
                                  // stream, concurrently with the 256-row kernel: -4 % (the event fork/join costs ~20 us per
                                  // layer; serialised on one stream it was -3 %): the tail is not worth a second launch
 #endif
+#ifndef SUBREG_WAVES_K2
+#define SUBREG_WAVES_K2 1        // 1: grids of <= 256 workgroups (128-row tiles, 3 taps per step) put two waves on every tile
+#endif
 #ifndef SUBREG_TM512
 #define SUBREG_TM512 0           // 1: 512-row, 8-wave workgroups for the big wide layers: -10..20 % at 42x42 / 21x21
 #endif
@@ -125,10 +128,14 @@ __device__ __forceinline__ void mma_step<float>(const uint4& a, const uint4& b, 
 
 // NI x NJ 32x32 accumulator blocks per wave (held as TR x TR MFMA tiles); WAVES_M x WAVES_N waves per workgroup; TPS taps staged per step
 // (one barrier per step); MINW = minimum waves per SIMD the register allocation must allow.
-template <typename T, int NI, int NJ, int WAVES_M, int WAVES_N, int TAPS, int TPS, bool POOL, int AROWS, int MINW>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(const ConvArgs a) {
+// WK = 2: every output tile is owned by TWO waves that take alternate k-steps of each step and add their accumulators
+// through LDS at the end - twice the waves per CU for grids that cannot fill the chip (one 4-wave workgroup per CU leaves
+// one wave per SIMD and nothing to hide its DMA issue, waits and barriers behind).
+template <typename T, int NI, int NJ, int WAVES_M, int WAVES_N, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1>
+__global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kernel(const ConvArgs a) {
     using K = KT<T>;
-    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int NWMN = WAVES_M * WAVES_N, NW = NWMN * WK;
+    static_assert(WK == 1 || WK == 2, "one or two waves per output tile");
     constexpr int TM = WAVES_M * NI * 32, TN = WAVES_N * NJ * 32;
     constexpr int SLOTS = K::SLOTS, ROWB = K::ROWB, ELEM = K::ELEM;
     constexpr int RPP = 1024 / ROWB;                     // rows per 1-KiB DMA piece (16 bf16 / 8 f32)
@@ -148,7 +155,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wid / WAVES_N, wave_n = wid % WAVES_N;
+    const int wave_k = wid / NWMN, wmn = wid % NWMN;
+    const int wave_m = wmn / WAVES_N, wave_n = wmn % WAVES_N;
     const int lr = lane % TR, lh = lane / TR;            // column (A: row) within an MFMA tile, k-slot / row group
     const ConvGeom g = a.g;
     // XCD-aware tile order (MI355X: 8 XCDs with private L2s, workgroups dealt round-robin): give each XCD one
@@ -345,6 +353,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
             constexpr int NK = TPS * KSTEPS;
             constexpr int KX = 16 * LG;                               // address XOR per k-step
             constexpr bool SWP = NI * NJ * 16 + 2 * (MI + MJ) * 4 + 40 <= 200;
+            static_assert(WK == 1 || !SWP, "the k-step split is implemented on the ring-pipelined path");
             constexpr int NGRP = SWP ? NK : NK * MJ;                  // MFMA groups of a step (DMA slots go between them)
             constexpr int SPG = (NS + NGRP - 1) / NGRP;               // slots per group
             auto after_group = [&](int gi) {
@@ -403,6 +412,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
 #pragma unroll
                 for (int kk = 0; kk < NK; ++kk) {
                     if (ph1 && kk >= KSTEPS) continue;
+                    if (WK > 1 && ((step * NK + kk) % WK) != wave_k) continue;    // the partner wave's k-step
                     const int tt = kk / KSTEPS, s = kk % KSTEPS;
                     uint4 fa[MI], fb[3];
                     auto rd_a = [&](int i) {
@@ -452,6 +462,32 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
         }
     }
 
+    if constexpr (WK > 1) {
+        // add the partner wave's accumulators: [tile*NR + r][lane] floats through the (now idle) staging LDS, as many
+        // tiles per round as fit; then only the first wave of each pair runs the epilogue
+        constexpr int TILES = MI * MJ, AVAIL = (2 * ABUF + NWB * BBUF) / (NWMN * 64 * 4) / NR;
+        constexpr int TPR = AVAIL < TILES ? AVAIL : TILES;
+        static_assert(TPR >= 1, "no LDS for the accumulator exchange");
+        float* const red = reinterpret_cast<float*>(smem) + (size_t)wmn * (TPR * NR * 64);
+#pragma unroll
+        for (int t0 = 0; t0 < TILES; t0 += TPR) {
+            if (wave_k == 1) {
+#pragma unroll
+                for (int t = t0; t < t0 + TPR && t < TILES; ++t)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) red[((t - t0) * NR + r) * 64 + lane] = acc[t / MJ][t % MJ][r];
+            }
+            __syncthreads();
+            if (wave_k == 0) {
+#pragma unroll
+                for (int t = t0; t < t0 + TPR && t < TILES; ++t)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) acc[t / MJ][t % MJ][r] += red[((t - t0) * NR + r) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (wave_k != 0) return;
+    }
     struct EpilogueStamp {                  // DIAG=3: cycles from the end of the main loop to the kernel's last instruction
         float* dst;
         unsigned long long t0;
@@ -472,7 +508,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
     const T* const res = reinterpret_cast<const T*>(a.res);
     const bool full = m0 + TM <= g.M && n0 + TN <= a.Cout;            // no ragged edge in this tile
     constexpr int TPB = 32 / TR;                                      // MFMA tiles per 32-row slab
-    constexpr bool SLAB_FITS = NW * 32 * (NJ * 32 * ELEM + 16) <= 2 * ABUF + NWB * BBUF;   // epilogue slabs reuse the staging LDS
+    constexpr bool SLAB_FITS = NWMN * 32 * (NJ * 32 * ELEM + 16) <= 2 * ABUF + NWB * BBUF;   // epilogue slabs reuse the staging LDS
     const bool raw_slab = !POOL && SLAB_FITS && full;                 // raw tile written by the slab path below
     if (a.raw) {
 #pragma unroll
@@ -511,7 +547,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
         // write it back as whole 16-byte vectors, consecutive lanes on consecutive addresses of a pixel row.  (The
         // direct path below needs one 2/4-byte store per accumulator register and dominated short-K layers.)
         constexpr int TNW = NJ * 32, RS = TNW * ELEM + 16, VPR = TNW * ELEM / 16, NV = 32 * VPR;
-        char* const slab = smem + wid * (32 * RS);               // all waves are past the last step's barrier
+        char* const slab = smem + wmn * (32 * RS);               // all waves are past the last step's barrier
         float shj[MJ], scj[MJ];
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
@@ -550,7 +586,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_fwd_kernel(c
         // Full pooled tile: 2x2 max in registers (4 consecutive accumulator registers = one window), the 8 pooled rows
         // of every 32-row slab staged through LDS and written as whole 16-byte vectors.
         constexpr int TNW = NJ * 32, RS = TNW * ELEM + 16, VPR = TNW * ELEM / 16, NV = 8 * VPR;
-        char* const slab = smem + wid * (32 * RS);
+        char* const slab = smem + wmn * (32 * RS);
 #pragma unroll
         for (int ib = 0; ib < NI; ++ib) {
 #pragma unroll
@@ -640,13 +676,13 @@ static int worst_patch_rows(const ConvGeom& g, int TM, int m_base, int m_rows) {
     return worst;
 }
 
-template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AROWS, int MINW>
+template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1>
 static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     using K = KT<T>;
     constexpr int TM = WM * NI * 32, TN = WN * NJ * 32;
     constexpr int ABUF = (AROWS + 1) * K::ROWB, BBUF = TPS * TN * K::ROWB;
     const size_t lds = 2 * (size_t)ABUF + (size_t)weight_buffers(ABUF, BBUF) * BBUF + 2 * TN * sizeof(float);   // + shift/scale
-    auto kern = conv_fwd_kernel<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AROWS, MINW>;
+    auto kern = conv_fwd_kernel<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AROWS, MINW, WK>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -655,31 +691,31 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
         attr_done = true;
     }
     dim3 grid(((a.m_rows + TM - 1) / TM) * ((a.Cout + TN - 1) / TN));   // 1-D: the kernel decodes (m-tile, n-tile) itself
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * WK * 64), lds, stream, a);
     return launch_status();
 }
 
 // AR_S / AR_L: small and large LDS patch capacities (rows); the small one allows more workgroups per CU
-template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AR_S, int AR_L, int MINW>
+template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AR_S, int AR_L, int MINW, int WK = 1>
 static int launch_rows(const ConvArgs& a, hipStream_t s) {
     if ((long long)a.g.M * a.Cout >= (1LL << 31) || (long long)a.g.npix * a.Cout >= (1LL << 31)) return SUBREG_EUNSUPPORTED;
     const int worst = worst_patch_rows<POOL>(a.g, WM * NI * 32, a.m_base, a.m_rows);
-    if (worst <= AR_S) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_S, MINW>(a, s);
-    if (worst <= AR_L) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_L, MINW>(a, s);
+    if (worst <= AR_S) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_S, MINW, WK>(a, s);
+    if (worst <= AR_L) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_L, MINW, WK>(a, s);
     return SUBREG_EUNSUPPORTED;      // image too wide for the LDS patch
 }
 
 // TPS3: taps staged per step for the 3x3 case (1x1 convs always stage their single tap)
-template <typename T, int NI, int NJ, int WM, int WN, int TPS3, int AR_S, int AR_L, int MINW>
+template <typename T, int NI, int NJ, int WM, int WN, int TPS3, int AR_S, int AR_L, int MINW, int WK = 1>
 static int launch_shape(const ConvArgs& a, bool pool, hipStream_t s) {
     if (a.g.taps == 9) {
-        return pool ? launch_rows<T, NI, NJ, WM, WN, 9, TPS3, true, AR_S, AR_L, MINW>(a, s)
-                    : launch_rows<T, NI, NJ, WM, WN, 9, TPS3, false, AR_S, AR_L, MINW>(a, s);
+        return pool ? launch_rows<T, NI, NJ, WM, WN, 9, TPS3, true, AR_S, AR_L, MINW, WK>(a, s)
+                    : launch_rows<T, NI, NJ, WM, WN, 9, TPS3, false, AR_S, AR_L, MINW, WK>(a, s);
     }
     // 1x1: the patch is exactly the tile's own rows (no halo) => small patch buffers, more workgroups per CU
     constexpr int TM = WM * NI * 32;
-    return pool ? launch_rows<T, NI, NJ, WM, WN, 1, 1, true, AR_S, AR_L, MINW>(a, s)
-                : launch_rows<T, NI, NJ, WM, WN, 1, 1, false, TM, AR_L, MINW>(a, s);
+    return pool ? launch_rows<T, NI, NJ, WM, WN, 1, 1, true, AR_S, AR_L, MINW, WK>(a, s)
+                : launch_rows<T, NI, NJ, WM, WN, 1, 1, false, TM, AR_L, MINW, WK>(a, s);
 }
 
 // bf16, Cout % 160 == 0: 256-row tiles (2 workgroups per CU: 512 slots) or 128-row tiles (3 per CU: 768 slots).
@@ -767,7 +803,11 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
                 const int rc = launch_shape<__bf16, 1, 5, 4, 1, 1, 192, 224, 2>(b, pool, st);    // 224: 42x42 maps, still 3 per CU
                 return rc != SUBREG_EUNSUPPORTED ? rc : launch_shape<__bf16, 1, 5, 4, 1, 1, 432, 432, 2>(b, pool, st);
             }
+#if SUBREG_WAVES_K2
+            return launch_shape<__bf16, 1, 5, 4, 1, 3, 192, 432, 2, 2>(b, pool, st);      // two waves per tile (8 waves per CU)
+#else
             return launch_shape<__bf16, 1, 5, 4, 1, 3, 192, 432, 2>(b, pool, st);
+#endif
         };
         if (!wide_takes_256_rows(a.g.M, Cout, W)) return tiles128(a, s);
 #if SUBREG_MIXED_TILES
