@@ -133,6 +133,9 @@ long long subreg_backbone_stats_floats(const subreg_backbone_desc* d, int B, int
 /* (re)pack every conv weight: the raw copy, and the copy with the eval-mode BN scale folded in; writes shift[].
  * Call after the weights or the BN statistics changed. */
 int subreg_backbone_fold(const subreg_backbone_desc* d, void* stream);
+/* only the raw packed copies (`w`): all a train-mode forward needs after an optimiser step (the folded copies and the
+ * eval-mode scale/shift stay stale until the next subreg_backbone_fold) */
+int subreg_backbone_pack_raw(const subreg_backbone_desc* d, void* stream);
 /* x NCHW fp32 [B,3,H,W] -> feat fp32 [B][C_last].  stage_out[i] (optional, may be NULL) receives block i's
  * output as NCHW fp32 (is_feat=True, :189-190). */
 int subreg_backbone_forward(const subreg_backbone_desc* d, const float* x_nchw, int B, int H, int W, float* feat,
@@ -164,6 +167,12 @@ int subreg_block_tail_bwd(const void* grad_out, const unsigned char* keep_mask, 
                           const float* res_shift, void* dv, int B, int H, int W, int C, int pool, int dtype, void* stream);
 int subreg_avgpool_bwd(const float* dfeat, void* dx, int B, int H, int W, int C, int dtype, void* stream);
 /* torch.optim.SGD step (train_supervised.py:133-136): d = g + wd*p; buf = first ? d : m*buf + d; p -= lr*buf */
+/* the same update for n tensors in ONE launch: params / bufs are DEVICE arrays of n pointers, grad_offsets[n] element offsets
+ * of every tensor's gradient inside the flat buffer grad_base, ends[n] the inclusive prefix sums of the tensor sizes
+ * (device), total = ends[n-1] (host) */
+int subreg_sgd_momentum_multi(float* const* params, float* const* momentum_bufs, const float* grad_base,
+                              const long long* grad_offsets, const long long* ends, int n, long long total, float lr,
+                              float momentum, float weight_decay, int first_step, void* stream);
 int subreg_sgd_momentum(float* param, const float* grad, float* momentum_buf, long long n, float lr, float momentum,
                         float weight_decay, int first_step, void* stream);
 

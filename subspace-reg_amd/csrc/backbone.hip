@@ -97,6 +97,19 @@ extern "C" int subreg_backbone_fold(const subreg_backbone_desc* d, void* stream)
     return SUBREG_OK;
 }
 
+extern "C" int subreg_backbone_pack_raw(const subreg_backbone_desc* d, void* stream) {
+    SUBREG_CHECK_ARG(d && d->blocks && d->n_blocks > 0);
+    for (int i = 0; i < d->n_blocks; ++i) {
+        const subreg_block_desc& b = d->blocks[i];
+        const subreg_conv_desc* cs[4] = {&b.conv1, &b.conv2, &b.conv3, &b.down};
+        for (const subreg_conv_desc* c : cs)
+            if (c->w)
+                TRY(subreg_pack_conv_weight(c->w_oihw, nullptr, const_cast<void*>(c->w), c->cout, c->cin_raw, c->ksize_raw,
+                                            c->cin_raw == 3 ? 1 : 0, d->dtype, stream));
+    }
+    return SUBREG_OK;
+}
+
 extern "C" int subreg_backbone_forward(const subreg_backbone_desc* d, const float* x_nchw, int B, int H, int W, float* feat,
                                        float* const* stage_out, int flags, void* stream) {
     SUBREG_CHECK_ARG(d && d->blocks && d->n_blocks > 0 && x_nchw && feat && B > 0 && H > 0 && W > 0);

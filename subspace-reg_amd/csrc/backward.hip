@@ -528,6 +528,26 @@ __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restri
     p[i] -= lr * b;
 }
 
+// n tensors in one launch: thread i finds its tensor by binary search in the prefix sums
+__global__ void sgd_momentum_multi_kernel(float* const* __restrict__ params, float* const* __restrict__ bufs,
+                                          const float* __restrict__ gbase, const long long* __restrict__ goff,
+                                          const long long* __restrict__ ends, int n, float lr, float momentum, float wd, int first) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ends[n - 1]) return;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (i < ends[mid]) hi = mid; else lo = mid + 1;
+    }
+    const long long j = i - (lo ? ends[lo - 1] : 0);
+    float* p = params[lo];
+    float* b = bufs[lo];
+    const float d = gbase[goff[lo] + j] + wd * p[j];
+    const float m = first ? d : momentum * b[j] + d;
+    b[j] = m;
+    p[j] -= lr * m;
+}
+
 }  // namespace subreg
 
 using namespace subreg;
@@ -674,6 +694,15 @@ extern "C" int subreg_pack_conv_weight_dgrad(const float* w_oihw, void* out, int
     const size_t n = (size_t)Cout * Cin * ksize * ksize;
     DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_dgrad_kernel<float>, bw_blocks(n), BW_THREADS, 0, s, w_oihw, (float*)out, Cout, Cin, ksize),
                hipLaunchKernelGGL(pack_weight_dgrad_kernel<__bf16>, bw_blocks(n), BW_THREADS, 0, s, w_oihw, (__bf16*)out, Cout, Cin, ksize));
+    return launch_status();
+}
+
+extern "C" int subreg_sgd_momentum_multi(float* const* params, float* const* momentum_bufs, const float* grad_base,
+                                         const long long* grad_offsets, const long long* ends, int n, long long total, float lr,
+                                         float momentum, float weight_decay, int first_step, void* stream) {
+    SUBREG_CHECK_ARG(params && momentum_bufs && grad_base && grad_offsets && ends && n > 0 && total > 0);
+    hipLaunchKernelGGL(sgd_momentum_multi_kernel, bw_blocks((size_t)total), BW_THREADS, 0, (hipStream_t)stream, params, momentum_bufs,
+                       grad_base, grad_offsets, ends, n, lr, momentum, weight_decay, first_step);
     return launch_status();
 }
 

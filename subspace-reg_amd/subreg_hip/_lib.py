@@ -108,6 +108,8 @@ SIGNATURES = {
     "subreg_backbone_ws_bytes": (_L, [C.POINTER(BackboneDesc), _I, _I, _I]),
     "subreg_backbone_stats_floats": (_L, [C.POINTER(BackboneDesc), _I, _I, _I]),
     "subreg_backbone_fold": (_I, [C.POINTER(BackboneDesc), _P]),
+    "subreg_backbone_pack_raw": (_I, [C.POINTER(BackboneDesc), _P]),
+    "subreg_sgd_momentum_multi": (_I, [_P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _I, _P]),
     "subreg_backbone_forward": (_I, [C.POINTER(BackboneDesc), _P, _I, _I, _I, _P, C.POINTER(_P), _I, _P]),
     "subreg_linear_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "subreg_linear_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

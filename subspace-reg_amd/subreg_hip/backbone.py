@@ -128,6 +128,13 @@ class HipBackbone:
             _lib.check(self.lib.subreg_backbone_fold(C.byref(self._desc), _lib.stream_ptr()), "backbone_fold")
             self._fold_versions = ver
 
+    def refresh_raw(self):
+        """After an optimiser step in training: re-pack only the raw conv weights (all a train-mode forward reads); the
+        BN-folded copies are left stale and rebuilt by the next refresh()."""
+        self._bind_pointers()
+        _lib.check(self.lib.subreg_backbone_pack_raw(C.byref(self._desc), _lib.stream_ptr()), "backbone_pack_raw")
+        self._fold_versions = None
+
     def _ensure_workspace(self, B, H, W):
         cb, ch, cw = self._cap
         if B <= cb and H == ch and W == cw:

@@ -109,7 +109,7 @@ class BackboneTrainFn(torch.autograd.Function):
     def forward(ctx, x, hb, masks, names, *params):
         B, _, H, W = x.shape
         x = x.contiguous().float()
-        hb.refresh()
+        hb.refresh_raw()                     # weights moved since the last step; the eval-mode folded copies are not needed here
         for i in range(len(hb.nbt)):
             hb.nbt[i] += 1
         stash = getattr(hb, "_train_stash", None)
@@ -147,6 +147,7 @@ class SGD:
         # one param group, torch-style: adjust_learning_rate (util.py:45-51) writes param_groups[i]['lr']
         self.param_groups = [{"params": self.params, "lr": lr}]
         self.bufs = [None] * len(self.params)
+        self._multi = {}                     # device pointer tables of the fused update, per parameter group
 
     @property
     def lr(self):
@@ -161,13 +162,42 @@ class SGD:
             p.grad = None
 
     def step(self):
+        """One fused launch for all parameters whose gradients are views of ONE flat buffer (what BackboneTrainFn.backward
+        returns for the backbone: 66 tensors), the per-tensor kernel for the rest (the classifier)."""
         lib = _lib.load()
-        for i, p in enumerate(self.params):
-            if p.grad is None:
-                continue
-            first = self.bufs[i] is None
-            if first:
+        live = [(i, p) for i, p in enumerate(self.params) if p.grad is not None]
+        first_any = [self.bufs[i] is None for i, _p in live]
+        for i, p in live:
+            if self.bufs[i] is None:
                 self.bufs[i] = torch.empty_like(p.data)
-            g = p.grad.contiguous()
-            _lib.check(lib.subreg_sgd_momentum(_lib.ptr(p.data), _lib.ptr(g), _lib.ptr(self.bufs[i]), p.numel(), self.lr,
-                                               self.momentum, self.weight_decay, int(first), _lib.stream_ptr()), "sgd_momentum")
+        groups = {}
+        for (i, p), first in zip(live, first_any):
+            g = p.grad
+            base = g._base if (g._base is not None and g.is_contiguous() and g.dtype == torch.float32) else None
+            groups.setdefault((id(base) if base is not None else None, first), []).append((i, p, base))
+        for (bid, first), items in groups.items():
+            if bid is None or len(items) < 4:
+                for i, p, _b in items:
+                    g = p.grad.contiguous()
+                    _lib.check(lib.subreg_sgd_momentum(_lib.ptr(p.data), _lib.ptr(g), _lib.ptr(self.bufs[i]), p.numel(), self.lr,
+                                                       self.momentum, self.weight_decay, int(first), _lib.stream_ptr()), "sgd_momentum")
+                continue
+            base = items[0][2]
+            key = tuple(i for i, _p, _b in items)
+            cache = self._multi.get(key)
+            if cache is None or cache["ptrs"] != [p.data.data_ptr() for _i, p, _b in items]:
+                dev = base.device
+                sizes = [p.numel() for _i, p, _b in items]
+                cache = {"ptrs": [p.data.data_ptr() for _i, p, _b in items],
+                         "params": torch.tensor([p.data.data_ptr() for _i, p, _b in items], dtype=torch.int64, device=dev),
+                         "bufs": torch.tensor([self.bufs[i].data_ptr() for i, _p, _b in items], dtype=torch.int64, device=dev),
+                         "ends": torch.tensor(np.cumsum(sizes), dtype=torch.int64, device=dev), "total": int(sum(sizes))}
+                self._multi[key] = cache
+            offs = [(p.grad.data_ptr() - base.data_ptr()) // 4 for _i, p, _b in items]
+            if cache.get("offs_host") != offs:
+                cache["offs_host"] = offs
+                cache["offs"] = torch.tensor(offs, dtype=torch.int64, device=base.device)
+            _lib.check(lib.subreg_sgd_momentum_multi(_lib.ptr(cache["params"]), _lib.ptr(cache["bufs"]), _lib.ptr(base),
+                                                     _lib.ptr(cache["offs"]), _lib.ptr(cache["ends"]), len(items), cache["total"],
+                                                     self.lr, self.momentum, self.weight_decay, int(first), _lib.stream_ptr()),
+                       "sgd_momentum_multi")

@@ -249,3 +249,31 @@ def test_pretrain_driver_runs_the_reference_routine(tmp_path):
     net2 = ck.model_from_checkpoint(last, "resnet18", 10, argparse.Namespace(no_dropblock=True, hip_dtype="bf16")).cuda()
     for (k, a), (_k, b) in zip(net.state_dict().items(), net2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_fused_multi_tensor_sgd_matches_oracle_over_two_steps():
+    """subreg_sgd_momentum_multi (gradients = views of one flat buffer, as BackboneTrainFn.backward returns them) against the
+    oracle's torch.optim.SGD restatement: first step (buffer = d) and second step (momentum)."""
+    from subreg_hip.train import SGD
+    rs = np.random.RandomState(9)
+    shapes = [(64, 3, 3, 3), (64,), (64,), (160, 64, 3, 3), (7,), (320, 160, 1, 1)]
+    ps = [torch.nn.Parameter(torch.from_numpy(rs.standard_normal(s).astype(np.float32)).cuda()) for s in shapes]
+    opt = SGD(ps, lr=0.05, momentum=0.9, weight_decay=5e-4)
+    ref_p = [p.detach().cpu().numpy().astype(np.float64) for p in ps]
+    ref_b = [None] * len(ps)
+    for step in range(2):
+        sizes = [int(np.prod(s)) for s in shapes]
+        flat = torch.from_numpy(rs.standard_normal(sum(sizes)).astype(np.float32)).cuda()
+        off = 0
+        for p, n, s in zip(ps, sizes, shapes):
+            p.grad = flat[off:off + n].view(s)
+            off += n
+        opt.step()
+        off = 0
+        for i, (n, s) in enumerate(zip(sizes, shapes)):
+            g = flat[off:off + n].view(s).cpu().numpy().astype(np.float64)
+            ref_p[i], ref_b[i] = br.sgd_momentum_step(ref_p[i], g, ref_b[i], 0.05, 0.9, 5e-4)
+            off += n
+    assert opt._multi, "the fused path was not taken"
+    for p, r in zip(ps, ref_p):
+        _cmp("multi sgd", p.detach().cpu().numpy(), r, 1e-6, 1e-5)
