@@ -52,6 +52,11 @@
 #ifndef SUBREG_WAVES_K2
 #define SUBREG_WAVES_K2 1        // 1: grids of <= 256 workgroups (128-row tiles, 3 taps per step) put two waves on every tile
 #endif
+#ifndef SUBREG_TWO_TILES
+#define SUBREG_TWO_TILES 0       // 1: the Cout=64 3x3 convs (eval mode) compute two consecutive m-tiles per workgroup (T2, the
+                                 // staging pipeline runs across the tile boundary): 0 % / -4 % (pooled) - the co-resident
+                                 // workgroup already covers a prologue, and half as many workgroups balance worse
+#endif
 #ifndef SUBREG_TM512
 #define SUBREG_TM512 0           // 1: 512-row, 8-wave workgroups for the big wide layers: -10..20 % at 42x42 / 21x21
 #endif
@@ -131,11 +136,18 @@ __device__ __forceinline__ void mma_step<float>(const uint4& a, const uint4& b, 
 // WK = 2: every output tile is owned by TWO waves that take alternate k-steps of each step and add their accumulators
 // through LDS at the end - twice the waves per CU for grids that cannot fill the chip (one 4-wave workgroup per CU leaves
 // one wave per SIMD and nothing to hide its DMA issue, waits and barriers behind).
-template <typename T, int NI, int NJ, int WAVES_M, int WAVES_N, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1>
+// T2: every workgroup computes TWO consecutive m-tiles (same n-tile).  The staging pipeline simply continues across the
+// tile boundary - the last chunk of tile 1 prefetches chunk 0 of tile 2 into the free patch buffer, the last step its
+// first weight tile - so the second tile has no prologue DMA wait; the epilogue slabs of tile 1 live in the patch buffer
+// it has just consumed.  For short-K layers (layer 1: 6 steps per tile) the prologue is a quarter of a tile's time.
+template <typename T, int NI, int NJ, int WAVES_M, int WAVES_N, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1,
+          bool T2 = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kernel(const ConvArgs a) {
     using K = KT<T>;
     constexpr int NWMN = WAVES_M * WAVES_N, NW = NWMN * WK;
+    constexpr int NT = T2 ? 2 : 1;                       // m-tiles per workgroup
     static_assert(WK == 1 || WK == 2, "one or two waves per output tile");
+    static_assert(!T2 || WK == 1, "two tiles per workgroup: one wave per tile only");
     constexpr int TM = WAVES_M * NI * 32, TN = WAVES_N * NJ * 32;
     constexpr int SLOTS = K::SLOTS, ROWB = K::ROWB, ELEM = K::ELEM;
     constexpr int RPP = 1024 / ROWB;                     // rows per 1-KiB DMA piece (16 bf16 / 8 f32)
@@ -168,13 +180,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
         const int nwg = gridDim.x, lid = blockIdx.x, q8 = nwg / 8, r8 = nwg % 8, xcd = lid % 8, slot = lid / 8;
         vtile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
     }
-    const int mtile = vtile / ntn;
-    const int m0 = a.m_base + mtile * TM, n0 = (vtile % ntn) * TN;
+    int mtile = (vtile / ntn) * NT;
+    int m0 = a.m_base + mtile * TM;
+    const int n0 = (vtile % ntn) * TN;
 
     int plo, phi;
     patch_range<POOL>(g, m0, TM, &plo, &phi);
-    const int prow = phi - plo;
-    const int apieces = (prow + RPP - 1) / RPP;
+    int prow = phi - plo;
+    int apieces = (prow + RPP - 1) / RPP;
+    // the second tile of this workgroup (T2): its patch range is needed while the first tile is still computing
+    const bool has2 = T2 && m0 + TM < a.m_base + a.m_rows;
+    int plo2 = 0, prow2 = 1, apieces2 = 1;
+    if (has2) {
+        int lo2, hi2;
+        patch_range<POOL>(g, m0 + TM, TM, &lo2, &hi2);
+        plo2 = lo2; prow2 = hi2 - lo2; apieces2 = (prow2 + RPP - 1) / RPP;
+    }
 
     // this tile's BN shift / scale into LDS now: fetched at the start of the epilogue they cost a full global-load
     // latency (several thousand cycles with the memory pipe busy) on every workgroup's critical path
@@ -205,16 +226,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of smem
     // piece group `grp` of a patch = pieces grp*NW .. grp*NW+NW-1, one per wave (the last group re-loads the last
     // piece on the surplus waves so that every wave issues the same number of DMAs: counted vmcnt waits rely on it)
-    auto stage_patch_group = [&](const char* xsrc, int cin, int chunk, int buf, int grp) {
+    auto stage_patch_group_of = [&](const char* xsrc, int cin, int chunk, int buf, int grp, int plo_, int prow_, int apieces_) {
         const unsigned xrow = (unsigned)cin * ELEM;
-        const char* base = xsrc + (size_t)plo * xrow + (size_t)chunk * 32 * ELEM;     // wave-uniform
+        const char* base = xsrc + (size_t)plo_ * xrow + (size_t)chunk * 32 * ELEM;    // wave-uniform
         int q = grp * NW + wid;
-        q = q < apieces ? q : apieces - 1;
+        q = q < apieces_ ? q : apieces_ - 1;
         const int row = q * RPP + prl;
-        const int srow = row < prow ? row : prow - 1;                // tail rows of the last piece: any valid source
+        const int srow = row < prow_ ? row : prow_ - 1;              // tail rows of the last piece: any valid source
         dma16(base, (unsigned)srow * xrow + ((psl ^ swz_tr<SLOTS, TR>(row)) << 4), lds_base + buf * ABUF + q * 1024);
     };
-    const int agroups = (apieces + NW - 1) / NW;                     // piece groups of one patch
+    auto stage_patch_group = [&](const char* xsrc, int cin, int chunk, int buf, int grp) {
+        stage_patch_group_of(xsrc, cin, chunk, buf, grp, plo, prow, apieces);
+    };
+    int agroups = (apieces + NW - 1) / NW;                           // piece groups of one patch
+    const int agroups2 = (apieces2 + NW - 1) / NW;
     auto stage_patch = [&](const char* xsrc, int cin, int chunk, int buf) {
         for (int grp = 0; grp < agroups; ++grp) stage_patch_group(xsrc, cin, chunk, buf, grp);
     };
@@ -269,22 +294,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     static_assert(ABUF < 65536, "packed A addresses are 16-bit");
     constexpr int NAP = (MI * TAPS + 1) / 2;
     unsigned apk[NAP];
+    auto compute_apk = [&]() {
 #pragma unroll
-    for (int k = 0; k < NAP; ++k) apk[k] = 0;
+        for (int k = 0; k < NAP; ++k) apk[k] = 0;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + (wave_m * MI + i) * TR + lr;
-        const bool mv = m < g.M;
-        const Pix px = row_to_pixel<POOL>(g, mv ? m : 0);
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + (wave_m * MI + i) * TR + lr;
+            const bool mv = m < g.M;
+            const Pix px = row_to_pixel<POOL>(g, mv ? m : 0);
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-            const int dy = TAPS == 9 ? t / 3 - 1 : 0, dx = TAPS == 9 ? t % 3 - 1 : 0;
-            const bool ok = mv && tap_valid(g, px.h, px.w, dy, dx);
-            const int row = px.p + dy * g.W + dx - plo;
-            const unsigned ad = ok ? row * ROWB + 16 * (lh ^ swz_tr<SLOTS, TR>(row)) : AROWS * ROWB + 16 * lh;
-            apk[(i * TAPS + t) >> 1] |= ad << (16 * ((i * TAPS + t) & 1));
+            for (int t = 0; t < TAPS; ++t) {
+                const int dy = TAPS == 9 ? t / 3 - 1 : 0, dx = TAPS == 9 ? t % 3 - 1 : 0;
+                const bool ok = mv && tap_valid(g, px.h, px.w, dy, dx);
+                const int row = px.p + dy * g.W + dx - plo;
+                const unsigned ad = ok ? row * ROWB + 16 * (lh ^ swz_tr<SLOTS, TR>(row)) : AROWS * ROWB + 16 * lh;
+                apk[(i * TAPS + t) >> 1] |= ad << (16 * ((i * TAPS + t) & 1));
+            }
         }
-    }
+    };
+    compute_apk();
     auto aaddr = [&](int i, int t) -> int {
         const int idx = i * TAPS + t;
         return (idx & 1) ? (int)(apk[idx >> 1] >> 16) : (int)(apk[idx >> 1] & 0xffffu);
@@ -305,13 +333,33 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     constexpr int PSTEPS = NG > 1 ? NG - 1 : 1;                       // steps of a chunk that carry patch groups
     constexpr int PA = (AROWS / RPP + NW * PSTEPS - 1) / (NW * PSTEPS);
     int step = 0;
+    int gc = 0;                                                       // chunks done by earlier tiles of this workgroup (buffer parity)
     if (STAMPS) t_loop = __builtin_amdgcn_s_memtime();
+  for (int ti = 0; ti < NT; ++ti) {
+    if (T2 && ti == 1) {
+        if (!has2) break;
+        // second tile: its first patch chunk and weight tile are already in LDS (prefetched by the first tile's last steps)
+        m0 += TM; ++mtile;
+        plo = plo2; prow = prow2; apieces = apieces2; agroups = agroups2;
+        compute_apk();
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < MJ; ++j)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc[i][j][r] = 0.f;
+    }
+    const bool next_tile = T2 && ti == 0 && has2;                     // the chunk after this tile's last one is tile 2's first
     for (int c = 0; c < nchunks; ++c) {
         const bool ph1 = c >= nch0;
-        const bool more = c + 1 < nchunks;
-        const char* nx = (c + 1 < nch0) ? a.x : a.x2;
-        const int ncin = (c + 1 < nch0) ? a.Cin : a.Cin2, nck = (c + 1 < nch0) ? c + 1 : c + 1 - nch0;
-        const int aoff = (c & 1) * ABUF;
+        const bool wrap = next_tile && c + 1 == nchunks;              // the next chunk belongs to the next tile
+        const bool more = c + 1 < nchunks || wrap;
+        const char* nx = (wrap || c + 1 < nch0) ? a.x : a.x2;
+        const int ncin = (wrap || c + 1 < nch0) ? a.Cin : a.Cin2, nck = wrap ? 0 : ((c + 1 < nch0) ? c + 1 : c + 1 - nch0);
+        const int nbuf = (gc + c + 1) & 1;                            // patch buffer of the next chunk
+        const int nplo = wrap ? plo2 : plo, nprow = wrap ? prow2 : prow, napieces = wrap ? apieces2 : apieces;
+        const int nagroups = wrap ? agroups2 : agroups;
+        const int aoff = ((gc + c) & 1) * ABUF;
 #pragma unroll
         for (int tg = 0; tg < NG; ++tg) {
             if (ph1 && tg != 0) continue;
@@ -324,7 +372,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
             constexpr int NSW = TPS * PW, NS = NSW + PA;
             int wc = c, wtg = tg;                                     // the step whose weights this step stages
 #pragma unroll
-            for (int d = 0; d < NWB - 1; ++d) advance(wc, wtg);
+            for (int d = 0; d < NWB - 1; ++d) {
+                advance(wc, wtg);
+                if (next_tile && wc >= nchunks) { wc = 0; wtg = 0; }      // the next tile starts over (same n-tile, same weights)
+            }
             const int wb = (step + NWB - 1) % NWB;
             int n_patch = 0, n_w = 0;
             auto slot = [&](int k) {
@@ -335,9 +386,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
                     n_w += stage_w_piece(wc, wtg, kk / PW, kk % PW, wb);
                 } else if (!ph1) {
                     const int grp = tg * PA + kk;
-                    if (more && (NG == 1 || tg < PSTEPS) && grp < agroups) { stage_patch_group(nx, ncin, nck, (c + 1) & 1, grp); ++n_patch; }
+                    if (more && (NG == 1 || tg < PSTEPS) && grp < nagroups) {
+                        stage_patch_group_of(nx, ncin, nck, nbuf, grp, nplo, nprow, napieces);
+                        ++n_patch;
+                    }
                 } else if (kk == 0 && more) {                         // a shortcut step consumes a whole patch: stage all of the next
-                    for (int grp = 0; grp < agroups; ++grp) stage_patch_group(nx, ncin, nck, (c + 1) & 1, grp);
+                    for (int grp = 0; grp < nagroups; ++grp) stage_patch_group_of(nx, ncin, nck, nbuf, grp, nplo, nprow, napieces);
                 }
             };
             const bool interleave = SUBREG_DMA_INTERLEAVE && !ph1 && NG > 1;
@@ -488,6 +542,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
         }
         if (wave_k != 0) return;
     }
+    // slabs of the LDS-staged epilogues: the whole staging area, or (T2, another tile follows) the patch buffer this tile
+    // consumed last - the other one already holds the next tile's first chunk
+    const int slab_off = T2 ? ((gc + nchunks - 1) & 1) * ABUF : 0;
+    auto epilogue = [&]() {
     struct EpilogueStamp {                  // DIAG=3: cycles from the end of the main loop to the kernel's last instruction
         float* dst;
         unsigned long long t0;
@@ -508,7 +566,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     const T* const res = reinterpret_cast<const T*>(a.res);
     const bool full = m0 + TM <= g.M && n0 + TN <= a.Cout;            // no ragged edge in this tile
     constexpr int TPB = 32 / TR;                                      // MFMA tiles per 32-row slab
-    constexpr bool SLAB_FITS = NWMN * 32 * (NJ * 32 * ELEM + 16) <= 2 * ABUF + NWB * BBUF;   // epilogue slabs reuse the staging LDS
+    constexpr bool SLAB_FITS = NWMN * 32 * (NJ * 32 * ELEM + 16) <= (T2 ? AROWS * ROWB : 2 * ABUF + NWB * BBUF);   // slabs reuse the staging LDS
     const bool raw_slab = !POOL && SLAB_FITS && full;                 // raw tile written by the slab path below
     if (a.raw) {
 #pragma unroll
@@ -547,7 +605,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
         // write it back as whole 16-byte vectors, consecutive lanes on consecutive addresses of a pixel row.  (The
         // direct path below needs one 2/4-byte store per accumulator register and dominated short-K layers.)
         constexpr int TNW = NJ * 32, RS = TNW * ELEM + 16, VPR = TNW * ELEM / 16, NV = 32 * VPR;
-        char* const slab = smem + wmn * (32 * RS);               // all waves are past the last step's barrier
+        char* const slab = smem + slab_off + wmn * (32 * RS);    // all waves are past the last step's barrier
         float shj[MJ], scj[MJ];
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
@@ -586,7 +644,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
         // Full pooled tile: 2x2 max in registers (4 consecutive accumulator registers = one window), the 8 pooled rows
         // of every 32-row slab staged through LDS and written as whole 16-byte vectors.
         constexpr int TNW = NJ * 32, RS = TNW * ELEM + 16, VPR = TNW * ELEM / 16, NV = 8 * VPR;
-        char* const slab = smem + wmn * (32 * RS);
+        char* const slab = smem + slab_off + wmn * (32 * RS);
 #pragma unroll
         for (int ib = 0; ib < NI; ++ib) {
 #pragma unroll
@@ -662,6 +720,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
             }
         }
     }
+    };   // epilogue
+    epilogue();
+    gc += nchunks;
+    if (T2 && ti == 0 && has2) __syncthreads();      // the slabs are read out before the next tile's DMAs reuse that buffer
+  }   // tiles of this workgroup
 }
 
 // ---------------------------------------------------------------------------- host side
@@ -676,13 +739,13 @@ static int worst_patch_rows(const ConvGeom& g, int TM, int m_base, int m_rows) {
     return worst;
 }
 
-template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1>
+template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1, bool T2 = false>
 static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     using K = KT<T>;
     constexpr int TM = WM * NI * 32, TN = WN * NJ * 32;
     constexpr int ABUF = (AROWS + 1) * K::ROWB, BBUF = TPS * TN * K::ROWB;
     const size_t lds = 2 * (size_t)ABUF + (size_t)weight_buffers(ABUF, BBUF) * BBUF + 2 * TN * sizeof(float);   // + shift/scale
-    auto kern = conv_fwd_kernel<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AROWS, MINW, WK>;
+    auto kern = conv_fwd_kernel<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AROWS, MINW, WK, T2>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -690,18 +753,20 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
             return SUBREG_EHIP;
         attr_done = true;
     }
-    dim3 grid(((a.m_rows + TM - 1) / TM) * ((a.Cout + TN - 1) / TN));   // 1-D: the kernel decodes (m-tile, n-tile) itself
+    constexpr int NT = T2 ? 2 : 1;                                       // m-tiles per workgroup
+    dim3 grid(((a.m_rows + TM * NT - 1) / (TM * NT)) * ((a.Cout + TN - 1) / TN));   // 1-D: the kernel decodes (m-tile, n-tile) itself
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * WK * 64), lds, stream, a);
     return launch_status();
 }
 
 // AR_S / AR_L: small and large LDS patch capacities (rows); the small one allows more workgroups per CU
-template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AR_S, int AR_L, int MINW, int WK = 1>
+template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AR_S, int AR_L, int MINW, int WK = 1,
+          bool T2 = false>
 static int launch_rows(const ConvArgs& a, hipStream_t s) {
     if ((long long)a.g.M * a.Cout >= (1LL << 31) || (long long)a.g.npix * a.Cout >= (1LL << 31)) return SUBREG_EUNSUPPORTED;
     const int worst = worst_patch_rows<POOL>(a.g, WM * NI * 32, a.m_base, a.m_rows);
-    if (worst <= AR_S) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_S, MINW, WK>(a, s);
-    if (worst <= AR_L) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_L, MINW, WK>(a, s);
+    if (worst <= AR_S) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_S, MINW, WK, T2>(a, s);
+    if (worst <= AR_L) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_L, MINW, WK, T2>(a, s);
     return SUBREG_EUNSUPPORTED;      // image too wide for the LDS patch
 }
 
@@ -779,6 +844,10 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
             // train mode keeps 256 rows (subreg_conv_stats_rows does not know the kernel size)
             if (a.g.taps == 1 && !raw) return launch_shape<__bf16, 1, 2, 4, 1, 1, 432, 560, 2>(a, pool, s);
             if (a.g.taps == 1) return launch_shape<__bf16, 2, 2, 4, 1, 1, 432, 560, 2>(a, pool, s);
+#if SUBREG_TWO_TILES
+            if (!raw) return pool ? launch_rows<__bf16, 2, 2, 4, 1, 9, 1, true, 432, 560, 2, 1, true>(a, s)
+                                  : launch_rows<__bf16, 2, 2, 4, 1, 9, 3, false, 432, 560, 2, 1, true>(a, s);
+#endif
             if (!pool || raw) return launch_rows<__bf16, 2, 2, 4, 1, 9, 3, false, 432, 560, 2>(a, s);
             // pooled conv3 (+ fused K=32 shortcut): 256-row tiles with ONE tap per step measured 16-19 % faster than the
             // 128-row / 3-tap tiling (and than 256-row / 3-tap) at batch 256 and 700
