@@ -132,6 +132,8 @@ __global__ void linear_bwd_b_kernel(const float* __restrict__ dlogits, float* __
     db[n] = acc;
 }
 
+constexpr int MAX_BASE = 512;        // base classes (rows of W_base): 60 (miniImageNet) ... 351 (tieredImageNet); must be <= dim
+
 // ---------------------------------------------------------------- orthonormal basis of span(W_base rows)
 // One workgroup, classical Gram-Schmidt with re-orthogonalisation ("twice is enough") in fp64.
 // Q [nb][D] row-major: row j = j-th orthonormal basis vector (== column j of the reference's Q up to sign;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(1024) void subspace_basis_kernel(const float* __res
                                                                double* __restrict__ scratch /* [nb][D] */, int nb, int D,
                                                                int* __restrict__ info) {
     __shared__ double red[17];
-    __shared__ double coef[256];
+    __shared__ double coef[MAX_BASE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
     int deficient = 0;
     for (int k = 0; k < nb; ++k) {
@@ -205,7 +207,7 @@ __device__ __forceinline__ void project_row(const float* __restrict__ w, const f
 
 __global__ __launch_bounds__(256) void subspace_project_kernel(const float* __restrict__ w, const float* __restrict__ Q,
                                                                 float* __restrict__ P, int nb, int D) {
-    __shared__ float s_c[256];
+    __shared__ float s_c[MAX_BASE];
     const float* wr = w + (size_t)blockIdx.x * D;
     project_row(wr, Q, nb, D, s_c);
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256) void step_rows_kernel(const StepArgs a) {
 // phase B: grid = N class-row blocks: dW row, regulariser gradients, SGD(momentum, wd) update in place
 __global__ __launch_bounds__(256) void step_update_kernel(const StepArgs a) {
     __shared__ float s_dl[2048];
-    __shared__ float s_c[256];
+    __shared__ float s_c[MAX_BASE];
     __shared__ double red[17];
     if (a.st->stop) return;
     const int n = blockIdx.x, Bt = a.Bs + a.Bm, D = a.D;
@@ -637,13 +639,13 @@ extern "C" int subreg_linear_bwd(const float* dlogits, const float* feat, const 
 
 extern "C" int subreg_subspace_basis(const float* w_base, float* q, double* scratch, int n_base, int D, int* info,
                                      void* stream) {
-    SUBREG_CHECK_ARG(w_base && q && scratch && n_base > 0 && n_base <= 256 && D > 0);
+    SUBREG_CHECK_ARG(w_base && q && scratch && n_base > 0 && n_base <= MAX_BASE && D > 0);
     hipLaunchKernelGGL(subspace_basis_kernel, 1, 1024, 0, (hipStream_t)stream, w_base, q, scratch, n_base, D, info);
     return launch_status();
 }
 
 extern "C" int subreg_subspace_project(const float* w, const float* q, float* p, int k, int n_base, int D, void* stream) {
-    SUBREG_CHECK_ARG(w && q && p && k > 0 && n_base > 0 && n_base <= 256 && D > 0);
+    SUBREG_CHECK_ARG(w && q && p && k > 0 && n_base > 0 && n_base <= MAX_BASE && D > 0);
     hipLaunchKernelGGL(subspace_project_kernel, k, 256, 0, (hipStream_t)stream, w, q, p, n_base, D);
     return launch_status();
 }
@@ -719,7 +721,7 @@ extern "C" int subreg_finetune_step(const subreg_step_desc* d, void* stream) {
     SUBREG_CHECK_ARG(d && d->feat && d->labels && d->weight && d->momentum_buf && d->state && d->dlogits && d->rowloss &&
                      d->rowcorrect && d->norms && d->rowl1 && d->losses && d->train_acc);
     SUBREG_CHECK_ARG(d->n_support > 0 && d->n_memory >= 0 && d->n_classes > 0 && d->n_classes <= MAX_CLS && d->dim > 0);
-    SUBREG_CHECK_ARG(d->n_support + d->n_memory <= 2048 && d->n_base <= 256);
+    SUBREG_CHECK_ARG(d->n_support + d->n_memory <= 2048 && d->n_base <= MAX_BASE);
     SUBREG_CHECK_ARG(!d->use_base_reg || d->w_base);
     SUBREG_CHECK_ARG(!d->use_prev_reg || (d->w_prev && d->n_prev > 0));
     SUBREG_CHECK_ARG(!d->use_pull || d->basis || d->pull_target);

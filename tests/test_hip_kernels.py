@@ -299,6 +299,28 @@ def test_subspace_kernels_golden(case):
     _cmp("grad", w.grad.cpu().numpy(), g[case + ".grad"], 1e-6, 1e-5)
 
 
+def test_subspace_kernels_351_base_classes():
+    """tieredImageNet-sized base set (351 classes, BASELINE.json configs[4]): basis + projection + loss1 gradient against the
+    oracle's QR restatement (the same code the 60-class goldens pin)."""
+    from oracle import subspace_ref as sr
+    from subreg_hip import functional as HF
+    rs = np.random.RandomState(17)
+    wb = (rs.standard_normal((351, 640)) * 0.05 + rs.standard_normal((351, 1)) * rs.standard_normal((1, 640)) * 0.05).astype(np.float32)
+    w = (rs.standard_normal((5, 640)) * 0.04).astype(np.float32)
+    q, info = HF.subspace_basis(_t(wb))
+    assert int(info.item()) == 0
+    qq = q.cpu().numpy().astype(np.float64)
+    _cmp("orthonormal", qq @ qq.T, np.eye(351), 1e-5, 0)
+    wt = _t(w).requires_grad_(True)
+    P = HF.SubspaceProjectFn.apply(wt, q)
+    _cmp("P", P.detach().cpu().numpy(), sr.get_projected_weight(wb, w, np.float64), 1e-5, 1e-4)
+    loss = HF.SqDiffFn.apply(P, wt, 0.7)
+    loss.backward()
+    l_ref, g_ref = sr.loss1_and_grad(0.7, wb, w)
+    _cmp("loss1", loss.item(), l_ref, 1e-6, 1e-4)
+    _cmp("grad", wt.grad.cpu().numpy(), g_ref, 1e-5, 1e-4)
+
+
 def test_frob_kernels_golden():
     from subreg_hip import functional as HF
     g = np.load(os.path.join(GOLDEN, "reg.npz"))
