@@ -9,12 +9,23 @@ reference makes - no feature caching), the fused classifier/regularizer step, pe
 evaluation) starts every 8 steps.  Because the reference's stop rule is data-dependent, E is FIXED
 (--epochs, default 100 = SURVEY.md section 8d headline); the stop rule still runs on the device.
 With N GPUs every rank runs its own seed (the reference shards seeds over SLURM array tasks,
-scripts/continual/slurm_subspace_reg.sh:8,19-27): weak scaling, no data-path collective.
+scripts/continual/slurm_subspace_reg.sh:8,19-27): weak scaling, no data-path collective.  `python bench.py --gpus N`
+without a launcher starts its own N ranks (a parent process that never touches the GPU runs
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child and relays rank 0's line); under
+torchrun (RANK / WORLD_SIZE in the environment) it is a rank.
+
+After the timed region the same process group runs the 10-seed x 8-session sweep of
+scripts/continual/slurm_subspace_reg.sh:8,19-31 (BASELINE.json configs[3]; `--sweep-seeds`, 0 = skip) with
+subreg_hip.sweep.plan_sweep: one seed per rank while >= N seeds remain, then the remaining seeds shared by groups of
+ranks (RCCL broadcast of the seed's backbone to its group, row-sliced forwards, one feature all-gather per forward).
+Its episodes/s is reported under "sweep" in the same line (strong scaling: the work is fixed), so that
+sweep.value at N GPUs / sweep.value at 1 GPU is the speed-up the north star's >= 6x target is about.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (conv_fwd_kernel, implicit-GEMM MFMA):
 achieved = algorithmic conv FLOPs (8.1219 GFLOP/image x images forwarded in the timed region) / the summed
-HIP-event duration of those backbone forwards on the launch stream.  `cpu_baseline` times the NumPy oracle
-(a port, not the reference) on a bounded sample on this host.
+HIP-event duration of those backbone forwards on the launch stream.  `cpu_baseline` times a torch-CPU restatement
+(oracle/torch_ref.py: the library the reference computes with) of one fine-tune epoch on a bounded sample on this
+host; the NumPy oracle's forward rate is kept beside it.
 """
 import argparse
 import json
@@ -98,30 +109,129 @@ def images_per_episode(s, epochs, n_base):
 
 
 def cpu_baseline(args, n_base):
-    """NumPy oracle (port) eval-mode forward on a bounded sample, converted to episodes/s of the same workload."""
+    """One real fine-tune epoch of a -M session-1 episode (support forward, CE + three regularizers + SGD step, query
+    validation: language_eval.py:252-326) on the torch-CPU restatement, repeated for about --cpu-seconds, converted to
+    episodes/s of the benchmark's workload with the same images-per-episode count.  The NumPy oracle's forward rate is
+    reported beside it (`port_numpy`)."""
+    from oracle import torch_ref as tr
     from oracle.resnet_ref import ResNetRef
     from subreg_hip import synthetic as syn
-    net = ResNetRef(syn.make_state_dict(1))
-    net.features(syn.make_images(0, 2, 84))                  # page in BLAS
-    n, t = 4, 0.0
+    sd = syn.make_state_dict(1, randomize_bn=False)
+    threads = torch.get_num_threads()
+    net = tr.TorchCpuRef(sd)
+    g = torch.Generator().manual_seed(5)
+    n_img = 125 if args.cpu_seconds >= 8 else 25                # per set; the real episode has 125 support + 125 query
+    sy, qy = syn.session_labels(0)
+    sel = torch.arange(0, 125, 125 // n_img)[:n_img]
+    sx, qx = torch.randn(n_img, 3, 84, 84, generator=g), torch.randn(n_img, 3, 84, 84, generator=g)
+    lab_s = torch.from_numpy(sy)[sel] - int(sy.min()) + 60       # session-0 labels -> classifier rows 60..64
+    lab_q = torch.from_numpy(qy)[sel] - int(qy.min()) + 60
+    wb = torch.randn(60, 640, generator=g) * 0.05
+    W = torch.cat([wb, torch.randn(5, 640, generator=g) * 0.03])
+    hp = dict(lmbd_base=0.2, lmbd_prev=0.1, pull=1.0, lr=0.002, momentum=0.9, wd=5e-4)
+    net.features(sx[:2])                                         # page in MKL-DNN
+    mom, epochs, t0 = None, 0, time.time()
     while True:
-        x = syn.make_images(1, n, 84)
-        t0 = time.time()
-        net.features(x)
+        _loss, _accs, mom = tr.finetune_epoch(net, W, mom, wb, None, sx, lab_s, [(qx, lab_q)], hp)
+        epochs += 1
         t = time.time() - t0
-        if t >= args.cpu_seconds / 2 or n >= 512:
+        if t >= args.cpu_seconds * 0.6 or epochs >= 20:
             break
-        n = min(512, max(n * 2, int(n * args.cpu_seconds / max(t, 1e-3) * 0.8)))
-    img_s = n / t
+    img_s = epochs * 2 * n_img / t
     avg_imgs = np.mean([images_per_episode(s, args.epochs, n_base) for s in range(8)]) + n_base / 8.0   # + run-start base eval
+    out = {"value": img_s / avg_imgs, "unit": "episodes/s", "cores": threads, "kind": "port",
+           "sample": "torch-CPU restatement (F.conv2d / batch_norm / autograd, %d threads): %d fine-tune epoch(s) of a -M "
+                     "session-1 episode (%d support + %d query 84x84 images, step, validation) in %.1f s = %.1f img/s, "
+                     "scaled by the mean %.0f image-forwards per episode" % (threads, epochs, n_img, n_img, t, img_s, avg_imgs)}
+    # secondary: the NumPy oracle (the parity checker itself), forward only
+    onet = ResNetRef(syn.make_state_dict(1))
+    x = syn.make_images(1, 8, 84)
+    onet.features(x[:2])
+    t0 = time.time()
+    onet.features(x)
+    tn = time.time() - t0
     try:                                                      # threads the oracle's BLAS calls actually ran on
         from threadpoolctl import threadpool_info
-        threads = max([int(p.get("num_threads", 1)) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+        nthreads = max([int(p.get("num_threads", 1)) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
     except Exception:
-        threads = os.cpu_count()
-    return {"value": img_s / avg_imgs, "unit": "episodes/s", "cores": threads, "kind": "port",
-            "sample": "NumPy oracle eval-mode forward of %d 84x84 images in %.1f s (%.1f img/s), scaled by the mean "
-                      "%.0f image-forwards per episode" % (n, t, img_s, avg_imgs)}
+        nthreads = os.cpu_count()
+    out["port_numpy"] = {"value": 8 / tn / avg_imgs, "unit": "episodes/s", "cores": nthreads, "kind": "port-numpy",
+                         "sample": "NumPy oracle eval-mode forward of 8 images in %.1f s (%.1f img/s)" % (tn, 8 / tn)}
+    return out
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no launcher: start N ranks as a child `torch.distributed.run` job and relay its output.
+    This parent never initialises the GPU (no torch.cuda call happens before this point), and nothing is exec'ed from a
+    process that has: the ranks are fresh child processes (scripts/continual/slurm_subspace_reg.sh:7-8 starts one process
+    per GPU the same way, through the SLURM array)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return proc.returncode if line is not None or proc.returncode else 1
+
+
+def run_sweep(args, rank, world, dev, host_only):
+    """The 10-seed x 8-session sweep (BASELINE.json configs[3]) on this process group: plan = sweep.plan_sweep.
+    Returns the dict reported under "sweep" (rank 0's copy is printed)."""
+    import torch.distributed as dist
+    from subreg_hip import sweep
+    plan = sweep.plan_sweep(range(1, args.sweep_seeds + 1), world)
+    # every rank creates every group, in the same order (torch.distributed.new_group is collective over the world)
+    groups = {tuple(ranks): (dist.new_group(ranks) if world > 1 and len(ranks) > 1 else None)
+              for rnd in plan for _seed, ranks in rnd}
+    if not host_only:
+        from subreg_hip.incremental import IncrementalRunner
+        torch.cuda.synchronize()
+    sweep.barrier()
+    t0 = time.perf_counter()
+    done = []
+    for rnd in plan:
+        for seed, ranks in [(sd, rk) for sd, rk in rnd if rank in rk]:
+            group = groups[tuple(ranks)]
+            if host_only:                                   # control-path self-test: the plan, groups and collectives, no GPU work
+                t = torch.tensor([float(seed)])
+                if group is not None:
+                    dist.broadcast(t, ranks[0], group=group)
+                time.sleep(0.01)
+            else:
+                net, opt = make_net(args, seed, dev)         # same seed -> same synthetic backbone on every rank of the group ...
+                if group is not None:
+                    sweep.broadcast_module(net, ranks[0], group)   # ... a real sweep loads it on the leader only
+                meta, base = make_run_inputs(seed, dev, args.base_batch)
+                shard = sweep.RowShard(group) if group is not None else None
+                r = IncrementalRunner(net, meta, base, opt, None, None, None, args.epochs_per_sync or args.epochs, False,
+                                      verbose=False, row_shard=shard).start()
+                for idx in range(r.iter_num):
+                    r.run_session(idx)
+                r.finish()
+            if rank == ranks[0]:
+                done.append(seed)
+    if not host_only:
+        torch.cuda.synchronize()
+    sweep.barrier()
+    dt = sweep.max_over_ranks(time.perf_counter() - t0, None if host_only else dev)
+    seen = sorted(x for r in sweep.gather_results(done) for x in r)
+    return {"workload": "%d seeds x 8 sessions (BASELINE.json configs[3])" % args.sweep_seeds, "value": args.sweep_seeds * 8 / dt,
+            "unit": "episodes/s", "seconds": dt, "scaling": "strong", "seeds_done": seen,
+            "plan": [[[sd, len(rk)] for sd, rk in rnd] for rnd in plan],
+            "n_ranks_seen": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+            "model_speedup_over_1_gpu": sweep.sweep_speedup(args.sweep_seeds, world)}
 
 
 def main():
@@ -135,21 +245,41 @@ def main():
     ap.add_argument("--epochs-per-sync", type=int, default=0, help="0 = queue the whole episode")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep-seeds", type=int, default=10,
+                    help="also run the S-seed x 8-session sweep (configs[3]) after the timed region; 0 = skip")
+    ap.add_argument("--sweep-deadline", type=int, default=900, help="seconds after which the sweep leg is abandoned")
     ap.add_argument("--reuse-features", action="store_true",
                     help="NOT the headline: opt-in frozen-feature reuse (reported in DESIGN.md only)")
+    ap.add_argument("--selftest-host", action="store_true",
+                    help="control-path self-test WITHOUT a GPU (gloo): launch, rendezvous, sweep plan, collectives, JSON relay; "
+                         "computes nothing and reports value 0")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
+    import torch.distributed as dist
+    from subreg_hip import sweep
+    if args.selftest_host:
+        if world > 1:
+            dist.init_process_group("gloo")
+        sw = run_sweep(args, rank, world, None, True) if args.sweep_seeds > 0 else None
+        if rank == 0:
+            print(json.dumps({"metric": "incremental episodes/sec, ResNet18 miniImageNet 5w5s", "value": 0.0, "unit": "episodes/s",
+                              "n_gpus": world, "steps": 0, "warmup": 0, "data": "none (host control-path self-test)", "sweep": sw}),
+                  flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)       # RCCL; used only for the barrier and the max-over-ranks time
+        dist.init_process_group("nccl", device_id=dev)       # RCCL; the timed region uses it only for the barrier and the max-over-ranks time
 
-    from subreg_hip import sweep
     from subreg_hip.incremental import IncrementalRunner
     seed = rank + 1                                           # one seed per GPU, like the SLURM array
     net, opt = make_net(args, seed, dev)
@@ -200,12 +330,32 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "8-session FSCIL, subspace regularizer, -M (BASELINE.json configs[1]); one seed per GPU",
                    "epochs_per_episode": args.epochs, "images_per_gpu": imgs, "base_batch": args.base_batch,
-                   "feature_reuse": bool(args.reuse_features), "backbone": "ResNet18 (RFS ResNet-12 family, 8.1219 GFLOP/img)"},
+                   "feature_reuse": bool(args.reuse_features), "backbone": "ResNet18 (RFS ResNet-12 family, 8.1219 GFLOP/img)",
+                   "n_ranks_seen": dist.get_world_size() if world > 1 else 1},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                      "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": traffic,
                      "kernel": "conv_fwd_kernel family over %d backbone forwards (%.1f ms each)" % (n_fwd, fwd_ms / max(n_fwd, 1))},
         "images_per_s": imgs * world / dt,
     }
+    del runners, r
+    # ---- after the timed region: the 10-seed sweep on the same process group (strong scaling).  A failure or a hang of
+    #      this extra leg must not cost the headline line: rank 0 prints the line without it after a deadline.
+    if args.sweep_seeds > 0:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["sweep"] = {"error": "sweep leg did not finish within %d s" % args.sweep_deadline}
+                print(json.dumps(out), flush=True)
+            os._exit(0 if rank == 0 else 1)
+        timer = threading.Timer(args.sweep_deadline, give_up)
+        timer.daemon = True
+        timer.start()
+        try:
+            out["sweep"] = run_sweep(args, rank, world, dev, False)
+        except Exception as exc:                                   # noqa: BLE001 - reported in the line, never silently dropped
+            out["sweep"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        timer.cancel()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.base_batch)

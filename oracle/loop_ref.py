@@ -198,7 +198,10 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
         acc_b, _ = accuracy_top1(linear(base_feat, W), base_y)
         test_acc = [round(a, 2) for a in test_acc]                               # :372
         ta = float(np.array(test_acc).mean())
-        w1, w2 = 60, n_old + opt.n_ways - 60                                     # :383-386
+        w1 = 60 if getattr(opt, "dataset", "miniImageNet") == "miniImageNet" else 200      # :383 (hard-coded class counts)
+        w2 = n_old + opt.n_ways - 60                                             # :386
+        if getattr(opt, "avg_weights_follow_n_base", False):                     # the build's explicit alternative (real counts)
+            w1, w2 = n_base, n_old + opt.n_ways - n_base
         out["loss"].append(losses)
         out["train_acc"].append(tr_acc)
         out["test_acc"].append(test_acc)

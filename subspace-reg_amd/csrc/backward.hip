@@ -334,12 +334,8 @@ static int launch_wgrad_bf16(const __bf16* xq, const __bf16* dyq, float* gw, lon
     const size_t lds = (size_t)64 * (64 + 16) + (size_t)(64 + 2 * halo) * (NCW * 64 + 16);
     if (lds > 160 * 1024) return SUBREG_EUNSUPPORTED;
     auto kern = conv_wgrad_bf16_kernel<NCW, TAPS>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return SUBREG_EHIP;
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> lds_set{0};   // per instantiation
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, lds_set)) return rc;
     const int tiles = (Cout / 32) * (Cin / (32 * NCW));
     long long splits = (1536 + tiles - 1) / tiles;                        // ~6 workgroups per CU in total
     long long rpb = ((Q + splits - 1) / splits + 63) / 64 * 64;

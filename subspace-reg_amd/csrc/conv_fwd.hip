@@ -26,9 +26,9 @@
 #include "conv_index.h"
 #include "subreg_common.h"
 
-// Build-time switches.  DIAG is for measurements only; the others are design alternatives that were built, verified
-// bit-for-bit against the same tests and measured on MI355X (tools/bench_conv.py, B=256, whole conv stack), kept so the
-// next experiment starts from working code.  Defaults are the fastest measured combination.
+// Build-time switches.  DIAG is for measurements only.  Design alternatives that were built, verified and measured slower
+// or equal (DMAs issued between MFMA groups, a 3-deep weight ring, a concurrent 256+128-row tail tiling, two m-tiles per
+// workgroup, 512-row 8-wave workgroups) are recorded with their numbers in DESIGN.md section 4.1, not kept here.
 #ifndef SUBREG_DIAG
 #define SUBREG_DIAG 0            // 1 = no in-loop staging, 2 = no LDS reads / MFMAs (both: wrong results, timing only);
                                  // 3 = per-wave s_memtime stamps into `stats` of a non-raw call (tools/diag_conv.py)
@@ -36,29 +36,8 @@
 #ifndef SUBREG_BF16_MFMA16
 #define SUBREG_BF16_MFMA16 1     // 1: v_mfma_f32_16x16x32_bf16 where mfma_tile() says so, 0: v_mfma_f32_32x32x16_bf16 everywhere
 #endif
-#ifndef SUBREG_DMA_INTERLEAVE
-#define SUBREG_DMA_INTERLEAVE 0  // 1: issue the step's DMAs between MFMA groups instead of in a burst: -3 % (fewer issue
-                                 // stalls, but the weights land later and the end-of-step wait grows by as much)
-#endif
-#ifndef SUBREG_WRING3
-#define SUBREG_WRING3 0          // 1: weight tiles staged two steps ahead (3 buffers): 0 % on 64x160 wave tiles, -15 % on
-                                 // the 128-row tiles (one workgroup fewer per CU)
-#endif
-#ifndef SUBREG_MIXED_TILES
-#define SUBREG_MIXED_TILES 0     // 1: the rows of a wide layer's partial last round go to the 128-row kernel on a helper
-                                 // stream, concurrently with the 256-row kernel: -4 % (the event fork/join costs ~20 us per
-                                 // layer; serialised on one stream it was -3 %): the tail is not worth a second launch
-#endif
 #ifndef SUBREG_WAVES_K2
 #define SUBREG_WAVES_K2 1        // 1: grids of <= 256 workgroups (128-row tiles, 3 taps per step) put two waves on every tile
-#endif
-#ifndef SUBREG_TWO_TILES
-#define SUBREG_TWO_TILES 0       // 1: the Cout=64 3x3 convs (eval mode) compute two consecutive m-tiles per workgroup (T2, the
-                                 // staging pipeline runs across the tile boundary): 0 % / -4 % (pooled) - the co-resident
-                                 // workgroup already covers a prologue, and half as many workgroups balance worse
-#endif
-#ifndef SUBREG_TM512
-#define SUBREG_TM512 0           // 1: 512-row, 8-wave workgroups for the big wide layers: -10..20 % at 42x42 / 21x21
 #endif
 
 namespace subreg {
@@ -91,14 +70,7 @@ struct ConvArgs {
     int Cin, Cin2, Cout;
     int act;             // LeakyReLU(0.1) after scale/shift/residual
     int raw;             // write the un-normalised conv + stats partials
-    int m_base, m_rows;  // this launch covers GEMM rows [m_base, m_base + m_rows) (a layer may be split over two tilings)
 };
-
-// Depth of the weight-tile ring.  The L2 -> LDS latency of a tile under load (1300+ cycles by in-kernel stamps) exceeds
-// one step of a 64x160 wave tile, so stage two steps ahead wherever three buffers still leave two workgroups per CU.
-constexpr int weight_buffers(int abuf, int bbuf) {
-    return SUBREG_WRING3 && 2 * (2 * abuf + 3 * bbuf) <= 160 * 1024 ? 3 : 2;
-}
 
 template <int TR> struct AccT;                       // accumulator registers of one TR x TR tile (TR*TR/64 per lane)
 template <> struct AccT<32> { typedef f32x16 type; };
@@ -136,18 +108,11 @@ __device__ __forceinline__ void mma_step<float>(const uint4& a, const uint4& b, 
 // WK = 2: every output tile is owned by TWO waves that take alternate k-steps of each step and add their accumulators
 // through LDS at the end - twice the waves per CU for grids that cannot fill the chip (one 4-wave workgroup per CU leaves
 // one wave per SIMD and nothing to hide its DMA issue, waits and barriers behind).
-// T2: every workgroup computes TWO consecutive m-tiles (same n-tile).  The staging pipeline simply continues across the
-// tile boundary - the last chunk of tile 1 prefetches chunk 0 of tile 2 into the free patch buffer, the last step its
-// first weight tile - so the second tile has no prologue DMA wait; the epilogue slabs of tile 1 live in the patch buffer
-// it has just consumed.  For short-K layers (layer 1: 6 steps per tile) the prologue is a quarter of a tile's time.
-template <typename T, int NI, int NJ, int WAVES_M, int WAVES_N, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1,
-          bool T2 = false>
+template <typename T, int NI, int NJ, int WAVES_M, int WAVES_N, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1>
 __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kernel(const ConvArgs a) {
     using K = KT<T>;
     constexpr int NWMN = WAVES_M * WAVES_N, NW = NWMN * WK;
-    constexpr int NT = T2 ? 2 : 1;                       // m-tiles per workgroup
     static_assert(WK == 1 || WK == 2, "one or two waves per output tile");
-    static_assert(!T2 || WK == 1, "two tiles per workgroup: one wave per tile only");
     constexpr int TM = WAVES_M * NI * 32, TN = WAVES_N * NJ * 32;
     constexpr int SLOTS = K::SLOTS, ROWB = K::ROWB, ELEM = K::ELEM;
     constexpr int RPP = 1024 / ROWB;                     // rows per 1-KiB DMA piece (16 bf16 / 8 f32)
@@ -155,7 +120,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     constexpr int BTAP = TN * ROWB;                      // one tap's weight tile
     constexpr int BBUF = TPS * BTAP;
     constexpr int B_BASE = 2 * ABUF;
-    constexpr int NWB = weight_buffers(ABUF, BBUF);      // weight ring depth: steps are staged NWB-1 ahead
+    constexpr int NWB = 2;                               // weight buffers: a step's weights are staged one step ahead
     constexpr int CENTER = TAPS / 2;
     constexpr int TR = mfma_tile<T>(NI, NJ), LG = 64 / TR, NR = TR * TR / 64;   // MFMA tile edge, lane groups per tile, regs per tile
     constexpr int KSTEPS = SLOTS / LG;                   // MFMA k-steps per 32-channel chunk
@@ -180,22 +145,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
         const int nwg = gridDim.x, lid = blockIdx.x, q8 = nwg / 8, r8 = nwg % 8, xcd = lid % 8, slot = lid / 8;
         vtile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
     }
-    int mtile = (vtile / ntn) * NT;
-    int m0 = a.m_base + mtile * TM;
+    const int mtile = vtile / ntn;
+    const int m0 = mtile * TM;
     const int n0 = (vtile % ntn) * TN;
 
     int plo, phi;
     patch_range<POOL>(g, m0, TM, &plo, &phi);
-    int prow = phi - plo;
-    int apieces = (prow + RPP - 1) / RPP;
-    // the second tile of this workgroup (T2): its patch range is needed while the first tile is still computing
-    const bool has2 = T2 && m0 + TM < a.m_base + a.m_rows;
-    int plo2 = 0, prow2 = 1, apieces2 = 1;
-    if (has2) {
-        int lo2, hi2;
-        patch_range<POOL>(g, m0 + TM, TM, &lo2, &hi2);
-        plo2 = lo2; prow2 = hi2 - lo2; apieces2 = (prow2 + RPP - 1) / RPP;
-    }
+    const int prow = phi - plo;
+    const int apieces = (prow + RPP - 1) / RPP;
 
     // this tile's BN shift / scale into LDS now: fetched at the start of the epilogue they cost a full global-load
     // latency (several thousand cycles with the memory pipe busy) on every workgroup's critical path
@@ -226,20 +183,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of smem
     // piece group `grp` of a patch = pieces grp*NW .. grp*NW+NW-1, one per wave (the last group re-loads the last
     // piece on the surplus waves so that every wave issues the same number of DMAs: counted vmcnt waits rely on it)
-    auto stage_patch_group_of = [&](const char* xsrc, int cin, int chunk, int buf, int grp, int plo_, int prow_, int apieces_) {
+    auto stage_patch_group = [&](const char* xsrc, int cin, int chunk, int buf, int grp) {
         const unsigned xrow = (unsigned)cin * ELEM;
-        const char* base = xsrc + (size_t)plo_ * xrow + (size_t)chunk * 32 * ELEM;    // wave-uniform
+        const char* base = xsrc + (size_t)plo * xrow + (size_t)chunk * 32 * ELEM;     // wave-uniform
         int q = grp * NW + wid;
-        q = q < apieces_ ? q : apieces_ - 1;
+        q = q < apieces ? q : apieces - 1;
         const int row = q * RPP + prl;
-        const int srow = row < prow_ ? row : prow_ - 1;              // tail rows of the last piece: any valid source
+        const int srow = row < prow ? row : prow - 1;                // tail rows of the last piece: any valid source
         dma16(base, (unsigned)srow * xrow + ((psl ^ swz_tr<SLOTS, TR>(row)) << 4), lds_base + buf * ABUF + q * 1024);
     };
-    auto stage_patch_group = [&](const char* xsrc, int cin, int chunk, int buf, int grp) {
-        stage_patch_group_of(xsrc, cin, chunk, buf, grp, plo, prow, apieces);
-    };
-    int agroups = (apieces + NW - 1) / NW;                           // piece groups of one patch
-    const int agroups2 = (apieces2 + NW - 1) / NW;
+    const int agroups = (apieces + NW - 1) / NW;                     // piece groups of one patch
     auto stage_patch = [&](const char* xsrc, int cin, int chunk, int buf) {
         for (int grp = 0; grp < agroups; ++grp) stage_patch_group(xsrc, cin, chunk, buf, grp);
     };
@@ -279,22 +232,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
         if (sc >= nch0 || stg == NG - 1) { ++sc; stg = 0; } else { ++stg; }
     };
     stage_patch(a.x, a.Cin, 0, 0);
-    {
-        int sc = 0, stg = 0;
 #pragma unroll
-        for (int d = 0; d < NWB - 1; ++d) {
-#pragma unroll
-            for (int k = 0; k < TPS * PW; ++k) stage_w_piece(sc, stg, k / PW, k % PW, d);
-            advance(sc, stg);
-        }
-    }
+    for (int k = 0; k < TPS * PW; ++k) stage_w_piece(0, 0, k / PW, k % PW, 0);
     // per-lane LDS addresses of this lane's A rows for every tap (k-step 0; k-step s is addr ^ 16*LG*s): logical slot
     // LG*s + lh of the row, physical slot = logical ^ swz.  Kept as 16-bit halves (every patch buffer is < 64 KiB):
     // the 16x16 MFMA shape needs MI = 4 row addresses per tap and the accumulators leave no room for 36 registers.
     static_assert(ABUF < 65536, "packed A addresses are 16-bit");
     constexpr int NAP = (MI * TAPS + 1) / 2;
     unsigned apk[NAP];
-    auto compute_apk = [&]() {
+    {
 #pragma unroll
         for (int k = 0; k < NAP; ++k) apk[k] = 0;
 #pragma unroll
@@ -311,8 +257,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
                 apk[(i * TAPS + t) >> 1] |= ad << (16 * ((i * TAPS + t) & 1));
             }
         }
-    };
-    compute_apk();
+    }
     auto aaddr = [&](int i, int t) -> int {
         const int idx = i * TAPS + t;
         return (idx & 1) ? (int)(apk[idx >> 1] >> 16) : (int)(apk[idx >> 1] & 0xffffu);
@@ -325,79 +270,46 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's DMA landed ...
     __syncthreads();                                                  // ... everyone's did; zero rows visible
     // Patch of chunk c+1 is prefetched during chunk c, PA piece groups per step (none in the chunk's last step when
-    // there are several).  LDS-DMA completes in issue order and the end-of-step wait is `vmcnt(N)` with N = the
-    // youngest DMAs that may stay in flight:
-    //   NWB = 2: a step issues [weights of step+1][patch groups]   and waits N = patch groups (0 at a chunk end);
-    //   NWB = 3: a step issues [patch groups][weights of step+2]   and waits N = weights (+ patch groups unless at
-    //            a chunk end): the weights of step+1 went out a whole step earlier.
+    // there are several).  LDS-DMA completes in issue order; a step issues [weights of step+1][patch groups] and its
+    // end-of-step wait is `vmcnt(N)` with N = the patch groups, the youngest DMAs, which may stay in flight (0 at a chunk end).
     constexpr int PSTEPS = NG > 1 ? NG - 1 : 1;                       // steps of a chunk that carry patch groups
     constexpr int PA = (AROWS / RPP + NW * PSTEPS - 1) / (NW * PSTEPS);
     int step = 0;
-    int gc = 0;                                                       // chunks done by earlier tiles of this workgroup (buffer parity)
     if (STAMPS) t_loop = __builtin_amdgcn_s_memtime();
-  for (int ti = 0; ti < NT; ++ti) {
-    if (T2 && ti == 1) {
-        if (!has2) break;
-        // second tile: its first patch chunk and weight tile are already in LDS (prefetched by the first tile's last steps)
-        m0 += TM; ++mtile;
-        plo = plo2; prow = prow2; apieces = apieces2; agroups = agroups2;
-        compute_apk();
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < MJ; ++j)
-#pragma unroll
-                for (int r = 0; r < NR; ++r) acc[i][j][r] = 0.f;
-    }
-    const bool next_tile = T2 && ti == 0 && has2;                     // the chunk after this tile's last one is tile 2's first
     for (int c = 0; c < nchunks; ++c) {
         const bool ph1 = c >= nch0;
-        const bool wrap = next_tile && c + 1 == nchunks;              // the next chunk belongs to the next tile
-        const bool more = c + 1 < nchunks || wrap;
-        const char* nx = (wrap || c + 1 < nch0) ? a.x : a.x2;
-        const int ncin = (wrap || c + 1 < nch0) ? a.Cin : a.Cin2, nck = wrap ? 0 : ((c + 1 < nch0) ? c + 1 : c + 1 - nch0);
-        const int nbuf = (gc + c + 1) & 1;                            // patch buffer of the next chunk
-        const int nplo = wrap ? plo2 : plo, nprow = wrap ? prow2 : prow, napieces = wrap ? apieces2 : apieces;
-        const int nagroups = wrap ? agroups2 : agroups;
-        const int aoff = ((gc + c) & 1) * ABUF;
+        const bool more = c + 1 < nchunks;
+        const char* nx = c + 1 < nch0 ? a.x : a.x2;
+        const int ncin = c + 1 < nch0 ? a.Cin : a.Cin2, nck = c + 1 < nch0 ? c + 1 : c + 1 - nch0;
+        const int nbuf = (c + 1) & 1;                                 // patch buffer of the next chunk
+        const int aoff = (c & 1) * ABUF;
 #pragma unroll
         for (int tg = 0; tg < NG; ++tg) {
             if (ph1 && tg != 0) continue;
             const bool last_grp = ph1 || tg == NG - 1;
-            // DMA work of this step as numbered slots (PA patch slots, NSW weight slots; order by NWB as above).
-            // Issued in one burst right after the barrier the DMAs of the four waves queue up behind each other in the
-            // CU's one address path (~75 stalled cycles each, in-kernel stamps); SUBREG_DMA_INTERLEAVE issues one slot
-            // after each of the first MFMA groups instead.
+            // DMA work of this step: the next step's weight pieces, then PA patch groups of the next chunk.  Issued in one
+            // burst right after the barrier; the DMAs of the four waves queue up behind each other in the CU's one address
+            // path (~75 stalled cycles each, in-kernel stamps).
             if (STAMPS) tq = __builtin_amdgcn_s_memtime();
-            constexpr int NSW = TPS * PW, NS = NSW + PA;
             int wc = c, wtg = tg;                                     // the step whose weights this step stages
+            advance(wc, wtg);
+            const int wb = (step + 1) % NWB;
+            int n_patch = 0;
+            if (SUBREG_DIAG != 1) {
 #pragma unroll
-            for (int d = 0; d < NWB - 1; ++d) {
-                advance(wc, wtg);
-                if (next_tile && wc >= nchunks) { wc = 0; wtg = 0; }      // the next tile starts over (same n-tile, same weights)
-            }
-            const int wb = (step + NWB - 1) % NWB;
-            int n_patch = 0, n_w = 0;
-            auto slot = [&](int k) {
-                const bool is_w = NWB == 2 ? k < NSW : k >= PA;
-                const int kk = NWB == 2 ? (is_w ? k : k - NSW) : (is_w ? k - PA : k);
-                if (SUBREG_DIAG == 1) return;
-                if (is_w) {
-                    n_w += stage_w_piece(wc, wtg, kk / PW, kk % PW, wb);
-                } else if (!ph1) {
-                    const int grp = tg * PA + kk;
-                    if (more && (NG == 1 || tg < PSTEPS) && grp < nagroups) {
-                        stage_patch_group_of(nx, ncin, nck, nbuf, grp, nplo, nprow, napieces);
-                        ++n_patch;
+                for (int k = 0; k < TPS * PW; ++k) stage_w_piece(wc, wtg, k / PW, k % PW, wb);
+                if (!ph1) {
+#pragma unroll
+                    for (int k = 0; k < PA; ++k) {
+                        const int grp = tg * PA + k;
+                        if (more && (NG == 1 || tg < PSTEPS) && grp < agroups) {
+                            stage_patch_group(nx, ncin, nck, nbuf, grp);
+                            ++n_patch;
+                        }
                     }
-                } else if (kk == 0 && more) {                         // a shortcut step consumes a whole patch: stage all of the next
-                    for (int grp = 0; grp < nagroups; ++grp) stage_patch_group_of(nx, ncin, nck, nbuf, grp, nplo, nprow, napieces);
+                } else if (more) {                                    // a shortcut step consumes a whole patch: stage all of the next
+                    for (int grp = 0; grp < agroups; ++grp) stage_patch_group(nx, ncin, nck, nbuf, grp);
                 }
-            };
-            const bool interleave = SUBREG_DMA_INTERLEAVE && !ph1 && NG > 1;
-            if (!interleave) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) slot(k);
             }
             if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_issue += n - tq; tq = n; }
             const int boff = (step % NWB) * BBUF;
@@ -408,14 +320,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
             constexpr int KX = 16 * LG;                               // address XOR per k-step
             constexpr bool SWP = NI * NJ * 16 + 2 * (MI + MJ) * 4 + 40 <= 200;
             static_assert(WK == 1 || !SWP, "the k-step split is implemented on the ring-pipelined path");
-            constexpr int NGRP = SWP ? NK : NK * MJ;                  // MFMA groups of a step (DMA slots go between them)
-            constexpr int SPG = (NS + NGRP - 1) / NGRP;               // slots per group
-            auto after_group = [&](int gi) {
-                if (!interleave) return;
-#pragma unroll
-                for (int k = gi * SPG; k < (gi + 1) * SPG; ++k)
-                    if (k < NS) slot(k);
-            };
             auto load_a = [&](int kk, uint4(&xa)[MI]) {
                 const int tt = kk / KSTEPS, s = kk % KSTEPS;
 #pragma unroll
@@ -455,7 +359,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
                             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         }
                     }
-                    after_group(kk);
                 }
             } else {
                 // big wave tiles: no room for a second fragment set.  Per k-step: the A fragments, then the B fragments
@@ -488,7 +391,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
 #pragma unroll
                         for (int i = 0; i < MI; ++i) mma_step<T>(fa[i], fb[j % 3], acc[i][j]);
                         __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
-                        after_group(kk * MJ + j);
                     }
                 }
             }
@@ -497,7 +399,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
             // end of step: next step's weights landed (and, at a chunk boundary, the whole next patch); this wave's
             // LDS reads are complete (their results fed the MFMAs); then the workgroup barrier
             {
-                const int keep = NWB == 2 ? (last_grp ? 0 : n_patch) : n_w + (last_grp ? 0 : n_patch);
+                const int keep = last_grp ? 0 : n_patch;
                 switch (keep) {
                 case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
                 case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
@@ -542,10 +444,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
         }
         if (wave_k != 0) return;
     }
-    // slabs of the LDS-staged epilogues: the whole staging area, or (T2, another tile follows) the patch buffer this tile
-    // consumed last - the other one already holds the next tile's first chunk
-    const int slab_off = T2 ? ((gc + nchunks - 1) & 1) * ABUF : 0;
-    auto epilogue = [&]() {
     struct EpilogueStamp {                  // DIAG=3: cycles from the end of the main loop to the kernel's last instruction
         float* dst;
         unsigned long long t0;
@@ -566,7 +464,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     const T* const res = reinterpret_cast<const T*>(a.res);
     const bool full = m0 + TM <= g.M && n0 + TN <= a.Cout;            // no ragged edge in this tile
     constexpr int TPB = 32 / TR;                                      // MFMA tiles per 32-row slab
-    constexpr bool SLAB_FITS = NWMN * 32 * (NJ * 32 * ELEM + 16) <= (T2 ? AROWS * ROWB : 2 * ABUF + NWB * BBUF);   // slabs reuse the staging LDS
+    constexpr bool SLAB_FITS = NWMN * 32 * (NJ * 32 * ELEM + 16) <= 2 * ABUF + NWB * BBUF;   // slabs reuse the staging LDS
     const bool raw_slab = !POOL && SLAB_FITS && full;                 // raw tile written by the slab path below
     if (a.raw) {
 #pragma unroll
@@ -605,7 +503,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
         // write it back as whole 16-byte vectors, consecutive lanes on consecutive addresses of a pixel row.  (The
         // direct path below needs one 2/4-byte store per accumulator register and dominated short-K layers.)
         constexpr int TNW = NJ * 32, RS = TNW * ELEM + 16, VPR = TNW * ELEM / 16, NV = 32 * VPR;
-        char* const slab = smem + slab_off + wmn * (32 * RS);    // all waves are past the last step's barrier
+        char* const slab = smem + wmn * (32 * RS);    // all waves are past the last step's barrier
         float shj[MJ], scj[MJ];
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
@@ -644,7 +542,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
         // Full pooled tile: 2x2 max in registers (4 consecutive accumulator registers = one window), the 8 pooled rows
         // of every 32-row slab staged through LDS and written as whole 16-byte vectors.
         constexpr int TNW = NJ * 32, RS = TNW * ELEM + 16, VPR = TNW * ELEM / 16, NV = 8 * VPR;
-        char* const slab = smem + slab_off + wmn * (32 * RS);
+        char* const slab = smem + wmn * (32 * RS);
 #pragma unroll
         for (int ib = 0; ib < NI; ++ib) {
 #pragma unroll
@@ -720,18 +618,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
             }
         }
     }
-    };   // epilogue
-    epilogue();
-    gc += nchunks;
-    if (T2 && ti == 0 && has2) __syncthreads();      // the slabs are read out before the next tile's DMAs reuse that buffer
-  }   // tiles of this workgroup
 }
 
 // ---------------------------------------------------------------------------- host side
 template <bool POOL>
-static int worst_patch_rows(const ConvGeom& g, int TM, int m_base, int m_rows) {
+static int worst_patch_rows(const ConvGeom& g, int TM) {
     int worst = 0;
-    for (int m0 = m_base; m0 < m_base + m_rows; m0 += TM) {
+    for (int m0 = 0; m0 < g.M; m0 += TM) {
         int lo, hi;
         patch_range<POOL>(g, m0, TM, &lo, &hi);
         if (hi - lo > worst) worst = hi - lo;
@@ -739,34 +632,27 @@ static int worst_patch_rows(const ConvGeom& g, int TM, int m_base, int m_rows) {
     return worst;
 }
 
-template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1, bool T2 = false>
+template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1>
 static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     using K = KT<T>;
     constexpr int TM = WM * NI * 32, TN = WN * NJ * 32;
     constexpr int ABUF = (AROWS + 1) * K::ROWB, BBUF = TPS * TN * K::ROWB;
-    const size_t lds = 2 * (size_t)ABUF + (size_t)weight_buffers(ABUF, BBUF) * BBUF + 2 * TN * sizeof(float);   // + shift/scale
-    auto kern = conv_fwd_kernel<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AROWS, MINW, WK, T2>;
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return SUBREG_EHIP;
-        attr_done = true;
-    }
-    constexpr int NT = T2 ? 2 : 1;                                       // m-tiles per workgroup
-    dim3 grid(((a.m_rows + TM * NT - 1) / (TM * NT)) * ((a.Cout + TN - 1) / TN));   // 1-D: the kernel decodes (m-tile, n-tile) itself
+    const size_t lds = 2 * (size_t)ABUF + 2 * (size_t)BBUF + 2 * TN * sizeof(float);   // patch x2, weights x2, shift/scale
+    auto kern = conv_fwd_kernel<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AROWS, MINW, WK>;
+    static std::atomic<unsigned long long> lds_set{0};   // per instantiation
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set)) return rc;
+    dim3 grid(((a.g.M + TM - 1) / TM) * ((a.Cout + TN - 1) / TN));   // 1-D: the kernel decodes (m-tile, n-tile) itself
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * WK * 64), lds, stream, a);
     return launch_status();
 }
 
 // AR_S / AR_L: small and large LDS patch capacities (rows); the small one allows more workgroups per CU
-template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AR_S, int AR_L, int MINW, int WK = 1,
-          bool T2 = false>
+template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AR_S, int AR_L, int MINW, int WK = 1>
 static int launch_rows(const ConvArgs& a, hipStream_t s) {
     if ((long long)a.g.M * a.Cout >= (1LL << 31) || (long long)a.g.npix * a.Cout >= (1LL << 31)) return SUBREG_EUNSUPPORTED;
-    const int worst = worst_patch_rows<POOL>(a.g, WM * NI * 32, a.m_base, a.m_rows);
-    if (worst <= AR_S) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_S, MINW, WK, T2>(a, s);
-    if (worst <= AR_L) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_L, MINW, WK, T2>(a, s);
+    const int worst = worst_patch_rows<POOL>(a.g, WM * NI * 32);
+    if (worst <= AR_S) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_S, MINW, WK>(a, s);
+    if (worst <= AR_L) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_L, MINW, WK>(a, s);
     return SUBREG_EUNSUPPORTED;      // image too wide for the LDS patch
 }
 
@@ -831,7 +717,6 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
     a.Cin = Cin; a.Cout = Cout;
     a.act = (flags & SUBREG_CONV_LRELU) ? 1 : 0;
     a.raw = raw ? 1 : 0;
-    a.m_base = 0; a.m_rows = a.g.M;
     hipStream_t s = (hipStream_t)stream;
     const bool wide = (Cout % 160 == 0);
     // LDS per block = 2 patch buffers + 2 weight buffers, sized so that >= 2 workgroups fit a CU (160 KiB).
@@ -844,22 +729,12 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
             // train mode keeps 256 rows (subreg_conv_stats_rows does not know the kernel size)
             if (a.g.taps == 1 && !raw) return launch_shape<__bf16, 1, 2, 4, 1, 1, 432, 560, 2>(a, pool, s);
             if (a.g.taps == 1) return launch_shape<__bf16, 2, 2, 4, 1, 1, 432, 560, 2>(a, pool, s);
-#if SUBREG_TWO_TILES
-            if (!raw) return pool ? launch_rows<__bf16, 2, 2, 4, 1, 9, 1, true, 432, 560, 2, 1, true>(a, s)
-                                  : launch_rows<__bf16, 2, 2, 4, 1, 9, 3, false, 432, 560, 2, 1, true>(a, s);
-#endif
             if (!pool || raw) return launch_rows<__bf16, 2, 2, 4, 1, 9, 3, false, 432, 560, 2>(a, s);
             // pooled conv3 (+ fused K=32 shortcut): 256-row tiles with ONE tap per step measured 16-19 % faster than the
             // 128-row / 3-tap tiling (and than 256-row / 3-tap) at batch 256 and 700
             return launch_rows<__bf16, 2, 2, 4, 1, 9, 1, true, 432, 560, 2>(a, s);
         }
         const long long nt = Cout / 160;
-#if SUBREG_TM512
-        // big maps: 512-row tiles, 8 waves, one workgroup per CU.  Same waves per SIMD as two 256-row workgroups, but
-        // every weight tile staged from L2 feeds twice the rows (the L2 -> LDS weight stream is what the 256-row tiling
-        // was bound by) and 3 taps per step = a third of the barriers.
-        if (!raw && wide_takes_256_rows(a.g.M, Cout, W)) return launch_shape<__bf16, 2, 5, 8, 1, 3, 608, 704, 2>(a, pool, s);
-#endif
         auto tiles256 = [&](const ConvArgs& b, hipStream_t st) {
             // patches of <= 352 rows (W <= 42 unpooled) keep the LDS footprint at two workgroups per CU with room to spare
             const int rc = launch_shape<__bf16, 2, 5, 4, 1, 1, 352, 432, 2>(b, pool, st);
@@ -868,7 +743,7 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
         auto tiles128 = [&](const ConvArgs& b, hipStream_t st) {
             // 128-row tiles.  If they all fit one per CU (<= 256 workgroups) stage 3 taps per step (84 KB LDS, covers the
             // LDS-DMA latency at that occupancy); otherwise 1 tap per step and 3 workgroups per CU.
-            if (((b.m_rows + 127) / 128) * nt > 256) {
+            if (((b.g.M + 127) / 128) * nt > 256) {
                 const int rc = launch_shape<__bf16, 1, 5, 4, 1, 1, 192, 224, 2>(b, pool, st);    // 224: 42x42 maps, still 3 per CU
                 return rc != SUBREG_EUNSUPPORTED ? rc : launch_shape<__bf16, 1, 5, 4, 1, 1, 432, 432, 2>(b, pool, st);
             }
@@ -879,37 +754,6 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
 #endif
         };
         if (!wide_takes_256_rows(a.g.M, Cout, W)) return tiles128(a, s);
-#if SUBREG_MIXED_TILES
-        // Tail quantisation: T tiles of 256 rows on 512 resident slots run ceil(T / 512) rounds (882 tiles: 2 rounds for
-        // 1.72 rounds of work).  Give the whole rounds to the 256-row kernel and the rows of the partial round to the
-        // 128-row kernel, launched on a helper stream so that its workgroups fill the slots the first kernel's last
-        // round leaves free (event fork / join around it: ordered with the caller's stream, no host synchronisation).
-        if (!raw) {
-            const int M = a.g.M, mt = (M + 255) / 256;
-            const long long T = (long long)mt * nt, rem = T % 512;
-            const long long mt1 = (T / 512) * 512 / nt;               // whole m-tiles of the full rounds
-            if (rem != 0 && rem <= 448 && mt1 > 0 && mt1 < mt) {
-                static hipStream_t side = nullptr;
-                static hipEvent_t fork = nullptr, join = nullptr;
-                if (!side) {
-                    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
-                        hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess)
-                        return SUBREG_EHIP;
-                }
-                ConvArgs a1 = a, a2 = a;
-                a1.m_rows = (int)mt1 * 256;
-                a2.m_base = a1.m_rows; a2.m_rows = M - a1.m_rows;
-                if (hipEventRecord(fork, s) != hipSuccess || hipStreamWaitEvent(side, fork, 0) != hipSuccess) return SUBREG_EHIP;
-                int rc = tiles256(a1, s);
-                if (rc != SUBREG_OK) return rc;
-                rc = tiles128(a2, side);
-                if (rc != SUBREG_OK) return rc;
-                if (hipEventRecord(join, side) != hipSuccess || hipStreamWaitEvent(s, join, 0) != hipSuccess) return SUBREG_EHIP;
-                return SUBREG_OK;
-            }
-        }
-#endif
         return tiles256(a, s);
     }
     return wide ? launch_shape<float, 2, 5, 2, 1, 1, 304, 408, 1>(a, pool, s) : launch_shape<float, 2, 2, 2, 1, 1, 304, 408, 1>(a, pool, s);

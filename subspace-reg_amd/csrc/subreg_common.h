@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/subreg_hip.h"
 
 namespace subreg {
@@ -15,6 +17,18 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SUBREG_OK : -(1000 + (int)e);
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: set it once per (kernel, device).  `done` is
+// a per-kernel bitmask of the devices already configured (one process may drive several GPUs; host threads may race).
+inline int ensure_dynamic_lds(const void* kern, size_t bytes, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return SUBREG_EHIP;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return SUBREG_OK;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return SUBREG_EHIP;
+    done.fetch_or(bit, std::memory_order_release);
+    return SUBREG_OK;
 }
 
 #define SUBREG_CHECK_ARG(cond)            \

@@ -44,6 +44,11 @@ class HipBackbone:
 
     MAX_EVAL_CHUNK = 1536     # images per launch sequence: one launch for a whole epoch's batch (<= 1125 images at 8 sessions) - larger grids
                               # waste less on partial last rounds (+8 % episodes/s over 512); 6.3 GB of workspaces in bf16
+    EVAL_LANES = 2            # eval-mode forwards: the batch is cut into this many sub-batches (images are independent in eval mode),
+                              # each running its own 22-conv launch sequence on its own HIP stream and workspaces, forked from and
+                              # joined to the caller's stream once per forward.  While one lane's kernel drains its partial last round
+                              # of workgroups, the other lanes' kernels fill the idle CUs (tools/bench_forward.py, graph replay,
+                              # 2 lanes vs 1: +5.8 % at 250 images, +5.3 % at 500, +4.7 % at 750, +2.6 % at 1125; 3-4 lanes: less).
 
     def __init__(self, params, n_blocks=(1, 1, 2, 2), dtype="bf16", block_size=1):
         self.lib = _lib.load()
@@ -59,7 +64,9 @@ class HipBackbone:
         self._packed, self._scale, self._shift = {}, {}, {}
         self._versions = None
         self._fold_versions = None
-        self._cap = (0, 0, 0)
+        self._cap = (0, 0, 0)          # allocated (workspace bytes, stats floats, im2col elements)
+        self._ws_ok = set()            # (B, H, W) known to fit the allocation
+        self._lanes = []               # extra eval lanes: dict(desc, ws, col, cap, stream, ok)
         self._keep = []
         self._blk = (_lib.BlockDesc * len(self.blocks))()
         self._desc = _lib.BackboneDesc()
@@ -136,21 +143,52 @@ class HipBackbone:
         self._fold_versions = None
 
     def _ensure_workspace(self, B, H, W):
-        cb, ch, cw = self._cap
-        if B <= cb and H == ch and W == cw:
+        """Workspaces for a forward of B images.  Neither size is monotone in B (the BN-partial row count follows the
+        tile height the conv picks for the batch: a smaller batch can need MORE partial rows), so capacity is tracked in
+        bytes / floats as the library reports them for exactly this (B, H, W), never inferred from a larger batch."""
+        if (B, H, W) in self._ws_ok:
             return
         dev = self.device
         nbytes = self.lib.subreg_backbone_ws_bytes(C.byref(self._desc), B, H, W)
         nstats = self.lib.subreg_backbone_stats_floats(C.byref(self._desc), B, H, W)
+        ncol = B * H * W * 32
         assert nbytes > 0 and nstats > 0
-        self._ws = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(4)]
-        self._col = torch.empty(B * H * W * 32, dtype=self.tdtype, device=dev)
-        self._stats = torch.empty(nstats, dtype=torch.float32, device=dev)
-        for i in range(4):
-            self._desc.ws[i] = self._ws[i].data_ptr()
-        self._desc.col = self._col.data_ptr()
-        self._desc.stats = self._stats.data_ptr()
-        self._cap = (B, H, W)
+        cap_b, cap_s, cap_c = self._cap
+        if nbytes > cap_b or nstats > cap_s or ncol > cap_c:
+            cap_b, cap_s, cap_c = max(cap_b, nbytes), max(cap_s, nstats), max(cap_c, ncol)
+            self._ws = [torch.empty(cap_b, dtype=torch.uint8, device=dev) for _ in range(4)]
+            self._col = torch.empty(cap_c, dtype=self.tdtype, device=dev)
+            self._stats = torch.empty(cap_s, dtype=torch.float32, device=dev)
+            for i in range(4):
+                self._desc.ws[i] = self._ws[i].data_ptr()
+            self._desc.col = self._col.data_ptr()
+            self._desc.stats = self._stats.data_ptr()
+            self._cap = (cap_b, cap_s, cap_c)
+        self._ws_ok.add((B, H, W))
+
+    def _lane(self, i, B, H, W):
+        """Descriptor of eval lane i >= 1 (lane 0 is self._desc): same packed weights, own workspaces and stream."""
+        while len(self._lanes) < i:
+            d = _lib.BackboneDesc()
+            C.memmove(C.byref(d), C.byref(self._desc), C.sizeof(d))
+            self._lanes.append(dict(desc=d, cap=(0, 0), ok=set(), stream=torch.cuda.Stream(device=self.device)))
+        ln = self._lanes[i - 1]
+        ln["desc"].blocks, ln["desc"].n_blocks = self._desc.blocks, self._desc.n_blocks
+        if (B, H, W) not in ln["ok"]:
+            nbytes = self.lib.subreg_backbone_ws_bytes(C.byref(self._desc), B, H, W)
+            ncol = B * H * W * 32
+            cb, cc = ln["cap"]
+            if nbytes > cb or ncol > cc:
+                cb, cc = max(cb, nbytes), max(cc, ncol)
+                ln["ws"] = [torch.empty(cb, dtype=torch.uint8, device=self.device) for _ in range(4)]
+                ln["col"] = torch.empty(cc, dtype=self.tdtype, device=self.device)
+                for k in range(4):
+                    ln["desc"].ws[k] = ln["ws"][k].data_ptr()
+                ln["desc"].col = ln["col"].data_ptr()
+                ln["desc"].stats = None
+                ln["cap"] = (cb, cc)
+            ln["ok"].add((B, H, W))
+        return ln
 
     # ------------------------------------------------------------------ train-mode masks
     def _prepare_masks(self, B, H, W, masks):
@@ -214,6 +252,29 @@ class HipBackbone:
         else:                                        # balanced chunks (1125 images -> 3 x 375, not 512 + 512 + 101)
             n_chunks = -(-B // self.MAX_EVAL_CHUNK)
             chunk = -(-B // n_chunks)
+        lanes = 1 if (train or return_stages) else max(1, min(int(self.EVAL_LANES), chunk // 64))
+        if lanes > 1:
+            # eval mode, several lanes: sub-batch i of every chunk goes to lane i (its own stream + workspaces)
+            sub = -(-chunk // lanes)
+            self._ensure_workspace(sub, H, W)
+            cur = torch.cuda.current_stream()
+            extra = [self._lane(i, sub, H, W) for i in range(1, lanes)]
+            for ln in extra:
+                ln["stream"].wait_stream(cur)                       # fork: x (and anything queued before) is ready
+            for b0 in range(0, B, chunk):
+                nb = min(chunk, B - b0)
+                for i in range(lanes):
+                    lo, hi = b0 + min(i * sub, nb), b0 + min((i + 1) * sub, nb)
+                    if hi <= lo:
+                        continue
+                    desc = self._desc if i == 0 else extra[i - 1]["desc"]
+                    with torch.cuda.stream(cur if i == 0 else extra[i - 1]["stream"]):
+                        _lib.check(self.lib.subreg_backbone_forward(C.byref(desc), _lib.ptr(x[lo:hi]), hi - lo, H, W,
+                                                                    _lib.ptr(feat[lo:hi]), None, 0, _lib.stream_ptr()),
+                                   "backbone_forward")
+            for ln in extra:
+                cur.wait_stream(ln["stream"])                       # join
+            return feat
         self._ensure_workspace(chunk, H, W)
         s = _lib.stream_ptr()
         if train:

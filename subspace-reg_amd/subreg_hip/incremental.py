@@ -85,6 +85,10 @@ class IncrementalRunner:
             raise NotImplementedError("fused loop assumes --no_linear_bias backbones (slurm_run_backbone.sh:39)")
         if getattr(opt, "adam", False):
             raise NotImplementedError("fused step implements SGD(momentum) (eval/util.py:98-101)")
+        if int(getattr(opt, "freeze_backbone_at", 1)) != 1:
+            # language_eval.py:247-249 trains the backbone with SGD until epoch == freeze_backbone_at; every script passes 1
+            raise NotImplementedError("freeze_backbone_at=%r: the fused loop keeps the backbone frozen from epoch 1 "
+                                      "(eval/util.py:62-69 with the scripts' value)" % (opt.freeze_backbone_at,))
         self.lib = _lib.load()
         self.net, self.opt = net, opt
         self.meta_valloader, self.base_val_loader, self.base_support_loader = meta_valloader, base_val_loader, base_support_loader
@@ -173,7 +177,7 @@ class IncrementalRunner:
         self.query_x, self.query_id = [], []
         self.mem_x = self.mem_y = None
         self.reserve = None
-        self.run = dict(loss=[], test_acc=[], epochs=[], train_acc=[], memory_inds=[])
+        self.run = dict(loss=[], test_acc=[], epochs=[], train_acc=[], memory_inds=[], graph_replays=[])
         self.vocab_base = self.vocab_novel = None
         return self
 
@@ -293,7 +297,7 @@ class IncrementalRunner:
         # ---- epochs >= 2: eval mode, one batched forward per epoch.  The forward is identical every epoch (frozen
         #      backbone, constant inputs): after one eager pass its launch sequence is captured into a hipGraph and
         #      replayed - every epoch still executes all 22 convolutions, only the host-side launches are saved.
-        graph, eager_done = None, 0
+        graph, eager_done, replays = None, 0, 0
         # what THIS rank forwards per epoch: everything, or its row slice of all_x (features all-gathered afterwards)
         if self.dp is None:
             x_loc, out_loc = all_x, feats
@@ -315,6 +319,7 @@ class IncrementalRunner:
                             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                             e0.record()
                         graph.replay()
+                        replays += 1
                         if self.profile:
                             e1.record()
                             self.fwd_events.append((e0, e1, x_loc.shape[0]))
@@ -353,8 +358,16 @@ class IncrementalRunner:
         acc_base_ = self._eval_base()                                          # :363-367
         p("Novel session accuracies: ", test_acc)
         ta = float(np.array(test_acc).mean())
-        w1 = 60 if opt.dataset == "miniImageNet" else 200                      # :383
-        w2 = len(vocab_base) + len(vocab_novel) - 60
+        # :383-386.  The reference hard-codes the class counts (w1 = 60 for miniImageNet, else 200 "tiered"; w2 subtracts
+        # 60) although its own tieredImageNet pretraining uses 351 base classes (train_supervised.py:94).  Default = the
+        # reference's numbers; opt.avg_weights_follow_n_base=True (this build's flag, absent from configs.py) weights by the
+        # real counts: w1 = n_base, w2 = novel classes seen so far.
+        if getattr(opt, "avg_weights_follow_n_base", False):
+            w1 = self.n_base
+            w2 = len(vocab_base) + len(vocab_novel) - self.n_base
+        else:
+            w1 = 60 if opt.dataset == "miniImageNet" else 200
+            w2 = len(vocab_base) + len(vocab_novel) - 60
         weighted_avg = (w1 * acc_base_ + w2 * ta) / (w1 + w2)
         self.weighted_avg_l.append(round(weighted_avg, 2))
         self.acc_novel_list.append(round(ta, 2))
@@ -366,6 +379,7 @@ class IncrementalRunner:
         run["loss"].append(losses)
         run["test_acc"].append(test_acc)
         run["epochs"].append(epochs)
+        run["graph_replays"].append(replays)
         run["train_acc"].append(ses.train_acc[:epochs].cpu().numpy())
         return epochs
 

@@ -54,6 +54,9 @@ class LangPuller(nn.Module):
 
     def __init__(self, opt, vocab_base, vocab_novel):
         super().__init__()
+        if getattr(opt, "use_synonyms", False):          # resnet_language.py:35-42 (synonym-averaged embeddings): not built
+            raise NotImplementedError("use_synonyms: the synonym branch of LangPuller.__init__ is not implemented "
+                                      "(no script under scripts/continual sets it)")
         self.mapping_model = None
         self.opt = opt
         self.vocab_base = vocab_base

@@ -80,7 +80,7 @@ def session_labels(s, n_ways=5, n_shots=5, n_aug=5, n_queries=25, first_novel=60
     return support_ys.astype(np.int64), query_ys.astype(np.int64)
 
 
-def make_sessions(seed, n_sessions, hw=84, class_signal=0.0):
+def make_sessions(seed, n_sessions, hw=84, class_signal=0.0, first_novel=60):
     """Episodes for `n_sessions` incremental sessions.
 
     class_signal > 0 adds a seeded per-class mean image so that accuracies are not
@@ -88,7 +88,7 @@ def make_sessions(seed, n_sessions, hw=84, class_signal=0.0):
     """
     sessions = []
     for s in range(n_sessions):
-        sy, qy = session_labels(s)
+        sy, qy = session_labels(s, first_novel=first_novel)
         sx = make_images(seed * 1000 + 2 * s, len(sy), hw)
         qx = make_images(seed * 1000 + 2 * s + 1, len(qy), hw)
         if class_signal:

@@ -189,6 +189,119 @@ def test_conv_folded_scale_and_fused_shortcut(case, dtype):
     _cmp("fused conv3", got, rr._nchw(want), a, r)
 
 
+# ---------------------------------------------------------------- production tile shapes (bench-scale batches)
+# Every tiling subreg_conv_fwd selects at the batch sizes the benchmark / the pretraining step run (conv_fwd.hip:
+# 256-row / 128-row one-tap / 128-row three-tap two-wave tiles for Cout % 160 == 0, the three Cout = 64 tilings) needs
+# grids far beyond what a full-tensor NumPy oracle finishes in seconds, so the oracle is evaluated on a SAMPLE of output
+# positions: all image corners / borders of the first and last image, rows around the 128/256-row tile boundaries, and
+# 384 random positions.
+BIG_CONV_CASES = [
+    # B, H, W, Cin, Cout, k, pool, Cin2 (fused shortcut GEMM: -1 none, 0 identity)     -> tiling reached (bf16)
+    (64, 84, 84, 64, 64, 3, False, -1),       # Cout=64, 256 rows, 3 taps / step
+    (64, 84, 84, 64, 64, 3, True, 32),        # Cout=64 pooled, 1 tap / step + K=32 shortcut (layer1.0 conv3)
+    (64, 84, 84, 32, 64, 1, False, -1),       # K=32 first conv, 128-row streaming tiles
+    (64, 42, 42, 160, 160, 3, False, -1),     # 441 tiles of 256 rows (>= 384): 256x160
+    (64, 42, 42, 160, 160, 3, True, 64),      # ... pooled + shortcut (layer2.0 conv3)
+    (40, 42, 42, 64, 160, 3, False, -1),      # 276 tiles of 256 rows (< 384): 128-row / 1 tap / 3 per CU at 42x42 (AROWS 224)
+    (160, 21, 21, 320, 320, 3, False, -1),    # 552 x 256-row tiles = 2 rounds -> 1104 x 128-row tiles (1 tap, 3 per CU)
+    (160, 21, 21, 320, 320, 3, True, 160),    # layer3.0 conv3 at that batch (floor pooling 21 -> 10)
+    (300, 10, 10, 320, 640, 3, False, -1),    # 472 x 256-row tiles: one round of 256 rows
+    (700, 5, 5, 640, 640, 3, False, 0),       # 548 x 128-row tiles, identity shortcut (layer4.1 conv3)
+    (120, 10, 10, 320, 320, 3, False, 0),     # 94 m-tiles x 2: <= 256 workgroups -> 3 taps / step, two waves per tile
+]
+
+
+def _conv_at(x_nhwc, w_oihw, b, h, wq):
+    """Oracle conv (cross-correlation, zero padding; resnet_language.py:402-405) at the sampled pixels only -> [S, O] f64."""
+    _B, H, W, _C = x_nhwc.shape
+    O, _, k, _ = w_oihw.shape
+    r = k // 2
+    out = np.zeros((len(b), O))
+    for dy in range(k):
+        for dx in range(k):
+            hh, ww = h + dy - r, wq + dx - r
+            ok = (hh >= 0) & (hh < H) & (ww >= 0) & (ww < W)
+            a = x_nhwc[b, np.clip(hh, 0, H - 1), np.clip(ww, 0, W - 1), :].astype(np.float64) * ok[:, None]
+            out += a @ w_oihw[:, :, dy, dx].T.astype(np.float64)
+    return out
+
+
+def _sample_positions(rs, B, Ho, Wo, n_random=384):
+    pts = set()
+    for b in (0, B - 1):
+        for h in (0, 1, Ho // 2, Ho - 2, Ho - 1):
+            for w in (0, 1, Wo // 2, Wo - 2, Wo - 1):
+                pts.add((b, max(h, 0), max(w, 0)))
+    n = B * Ho * Wo
+    for t in (128, 256, 512, 768, n - 256, n - 128):      # output rows next to tile boundaries (LINEAR order)
+        for d in (-1, 0, 1):
+            m = min(max(t + d, 0), n - 1)
+            pts.add((m // (Ho * Wo), (m // Wo) % Ho, m % Wo))
+    for m in rs.randint(0, n, n_random):
+        pts.add((int(m) // (Ho * Wo), (int(m) // Wo) % Ho, int(m) % Wo))
+    p = np.array(sorted(pts), dtype=np.int64)
+    return p[:, 0], p[:, 1], p[:, 2]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("case", BIG_CONV_CASES, ids=lambda c: "B%d_%dx%d_%d-%d_k%d_p%d_sc%d" % tuple(int(v) for v in c))
+def test_conv_fwd_production_tiles(case, dtype):
+    B, H, W, Cin, Cout, k, pool, Cin2 = case
+    lib = _lib.load()
+    rs = np.random.RandomState(hash(case) % (2 ** 31))
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+
+    def rnd(a):
+        return _round_bf16(a) if dtype == "bf16" else a
+    x = rnd(rs.standard_normal((B, H, W, Cin)).astype(np.float32))                 # NHWC, as the kernel reads it
+    w = (rs.standard_normal((Cout, Cin, k, k)) * (1.4 / np.sqrt(Cin * k * k))).astype(np.float32)
+    sc3 = rs.uniform(0.5, 1.5, Cout).astype(np.float32) * rs.choice([-1, 1], Cout).astype(np.float32)
+    shift = (rs.standard_normal(Cout) * 0.3).astype(np.float32)
+    wf = rnd(w * sc3[:, None, None, None])                                         # BN scale folded, then rounded
+    x2 = w2f = None
+    if Cin2 >= 0:
+        c2 = Cout if Cin2 == 0 else Cin2
+        x2 = rnd(rs.standard_normal((B, H, W, c2)).astype(np.float32))
+        w2 = np.eye(Cout, dtype=np.float32)[:, :, None, None] if Cin2 == 0 else \
+            (rs.standard_normal((Cout, c2, 1, 1)) / np.sqrt(c2)).astype(np.float32)
+        sc2 = np.ones(Cout, np.float32) if Cin2 == 0 else rs.uniform(0.5, 1.5, Cout).astype(np.float32)
+        w2f = rnd(w2 * sc2[:, None, None, None])
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    pb, ph, pw = _sample_positions(rs, B, Ho, Wo)
+
+    def pre_act(h, wq):
+        v = _conv_at(x, wf, pb, h, wq) + shift
+        if x2 is not None:
+            v = v + _conv_at(x2, w2f, pb, h, wq)
+        return v
+    if pool:
+        want = np.maximum.reduce([pre_act(2 * ph + dy, 2 * pw + dx) for dy in (0, 1) for dx in (0, 1)])
+    else:
+        want = pre_act(ph, pw)
+    want = rr.leaky_relu(want)
+    xd = torch.from_numpy(x).to(_dev(), td)
+    x2d = torch.from_numpy(x2).to(_dev(), td) if x2 is not None else None
+    wd = _pack_w(w, dtype, fold=sc3)
+    w2d = None
+    if Cin2 == 0:
+        w2d = torch.empty(Cout * Cout, dtype=td, device=_dev())
+        _lib.check(lib.subreg_pack_identity(_lib.ptr(w2d), Cout, _lib.dtype_code(dtype), _lib.stream_ptr()))
+    elif Cin2 > 0:
+        w2d = _pack_w(w2, dtype, fold=sc2)
+    y = torch.full((B * Ho * Wo, Cout), float("nan"), dtype=td, device=_dev())
+    shd = _t(shift)
+    flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0)
+    _lib.check(lib.subreg_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), None, _lib.ptr(shd), None, None, _lib.ptr(x2d),
+                                   _lib.ptr(w2d), (Cout if Cin2 == 0 else max(Cin2, 0)), B, H, W, Cin, Cout, k, flags,
+                                   _lib.dtype_code(dtype), _lib.stream_ptr()), "conv_fwd(big)")
+    torch.cuda.synchronize()
+    assert not torch.isnan(y.float()).any().item(), "an output row was never written"
+    rows = torch.from_numpy((pb * Ho + ph) * Wo + pw).to(_dev())
+    got = y[rows].float().cpu().numpy()
+    a, r = _tol(dtype, np.abs(want).max())
+    _cmp("conv (sampled)", got, want, a, r)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(3, 21, 21, 160, 320, 3), (2, 42, 42, 64, 160, 1), (5, 5, 5, 640, 640, 3)])
 def test_conv_raw_stats_and_bn_train(shape, dtype):
@@ -261,6 +374,30 @@ def test_backbone_golden(hw, dtype):
     torch.cuda.synchronize()
     _cmp("eval after stats moved", feat2.cpu().numpy() @ sd["classifier.weight"].T, g["hw%d.eval2_logits" % hw],
          5e-4 if dtype == "f32" else a, 5e-4 if dtype == "f32" else r)
+
+
+def test_workspace_capacity_is_not_monotone_in_batch():
+    """A train-mode forward at B=64 followed by B=55 (84x84, bf16): the smaller batch needs MORE BN-partial floats (layer 2
+    switches to 128-row tiles below 56 images).  The workspace must grow, and the result must equal a fresh backbone's."""
+    from subreg_hip.backbone import HipBackbone
+    sd = syn.make_state_dict(21)
+    lib = _lib.load()
+    outs = []
+    for warm in (True, False):
+        hb = HipBackbone(_params_from_sd(sd), (1, 1, 2, 2), "bf16", block_size=1)
+        if warm:
+            hb.forward(_t(syn.make_images(5, 64, 84)), train=True, masks=rr.OnesMaskSource())
+            for k, v in sd.items():                                   # undo the running-stat update of the warm-up pass
+                if "running_" in k:
+                    hb.params[k].copy_(_t(v))
+            hb.nbt = [0] * 6
+        feat = hb.forward(_t(syn.make_images(6, 55, 84)), train=True, masks=rr.OnesMaskSource())
+        torch.cuda.synchronize()
+        need = lib.subreg_backbone_stats_floats(C.byref(hb._desc), 55, 84, 84)
+        assert hb._stats.numel() >= need, (hb._stats.numel(), need)
+        outs.append(feat.cpu().numpy())
+    assert lib.subreg_backbone_stats_floats(C.byref(hb._desc), 55, 84, 84) > lib.subreg_backbone_stats_floats(C.byref(hb._desc), 64, 84, 84)
+    assert np.array_equal(outs[0], outs[1])
 
 
 def test_backbone_matches_oracle_dropblock5():

@@ -3,8 +3,9 @@
 
 f32 mode: per-epoch losses, per-session accuracies, stop epochs and the learned classifier rows must match
 the reference within the north_star's fp32 tolerance (1e-4 on weights; losses ~5 => 2e-4 abs+rel).
-bf16 mode: accuracy-level gate (per-session accuracy within +-2 query images = 1.6 points at these tiny
-query sets; the north_star's +-0.1 % is for the 10-seed average) and 5e-3 on weights.
+bf16 mode (ALWAYS compared; fixed-epoch goldens must run exactly the golden's epochs): per-session accuracy within
++-2 query images = 1.6 points at these 125-image sets (the north_star's +-0.1 % is for the 10-seed average),
+per-epoch loss 5e-2 / 2e-2, 5e-3 on the learned weights.
 The module-surface test drives the REFERENCE's own loop body (net(x), criterion, regloss, LangPuller,
 torch SGD) over the drop-in modules and checks it against the fused loop.
 """
@@ -96,8 +97,11 @@ def build_case(g, dtype, embed_dir=None):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw84_M", "hw32_sem", "hw32_map"])
+@pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw84_M", "hw32_sem", "hw32_map", "hw84_noM_s8"])
 def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
+    """hw84_noM_s8 is the bench-scale case (BASELINE.json configs[1]: 8 sessions, -M, 84x84, 1000-image base batch) with 6
+    epochs per session, so the per-epoch hipGraph is captured and replayed and up to 1125 images go through one launch
+    sequence - the code path bench.py times."""
     from subreg_hip.incremental import few_shot_finetune_incremental_test
     g = np.load(os.path.join(GOLDEN, "loop_%s.npz" % tag))
     net, opt, meta, base_loader, bsl, inits, picks = build_case(g, dtype, str(tmp_path / "word_embeds"))
@@ -111,17 +115,34 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
     run = net.last_run
     ns = int(g["n_sessions"])
     f32 = dtype == "f32"
+    data_dependent_stop = tag == "hw32_stop"          # every other golden runs a fixed number of epochs (max_novel_epochs)
+    one_image = 100.0 / 125 + 1e-6                    # one query image of a 125-image set, in accuracy points
     for s in range(ns):
+        want_e = int(g["s%d.epochs" % s])
+        want_acc = np.round(g["s%d.last_val" % s], 2)
         if f32:
-            assert run["epochs"][s] == int(g["s%d.epochs" % s]), (tag, s, run["epochs"], int(g["s%d.epochs" % s]))
+            assert run["epochs"][s] == want_e, (tag, s, run["epochs"], want_e)
             _cmp("loss s%d" % s, run["loss"][s], g["s%d.loss" % s], 2e-4, 2e-4)
-            _cmp("val acc s%d" % s, run["test_acc"][s], np.round(g["s%d.last_val" % s], 2), 1e-6, 0)
+            _cmp("val acc s%d" % s, run["test_acc"][s], want_acc, 1e-6, 0)
+            continue
+        # bf16 (the dtype of BASELINE.json configs[1]): ALWAYS compared.  Fixed-epoch goldens must run exactly those epochs;
+        # the data-dependent stop may move by at most two epochs (bf16 features shift the loss plateau slightly).
+        if data_dependent_stop:
+            assert abs(run["epochs"][s] - want_e) <= 2, (tag, s, run["epochs"], want_e)
         else:
-            if run["epochs"][s] == int(g["s%d.epochs" % s]):
-                _cmp("loss s%d" % s, run["loss"][s], g["s%d.loss" % s], 5e-2, 2e-2)
-                _cmp("val acc s%d" % s, run["test_acc"][s], np.round(g["s%d.last_val" % s], 2), 1.61, 0)
-    if f32 or all(run["epochs"][s] == int(g["s%d.epochs" % s]) for s in range(ns)):
+            assert run["epochs"][s] == want_e, (tag, s, run["epochs"], want_e)
+        n = min(run["epochs"][s], want_e)
+        _cmp("loss s%d" % s, run["loss"][s][:n], g["s%d.loss" % s][:n], 5e-2, 2e-2)
+        same = run["epochs"][s] == want_e
+        # accuracy: within 2 query images per 125-image set.  These short goldens sit near chance level, where many
+        # argmaxes are near-ties between freshly initialised novel rows; bf16 activations (8-bit mantissa, ~3e-3 relative
+        # on the features) flip up to two of them (measured: 28.0 vs 26.4 on hw32_sem), which no kernel change can avoid
+        _cmp("val acc s%d" % s, run["test_acc"][s], want_acc, (2 if same else 3) * one_image, 0)
+    if f32 or not data_dependent_stop:
         _cmp("final classifier", run["classifier_weight"], g["final_classifier"], 1e-4 if f32 else 5e-3, 1e-4 if f32 else 5e-3)
+    if int(g["hw"]) == 84 and int(g["opt.max_novel_epochs"]) > 5:
+        # the per-epoch forward was replayed as a hipGraph from epoch 3 on, in every session
+        assert all(r == int(g["opt.max_novel_epochs"]) - 2 for r in run["graph_replays"]), run["graph_replays"]
     if f32:
         _cmp("novel avg", novel_avg, g["novel_avg"], 1e-5, 1e-6)
         _cmp("base avg", base_avg, g["base_avg"], 1e-5, 1e-6)
@@ -129,6 +150,9 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
         for k in ("layer1.0.bn1", "layer4.1.bn3"):
             _cmp(k + ".running_mean", sd[k + ".running_mean"].cpu().numpy(), g[k + ".running_mean"], 1e-5, 1e-4)
             _cmp(k + ".running_var", sd[k + ".running_var"].cpu().numpy(), g[k + ".running_var"], 1e-5, 1e-4)
+    else:
+        _cmp("novel avg", novel_avg, g["novel_avg"], (2 if not data_dependent_stop else 3) * one_image, 0)
+        _cmp("base avg", base_avg, g["base_avg"], max(0.5, 100.0 / int(g["n_base_batch"]) + 1e-6), 0)   # <= 1 base image / 0.5 pt
 
 
 def test_feature_reuse_is_results_identical():
@@ -217,3 +241,56 @@ def test_semantic_regularizer_module_against_reference_golden(tmp_path):
     puller = LangPuller(opt, vb, v0)
     puller.create_pulling_mapping({"map.weight": torch.from_numpy(g["map.weight"]), "map.bias": torch.from_numpy(g["map.bias"])})
     _cmp("mapping pullers", puller(wb).cpu().numpy(), g["map.pullers0"], 1e-5, 1e-4)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fused_loop_351_base_classes_against_oracle(dtype):
+    """BASELINE.json configs[4]: tieredImageNet-sized base set (351 classes, train_supervised.py:94), +M, 2 sessions x 3 epochs at
+    32x32.  The reference cannot run this configuration (eval_incremental.py:82-83 raises), so parity is against the NumPy
+    restatement of its loop (oracle/loop_ref.py, pinned by the 60-class goldens) with n_base = 351.  Both weightings of the
+    running average are checked: the reference's hard-coded 200/60 (language_eval.py:383-386) and the explicit
+    avg_weights_follow_n_base flag."""
+    from oracle import loop_ref
+    from oracle.resnet_ref import ResNetRef, copy_state_dict
+    from subreg_hip.incremental import few_shot_finetune_incremental_test
+    from subreg_hip.resnet_language import create_model
+    NB, hw, ns, seed, signal = 351, 32, 2, 9, 3.0
+    for follow in (False, True):
+        opt = make_opt(set_seed=seed, neval_episodes=ns, memory_replay=1, hip_dtype=dtype, max_novel_epochs=3,
+                       dataset="tieredImageNet", avg_weights_follow_n_base=follow)
+        sd = syn.make_state_dict(40, n_cls=NB)
+        sessions = syn.make_sessions(seed, ns, hw, class_signal=signal, first_novel=NB)
+        bx, by = syn.make_base_batch(seed, 64, hw, n_base=NB, class_signal=signal)
+        sx, sy = syn.make_base_support(seed, hw, n_base=NB, class_signal=signal)
+        inits = syn.make_novel_inits(seed, ns)
+        picks = [np.array([1]), np.array([3])]
+        want = loop_ref.run_incremental(ResNetRef(copy_state_dict(sd)), sessions, (bx, by), opt, inits, base_support=(sx, sy),
+                                        masks=MaskSource(77), memory_picks=picks, n_base=NB)
+        net = create_model("resnet18", NB, opt, dataset="tieredImageNet")
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+        net = net.cuda()
+        net.mask_source = MaskSource(77)
+        names_base = ["b%d" % i for i in range(NB)]
+        base_loader = _Loader([(torch.from_numpy(bx), torch.from_numpy(by), torch.arange(len(by)))], names_base)
+        meta = _Loader([(torch.from_numpy(s["support_xs"])[None], torch.from_numpy(s["support_ys"])[None],
+                         torch.from_numpy(s["query_xs"])[None], torch.from_numpy(s["query_ys"])[None]) for s in sessions],
+                       ["n%d" % i for i in range(NB + 100)])
+        bsl = _Loader([(torch.from_numpy(sx)[None], torch.from_numpy(sy)[None], torch.zeros(1, 1, 3, hw, hw),
+                        torch.zeros(1, 1, dtype=torch.long))], names_base)
+        few_shot_finetune_incremental_test(net, {}, None, meta, base_loader, opt, base_support_loader=bsl, novel_inits=inits,
+                                           memory_picks=picks, verbose=False)
+        run = net.last_run
+        f32 = dtype == "f32"
+        assert run["classifier_weight"].shape == (NB + 5 * ns, 640)
+        for s in range(ns):
+            assert run["epochs"][s] == want["epochs"][s] == 3
+            _cmp("loss s%d" % s, run["loss"][s], want["loss"][s], 2e-4 if f32 else 5e-2, 2e-4 if f32 else 2e-2)
+            _cmp("val acc s%d" % s, run["test_acc"][s], want["test_acc"][s], 1e-6 if f32 else 200.0 / 125 + 1e-6, 0)
+        _cmp("final classifier", run["classifier_weight"], want["classifier_weight"], 1e-4 if f32 else 5e-3, 1e-4 if f32 else 5e-3)
+        if f32:
+            _cmp("weighted avg", run["weighted_avg"], want["weighted_avg"], 1e-6, 0)
+            _cmp("acc base", run["acc_base"], want["acc_base"], 1e-6, 0)
+        # the two weightings differ exactly as stated: 200/(351+5k-60) vs 351/(5k)
+        ab, an = want["acc_base"][-1], want["novel_acc"][-1]
+        w1, w2 = (NB, 5 * ns) if follow else (200, NB + 5 * ns - 60)
+        assert abs(want["weighted_avg"][-1] - round((w1 * want["base_vals"][-1] + w2 * want["novel_vals"][-1]) / (w1 + w2), 2)) < 1e-9, (ab, an)

@@ -65,6 +65,37 @@ def test_conv_wgrad_and_dgrad(shape, dtype):
     _cmp("dX", got, rr._nchw(dx_ref), tol * np.abs(dx_ref).max(), tol)
 
 
+@pytest.mark.parametrize("shape", [(64, 84, 84, 64, 64, 3), (64, 42, 42, 160, 160, 3), (64, 10, 10, 640, 640, 3)])
+def test_conv_wgrad_pretrain_batch(shape):
+    """The streaming bf16 dW kernel at the pretraining batch (B = 64, train_supervised.py:205-268): its K = pixels split runs
+    over ~2048 workgroups there, which the small cases above never reach.  Oracle: dW only (nine [O, pixels] x [pixels, C]
+    GEMMs in float64 on the same bf16-rounded operands)."""
+    B, H, W, Cin, Cout, k = shape
+    lib = _lib.load()
+    rs = np.random.RandomState(13)
+    x = _round_bf16(rs.standard_normal((B, H, W, Cin)).astype(np.float32))
+    dy = _round_bf16(rs.standard_normal((B, H, W, Cout)).astype(np.float32))
+    xp = np.zeros((B, H + 2, W + 2, Cin), np.float32)
+    xp[:, 1:-1, 1:-1] = x
+    d2 = dy.reshape(-1, Cout).astype(np.float64)
+    dw_ref = np.zeros((Cout, Cin, 3, 3))
+    for ky in range(3):
+        for kx in range(3):
+            dw_ref[:, :, ky, kx] = d2.T @ np.ascontiguousarray(xp[:, ky:ky + H, kx:kx + W]).reshape(-1, Cin).astype(np.float64)
+    dt = _lib.BF16
+    xd, dyd = torch.from_numpy(x).to(_dev(), torch.bfloat16), torch.from_numpy(dy).to(_dev(), torch.bfloat16)
+    nsplit = lib.subreg_conv_wgrad_splits(B, H, W, Cin, Cout, k, dt)
+    assert nsplit > 1, "the split-K streaming kernel was not selected"
+    gw = torch.full((nsplit * Cout * k * k * Cin,), float("nan"), dtype=torch.float32, device=_dev())
+    grad = torch.empty(Cout, Cin, k, k, dtype=torch.float32, device=_dev())
+    pads = [torch.empty(B * (H + 2) * (W + 2) * c, dtype=torch.bfloat16, device=_dev()) for c in (Cin, Cout)]
+    _lib.check(lib.subreg_conv_wgrad(_lib.ptr(xd), _lib.ptr(dyd), _lib.ptr(gw), _lib.ptr(pads[0]), _lib.ptr(pads[1]), B, H, W, Cin,
+                                     Cout, k, dt, _lib.stream_ptr()))
+    _lib.check(lib.subreg_unpack_wgrad(_lib.ptr(gw), _lib.ptr(grad), Cout, Cin, k, 0, nsplit, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    _cmp("dW (B=64)", grad.cpu().numpy(), dw_ref, 1e-3 * np.abs(dw_ref).max(), 1e-4)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("with_act", [False, True])
 def test_bn_backward(dtype, with_act):

@@ -135,3 +135,28 @@ def test_sweep_plan_reaches_the_scaling_target():
     assert 10 / sweep.makespan_units(10, 8) == 5.0                   # seed sharding alone
     assert sweep.sweep_speedup(10, 8) > 6.0                          # + intra-seed data parallelism for the last two seeds
     assert abs(sweep.sweep_speedup(8, 8) - 8.0) < 1e-9 and abs(sweep.sweep_speedup(10, 1) - 1.0) < 1e-9
+
+
+def test_bench_self_launch_and_sweep_plan_gloo():
+    """`python bench.py --gpus 2` WITHOUT a launcher: the parent starts two ranks itself (torch.distributed.run child), the ranks
+    rendezvous (gloo here, nccl on GPUs), walk sweep.plan_sweep incl. the shared-seed group of the last round (its group
+    broadcast), and rank 0's single JSON line is relayed.  --selftest-host replaces the GPU work with nothing."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--selftest-host", "--sweep-seeds", "3"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["sweep"]["n_ranks_seen"] == 2
+    assert out["sweep"]["seeds_done"] == [1, 2, 3]
+    assert out["sweep"]["plan"] == [[[1, 1], [2, 1]], [[3, 2]]]          # two own-seed runs, then one seed shared by both ranks
+    # a mismatching launcher is refused loudly
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p2 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--selftest-host"], stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, text=True, env=env2, timeout=120)
+    assert p2.returncode != 0 and "WORLD_SIZE" in p2.stderr

@@ -254,3 +254,50 @@ def test_semantic_regularizer_against_reference():
     e = sr.get_embeds(table, ["%s notaword %s" % (known, known), "notaword"])
     _close(e[0], table[known] / 3.0, 1e-6, 1e-6, "unknown word resets the sum")
     assert not e[1].any()
+
+
+# ---------------------------------------------------------------- torch-CPU restatement (bench.py's cpu_baseline leg)
+@pytest.mark.parametrize("hw", [32, 84])
+def test_torch_cpu_ref_backbone_matches_reference_golden(hw):
+    torch = pytest.importorskip("torch")
+    from oracle.torch_ref import TorchCpuRef
+    g = _load("backbone.npz")
+    net = TorchCpuRef(syn.make_state_dict(21))
+    feat = net.features(torch.from_numpy(syn.make_images(31, 4, hw))).numpy()
+    _close(feat, g["hw%d.eval_feat" % hw], what="torch-cpu feat")
+
+
+def test_torch_cpu_ref_epoch_matches_numpy_oracle_step():
+    """finetune_epoch (autograd + hand-written SGD) against the NumPy restatement's loss / gradient / update."""
+    torch = pytest.importorskip("torch")
+    from oracle import torch_ref as tr
+    rs = np.random.RandomState(4)
+    n_base, k_prev, k_new, n, d = 60, 5, 5, 40, 640
+    feat = rs.standard_normal((n, d)).astype(np.float32)
+    wb = (rs.standard_normal((n_base, d)) * 0.05).astype(np.float32)
+    prev = (rs.standard_normal((k_prev, d)) * 0.05).astype(np.float32)
+    W = np.concatenate([wb + 0.01 * rs.standard_normal(wb.shape), prev + 0.01 * rs.standard_normal(prev.shape),
+                        rs.standard_normal((k_new, d)) * 0.03]).astype(np.float32)
+    y = rs.randint(0, n_base + k_prev + k_new, n)
+    hp = dict(lmbd_base=0.2, lmbd_prev=0.1, pull=1.0, lr=0.002, momentum=0.9, wd=5e-4)
+
+    class _Net:
+        def features(self, x):
+            return x
+    Wt = torch.from_numpy(W.copy())
+    qy = rs.randint(0, 70, 30)
+    loss, accs, mom = tr.finetune_epoch(_Net(), Wt, None, torch.from_numpy(wb), torch.from_numpy(prev), torch.from_numpy(feat),
+                                        torch.from_numpy(y), [(torch.from_numpy(feat[:30]), torch.from_numpy(qy))], hp)
+    l_ce, dlog = loop_ref.cross_entropy(feat @ W.T, y)
+    grad = dlog.T @ feat.astype(np.float64)
+    l1, g1 = sr.frob_reg_and_grad(0.2, W[:60], wb)
+    l2, g2 = sr.frob_reg_and_grad(0.1, W[60:65], prev)
+    l3, g3 = sr.loss1_and_grad(1.0, wb, W[65:])
+    grad[:60] += g1
+    grad[60:65] += g2
+    grad[65:] += g3
+    _close(loss, l_ce + l1 + l2 + l3, 1e-5, 1e-5, "loss")
+    want = W - 0.002 * (grad.astype(np.float32) + np.float32(5e-4) * W)
+    _close(Wt.numpy(), want, 1e-6, 1e-5, "W after SGD")
+    acc_ref, _ = loop_ref.accuracy_top1(feat[:30] @ want.T, qy)
+    assert abs(accs[0] - acc_ref) < 1e-4

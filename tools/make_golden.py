@@ -553,6 +553,10 @@ def main():
         gen_episodes()
     if "loop84" in what:
         gen_loop("hw84_M", 84, 3, True, 40, seed=4, max_novel_epochs=4)
+    if "loop84s8" in what:
+        # bench-scale case (BASELINE.json configs[1]): 8 sessions, -M, 84x84, 1000-image base batch; 6 epochs per
+        # session so that the build's loop captures and replays its per-epoch hipGraph (~25 min of torch-CPU here)
+        gen_loop("hw84_noM_s8", 84, 8, False, 1000, seed=7, max_novel_epochs=6)
 
 
 if __name__ == "__main__":
