@@ -23,6 +23,8 @@
 // chunk ahead, the per-tap weight tile one step ahead, one barrier per step.
 //   bf16: v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16 by tile shape (mfma_tile below), fp32 accumulate
 //   f32 : v_mfma_f32_32x32x2_f32, bitwise an fmaf chain  (parity mode, 1e-4 gate)
+#include <stdlib.h>
+
 #include "conv_index.h"
 #include "subreg_common.h"
 
@@ -688,6 +690,15 @@ static int stats_rows_for(int dtype, int M, int Cout, int W) {
     return ((M + tm - 1) / tm) * 4;
 }
 
+int conv64_resident(const void* x, const void* w, void* y, const float* shift, const void* x2, const void* w2, int Cin2, int B,
+                    int H, int W, bool pool, int act, hipStream_t stream);      // conv64_resident.hip
+
+// measurement switch: SUBREG_NO_RESIDENT64=1 in the environment sends layer 1 through the general kernel (A/B runs)
+static bool resident64_enabled() {
+    static const bool on = [] { const char* e = getenv("SUBREG_NO_RESIDENT64"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
 }  // namespace subreg
 
 using namespace subreg;
@@ -723,6 +734,11 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
     // Tile height by problem size: the chip has 256 CUs x 2 resident workgroups, so small-M layers (10x10, 5x5
     // feature maps) take 128- or 64-row tiles to fill it.
     if (dtype == SUBREG_BF16) {
+        // layer 1's 3x3 convs (Cin = Cout = 64, eval mode): persistent kernel with register-resident weights (conv64_resident.hip)
+        if (Cin == 64 && Cout == 64 && a.g.taps == 9 && !raw && !residual && !scale && resident64_enabled()) {
+            const int rc = conv64_resident(x, w, y, shift, x2, w2, Cin2, B, H, W, pool, a.act, s);
+            if (rc != SUBREG_EUNSUPPORTED) return rc;
+        }
         if (!wide) {
             // Cout = 64 (layer 1): the unpooled convs stage 3 taps per step (64x64 wave tiles are barrier-bound at one)
             // 1x1 (the K=32 first layer): a streaming GEMM, 128-row tiles keep more workgroups in flight (-6 % vs 256 rows);

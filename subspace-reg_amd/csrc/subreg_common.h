@@ -60,6 +60,7 @@ __device__ __forceinline__ void dma16(const char* base_in, unsigned voff, unsign
     const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bu);
     const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bu >> 32));
     const char* base = (const char*)(size_t)(((unsigned long long)bhi << 32) | blo);
+    const unsigned lds_u = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);   // wave-uniform too (M0 is a scalar register)
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -68,7 +69,7 @@ __device__ __forceinline__ void dma16(const char* base_in, unsigned voff, unsign
         "global_load_lds_dwordx4 %1, %2\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voff), "s"(base), "s"(lds_addr)
+        : "v"(voff), "s"(base), "s"(lds_u)
         : "memory");
 }
 
