@@ -45,7 +45,33 @@ struct Conv64Args {
     FastDiv d_hw, d_w, d_pp, d_wp;   // H*W, W, Hp*Wp, Wp
 };
 
-constexpr int R64_TM = 256, R64_ROWB = 64, R64_NW = 8;
+constexpr int R64_ROWB = 64;
+#ifndef R64_TWO_WG
+#define R64_TWO_WG 1    // unpooled conv: 128-row tiles, two 4-wave workgroups per CU (0: one 8-wave workgroup, 256-row tiles)
+#endif
+constexpr int R64_TM_SMALL = 128;
+#ifndef R64_DIAG
+#define R64_DIAG 0      // 1: per-wave s_memtime stamps of the tile loop's phases into r64_diag (measurement builds only)
+#endif
+#if R64_DIAG
+__device__ float r64_diag[4096 * 8];   // [workgroup * waves + wave][8]: tiles, addr, chunk0, barrier1, chunk1, epilogue, dma wait, barrier2
+#endif
+#ifndef R64_DEPTH
+#define R64_DEPTH 4     // A-fragment reads in flight ahead of the MFMA that consumes them (+1)
+#endif
+
+// LDS fragment read whose completion the compiler must not guess: issued and waited for by hand (see `chunk` below)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 lds_read16(unsigned lds_addr) {
+    u32x4 d;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(lds_addr));
+    return d;
+}
+template <int N>
+__device__ __forceinline__ u32x4 lds_wait(u32x4 frag) {      // all but the N youngest LDS operations are done; `frag` is one of them
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N));
+    return frag;
+}
 
 template <bool POOL>
 __device__ __forceinline__ void r64_pixel(const Conv64Args& a, int m, int& p, int& h, int& w) {
@@ -65,9 +91,9 @@ __device__ __forceinline__ void r64_pixel(const Conv64Args& a, int m, int& p, in
 }
 
 // patch of tile rows [m0, m0 + 256): contiguous pixel range through all 9 taps ([lo, hi)) and without halo ([cf, cl])
-template <bool POOL>
+template <bool POOL, int TM>
 __device__ __forceinline__ void r64_range(const Conv64Args& a, int m0, int& lo, int& hi, int& cf, int& cl) {
-    int m1 = m0 + R64_TM;
+    int m1 = m0 + TM;
     if (m1 > a.M) m1 = a.M;
     int h, w;
     if (!POOL) {
@@ -85,9 +111,13 @@ __device__ __forceinline__ void r64_range(const Conv64Args& a, int m0, int& lo, 
     cf = __builtin_amdgcn_readfirstlane(cf); cl = __builtin_amdgcn_readfirstlane(cl);
 }
 
-// AROWS: patch rows an LDS plane holds (+ one zero row); XROWS: rows of the shortcut plane (tile rows without halo)
-template <bool POOL, bool SC, int AROWS, int XROWS>
-__global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const Conv64Args a) {
+// AROWS: patch rows an LDS plane holds (+ one zero row); XROWS: rows of the shortcut plane (tile rows without halo);
+// WM: waves along M (tile = 64 WM rows, 2 WM waves).  WM = 4: one 8-wave workgroup per CU; WM = 2: two independent 4-wave
+// workgroups per CU, whose phases (address arithmetic / MFMA / epilogue) drift apart and overlap - the 8 waves of one
+// workgroup run in lock step between the two barriers of a tile and leave the MFMA pipe idle during their common epilogue.
+template <bool POOL, bool SC, int AROWS, int XROWS, int WM>
+__global__ __launch_bounds__(2 * WM * 64, 2) void conv64_resident_kernel(const Conv64Args a) {
+    constexpr int R64_TM = 64 * WM, R64_NW = 2 * WM;
     constexpr int PLANE = (AROWS + 1) * R64_ROWB;                  // + zero row
     constexpr int XPLANE = SC ? (XROWS + 1) * R64_ROWB : 0;
     constexpr int SLAB_ROWS = POOL ? 8 : 32, SLAB_RS = 32 * 2 + 16;   // one wave's slab: rows x (32 bf16 + pad)
@@ -160,13 +190,19 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
     int t = t_begin;
     if (t >= t_end) return;
     int lo, hi, cf, cl;
-    r64_range<POOL>(a, t * R64_TM, lo, hi, cf, cl);
+    r64_range<POOL, R64_TM>(a, t * R64_TM, lo, hi, cf, cl);
     stage_plane(0, 0, lo, hi - lo);
     stage_plane(1, 1, lo, hi - lo);
     if (SC) stage_x2(cf, cl - cf + 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+#if R64_DIAG
+    unsigned long long dq = __builtin_amdgcn_s_memtime(), dt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define R64_STAMP(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dt[k] += n_ - dq; dq = n_; } while (0)
+#else
+#define R64_STAMP(k) do { } while (0)
+#endif
     for (int it = 0; t < t_end; ++it, t += nslot) {
         const int m0 = t * R64_TM;
         const int p0 = (2 * it) % 3, p1 = (2 * it + 1) % 3, pf = (2 * it + 2) % 3;   // planes: chunk 0, chunk 1, free
@@ -174,7 +210,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
         const bool more = tn < t_end;
         int nlo = 0, nhi = 0, ncf = 0, ncl = 0;
         if (more) {
-            r64_range<POOL>(a, tn * R64_TM, nlo, nhi, ncf, ncl);
+            r64_range<POOL, R64_TM>(a, tn * R64_TM, nlo, nhi, ncf, ncl);
             stage_plane(pf, 0, nlo, nhi - nlo);                    // next tile's chunk 0 -> the free plane
         }
         // per-lane LDS addresses (relative to a plane) of this lane's two A rows for the nine taps; k-step s is addr ^ 32 s
@@ -212,21 +248,44 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#if R64_DIAG
+        asm volatile("" : "+v"(apk[0]), "+v"(apk[8]));                // the address arithmetic ends here
+        dt[0] += 1;
+#endif
+        R64_STAMP(1);
 
         auto mma = [&](const uint4& av, const uint4& bv, f32x16& c) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
         };
+        // one channel chunk = 36 A-fragment reads (tap-major, then k-step, then row tile), each feeding one MFMA.  An LDS read
+        // takes ~100+ cycles and an MFMA 32, so the reads run RD - 1 fragments ahead of their use through a register ring.
+        // hipcc serialises read -> wait -> MFMA on one register when left alone (it minimises pressure), so the reads and
+        // their counted waits are inline asm: the wait statement names the fragment it completes ("+v"), which orders the
+        // MFMA behind it; no other LDS / scalar-memory operation is in flight inside a chunk (drained on entry).
         auto chunk = [&](int pl, int c) {
-            const char* pb = smem + pl * PLANE;
+            const unsigned pb = lds_base + pl * PLANE;
+            constexpr int NRD = 36, RD = R64_DEPTH;
+            u32x4 ring[RD];
+            auto rd = [&](int j) {
+                const int tt = j >> 2, s = (j >> 1) & 1, i = j & 1;
+                ring[j % RD] = lds_read16(pb + (aaddr(i, tt) ^ (32u * s)));
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int tt = 0; tt < 9; ++tt)
+            for (int j = 0; j < RD - 1; ++j) rd(j);
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const uint4 a0 = *reinterpret_cast<const uint4*>(pb + (aaddr(0, tt) ^ (32u * s)));
-                    const uint4 a1 = *reinterpret_cast<const uint4*>(pb + (aaddr(1, tt) ^ (32u * s)));
-                    mma(a0, bw[c][tt][s], acc[0]);
-                    mma(a1, bw[c][tt][s], acc[1]);
-                }
+            for (int j = 0; j < NRD; ++j) {
+                if (j + RD - 1 < NRD) rd(j + RD - 1);
+                const int left = NRD - 1 - j;                          // reads issued after fragment j
+                u32x4 f = ring[j % RD];
+                if (left >= RD - 1) f = lds_wait<RD - 1>(f);
+                else if (left == 3) f = lds_wait<3>(f);
+                else if (left == 2) f = lds_wait<2>(f);
+                else if (left == 1) f = lds_wait<1>(f);
+                else f = lds_wait<0>(f);
+                acc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f), __builtin_bit_cast(bf16x8, bw[c][j >> 2][(j >> 1) & 1]),
+                                                                      acc[j & 1], 0, 0, 0);
+            }
         };
         if (SC) {                                                   // shortcut GEMM first: its plane is re-staged at the mid barrier
 #pragma unroll
@@ -240,13 +299,17 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
         chunk(p0, 0);
         // every wave has finished reading plane p0 (and the shortcut plane): their data fed MFMAs already issued
         __builtin_amdgcn_sched_barrier(0);
+        R64_STAMP(2);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        R64_STAMP(3);
         if (more) {
             stage_plane(p0, 1, nlo, nhi - nlo);                    // next tile's chunk 1 -> the plane chunk 0 just left
             if (SC) stage_x2(ncf, ncl - ncf + 1);
         }
         chunk(p1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        R64_STAMP(4);
 
         // ---- epilogue: + shift, LeakyReLU, (2x2 max), bf16, through this wave's LDS slab, 16-byte stores
         // C layout of a 32x32 tile: column = lane % 32; register r holds row (r & 3) + 8 (r >> 2) + 4 (lane / 32)
@@ -286,24 +349,36 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        R64_STAMP(5);
         // the next tile's DMAs are older than this epilogue's stores: wait for all but the 2 NST youngest operations
         // (a ragged last tile may skip store instructions: wait for everything there)
         if (m0 + R64_TM > a.M) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (NST == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        R64_STAMP(6);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        R64_STAMP(7);
         lo = nlo; cf = ncf;
     }
+#if R64_DIAG
+    if (lane == 0 && blockIdx.x * R64_NW + wid < 4096) {
+        float* d = r64_diag + (size_t)(blockIdx.x * R64_NW + wid) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = (float)dt[k];
+    }
+#endif
 }
 
-template <bool POOL, bool SC, int AROWS, int XROWS>
+template <bool POOL, bool SC, int AROWS, int XROWS, int WM>
 static int launch_r64(const Conv64Args& a, hipStream_t stream) {
+    constexpr int NW = 2 * WM;
     constexpr int PLANE = (AROWS + 1) * R64_ROWB, XPLANE = SC ? (XROWS + 1) * R64_ROWB : 0;
     constexpr int SLAB = (POOL ? 8 : 32) * (32 * 2 + 16);
-    const size_t lds = 3 * (size_t)PLANE + XPLANE + R64_NW * SLAB + 64 * sizeof(float);
-    static_assert(3 * PLANE + XPLANE + R64_NW * SLAB + 256 <= 160 * 1024, "LDS budget");
-    auto kern = conv64_resident_kernel<POOL, SC, AROWS, XROWS>;
+    const size_t lds = 3 * (size_t)PLANE + XPLANE + NW * SLAB + 64 * sizeof(float);
+    static_assert((3 * PLANE + XPLANE + NW * SLAB + 256) * (WM == 2 ? 2 : 1) <= 160 * 1024, "LDS budget (two workgroups per CU when WM = 2)");
+    auto kern = conv64_resident_kernel<POOL, SC, AROWS, XROWS, WM>;
     static std::atomic<unsigned long long> lds_set{0};
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set)) return rc;
     int dev = 0, cus = 256;
@@ -311,10 +386,37 @@ static int launch_r64(const Conv64Args& a, hipStream_t stream) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    int grid = cus < a.ntiles ? cus : a.ntiles;                    // one persistent workgroup per CU
+    const int slots = cus * (WM == 2 ? 2 : 1);                     // persistent workgroups the chip holds at once
+    int grid = slots < a.ntiles ? slots : a.ntiles;
     grid = (grid + 7) / 8 * 8;                                     // whole XCD groups (surplus workgroups exit at once)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(R64_NW * 64), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, stream, a);
     return launch_status();
+}
+
+// rows a patch plane (with halo) and the shortcut plane (without) must hold for TM-row tiles: scan one period of tile starts
+// (tile t starts at window TM/4 * t; the pattern repeats after Hp*Wp tiles) plus the last tile
+static void r64_worst_rows(const ConvGeom& g, bool pool, int TM, int* worst_out, int* xworst_out) {
+    int worst = 1, xworst = 1;
+    const int ntiles = (g.M + TM - 1) / TM;
+    const int period = pool ? g.Hp * g.Wp + 1 : 3;
+    for (int k = 0; k <= period; ++k) {
+        const int t = k < period ? k : ntiles - 1;
+        if (t >= ntiles) continue;
+        int lo, hi;
+        int m1 = t * TM + TM;
+        if (m1 > g.M) m1 = g.M;
+        int core;
+        if (pool) {
+            patch_range<true>(g, t * TM, TM, &lo, &hi);
+            core = row_to_pixel<true>(g, (m1 - 1) | 3).p - row_to_pixel<true>(g, t * TM).p + 1;
+        } else {
+            patch_range<false>(g, t * TM, TM, &lo, &hi);
+            core = m1 - t * TM;
+        }
+        if (hi - lo > worst) worst = hi - lo;
+        if (core > xworst) xworst = core;
+    }
+    *worst_out = worst; *xworst_out = xworst;
 }
 
 // Returns SUBREG_EUNSUPPORTED when the shape is not this kernel's (the caller then uses the general kernel).
@@ -323,42 +425,33 @@ int conv64_resident(const void* x, const void* w, void* y, const float* shift, c
     if ((x2 != nullptr) != (w2 != nullptr) || (x2 && Cin2 != 32)) return SUBREG_EUNSUPPORTED;
     const ConvGeom g = make_geom(B, H, W, 9, pool);
     if ((long long)g.npix * (H * W) >= (1LL << 40) || g.npix >= (1 << 27)) return SUBREG_EUNSUPPORTED;   // FastDiv range, 32-bit offsets
-    // rows a patch plane (with halo) and the shortcut plane (without) must hold: scan one period of tile starts (tile t starts
-    // at window 64 t; the pattern repeats after Hp*Wp tiles) plus the first and last tile
-    int worst = 1, xworst = 1;
-    {
-        const int ntiles = (g.M + R64_TM - 1) / R64_TM;
-        const int period = pool ? g.Hp * g.Wp + 1 : 3;
-        for (int k = 0; k <= period; ++k) {
-            const int t = k < period ? k : ntiles - 1;
-            if (t >= ntiles) continue;
-            int lo, hi;
-            int m1 = t * R64_TM + R64_TM;
-            if (m1 > g.M) m1 = g.M;
-            int core;
-            if (pool) {
-                patch_range<true>(g, t * R64_TM, R64_TM, &lo, &hi);
-                core = row_to_pixel<true>(g, (m1 - 1) | 3).p - row_to_pixel<true>(g, t * R64_TM).p + 1;
-            } else {
-                patch_range<false>(g, t * R64_TM, R64_TM, &lo, &hi);
-                core = m1 - t * R64_TM;
-            }
-            if (hi - lo > worst) worst = hi - lo;
-            if (core > xworst) xworst = core;
-        }
-    }
     Conv64Args a;
     a.x = (const char*)x; a.w = (const char*)w; a.x2 = (const char*)x2; a.w2 = (const char*)w2; a.y = (char*)y; a.shift = shift;
     a.H = H; a.W = W; a.Hp = g.Hp; a.Wp = g.Wp; a.npix = g.npix; a.M = g.M; a.act = act;
-    a.ntiles = (g.M + R64_TM - 1) / R64_TM;
     a.d_hw = make_fastdiv(H * W); a.d_w = make_fastdiv(W);
     a.d_pp = make_fastdiv(g.Hp * g.Wp > 0 ? g.Hp * g.Wp : 1); a.d_wp = make_fastdiv(g.Wp > 0 ? g.Wp : 1);
+    int worst, xworst;
     if (!pool) {
-        if (worst > 432 || xworst > 256) return SUBREG_EUNSUPPORTED;
-        return x2 ? launch_r64<false, true, 432, 256>(a, stream) : launch_r64<false, false, 432, 256>(a, stream);
+        r64_worst_rows(g, false, R64_TM_SMALL, &worst, &xworst);
+        if (R64_TWO_WG && worst <= 304) {                              // 128-row tiles, two workgroups per CU
+            a.ntiles = (g.M + R64_TM_SMALL - 1) / R64_TM_SMALL;
+            return x2 ? launch_r64<false, true, 304, 128, 2>(a, stream) : launch_r64<false, false, 304, 128, 2>(a, stream);
+        }
+        r64_worst_rows(g, false, 256, &worst, &xworst);
+        if (worst > 432) return SUBREG_EUNSUPPORTED;
+        a.ntiles = (g.M + 255) / 256;
+        return x2 ? launch_r64<false, true, 432, 256, 4>(a, stream) : launch_r64<false, false, 432, 256, 4>(a, stream);
     }
+    r64_worst_rows(g, true, 256, &worst, &xworst);
     if (worst > 560 || xworst > 384) return SUBREG_EUNSUPPORTED;
-    return x2 ? launch_r64<true, true, 560, 384>(a, stream) : launch_r64<true, false, 560, 384>(a, stream);
+    a.ntiles = (g.M + 255) / 256;
+    return x2 ? launch_r64<true, true, 560, 384, 4>(a, stream) : launch_r64<true, false, 560, 384, 4>(a, stream);
 }
+
+#if R64_DIAG
+extern "C" int subreg_r64_diag_read(float* host_out, int n_floats) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(r64_diag), sizeof(float) * n_floats) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace subreg

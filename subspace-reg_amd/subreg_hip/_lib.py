@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsubreg_hip.so")
+# SUBREG_LIB: another build of the same library (kernel experiments: several variants measured in one process group)
+LIB_PATH = os.environ.get("SUBREG_LIB") or os.path.join(_HERE, "libsubreg_hip.so")
 
 F32, BF16 = 0, 1
 CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
