@@ -1,25 +1,45 @@
-// Layer-1 3x3 convolutions (Cin = Cout = 64, 84x84 maps: models/resnet_language.py:249-256 conv2 / conv3 of layer1.0) as a
-// PERSISTENT implicit GEMM with REGISTER-RESIDENT weights, bf16, eval mode (BN scale folded into the weights, shift +
+// Layer-1 3x3 convolutions (Cin = Cout = 64 on 84x84 maps: models/resnet_language.py:249-256, conv2 / conv3 of layer1.0) as a
+// PERSISTENT implicit GEMM with REGISTER-RESIDENT weights, bf16, eval mode (BN scale folded into the weights; shift +
 // LeakyReLU(0.1) + optional MaxPool2d(2) + the fused K=32 shortcut GEMM of conv3 in the epilogue, :268-301).
 //
-// Why a second kernel for this shape (measurements of the general kernel in profiles/r01_conv_stamps.txt): with K = 576
-// and N = 64 a 256-row tile is only 4.6 k MFMA cycles per wave, but it stages 74 KB of weights + 55 KB of activation
-// patch and pays a 5.5 k-cycle prologue and a 4.3 k-cycle epilogue per tile - the layer ran at 23-25 % of the MFMA peak
-// and is 20 % of the backbone's time.  Here:
-//   * one workgroup of 8 waves per CU, looping over m-tiles (persistent): no per-tile prologue, the next tile's patch is
-//     prefetched by LDS-DMA while this tile computes;
-//   * the WHOLE weight matrix lives in registers: wave (wm, h) owns output rows [64 wm, 64 wm + 64) x columns
-//     [32 h, 32 h + 32) of the 256 x 64 tile and keeps the 36 B fragments (9 taps x 2 channel chunks x 2 k-steps) of its 32
-//     columns in 144 VGPRs for the whole kernel - no weight staging, no weight LDS reads, ever;
-//   * LDS holds only activation planes ([row][32 channels], 64-byte rows, XOR-swizzled like conv_index.h::swz): three
-//     planes in rotation (chunk 0 / chunk 1 of this tile, chunk 0 of the next), plus the K=32 shortcut rows of conv3;
-//     two workgroup barriers per tile.
-// Same data layouts, same row orders (LINEAR / POOL window-major) and the same numerics as conv_fwd.hip: fp32
-// accumulation over taps in the same tap order per k-step.
+// Why a second kernel for this shape: with K = 576 and N = 64 a 256-row tile is only 4.6 k MFMA cycles per wave; the general
+// kernel (conv_fwd.hip) stages 74 KB of weights + 55 KB of patch per tile and pays a 5.5 k-cycle prologue and a 4.3 k-cycle
+// epilogue around them - 23-25 % of the MFMA peak on 20 % of the backbone's time (profiles/r01_conv_stamps.txt).  A first
+// persistent version with per-tile address arithmetic turned out VALU-ISSUE bound (in-kernel stamps: ~900 instructions per
+// 72 MFMAs per wave and tile, a quarter of them address arithmetic).  This version removes the per-tile arithmetic:
+//   * one workgroup of 8 waves per CU loops over tiles (persistent); the next tile's patch is prefetched by LDS-DMA;
+//   * the WHOLE weight matrix lives in registers: wave (wm, wh) owns rows [64 wm, +64) x columns [32 wh, +32) of the
+//     256 x 64 tile and keeps the 36 B fragments (9 taps x 2 channel chunks x 2 k-steps) of its columns in 144 VGPRs;
+//   * LDS holds activation planes ([row][32 channels], 64-byte rows, XOR-swizzled like conv_index.h::swz) in a PADDED image
+//     layout: every image row of the patch is a block of P = 96 LDS rows (one zero row, the W pixels, zero rows), rows
+//     outside the image are blocks of zeros.  A tap is then a CONSTANT offset: dy = +-1 is +-P rows (an immediate of the
+//     ds_read), dx = +-1 a second / third base register; no validity selects (the zero padding does it), and because a
+//     LINEAR tile is a whole number of image rows (3 rows = 252 of 256 GEMM rows) its per-lane addresses are the same
+//     for every tile - computed once per kernel.  POOL tiles are 63 windows (1.5 row pairs): two alternating geometries.
+// Same data layouts and row orders (LINEAR / POOL window-major) as conv_fwd.hip; fp32 accumulation.
+#include <type_traits>
+
 #include "conv_index.h"
 #include "subreg_common.h"
 
 namespace subreg {
+
+#ifndef R64_DEPTH
+#define R64_DEPTH 4     // A-fragment reads in flight ahead of the MFMA that consumes them (+1)
+#endif
+#ifndef R64_DIAG
+#define R64_DIAG 0      // 1: per-wave s_memtime stamps of the tile loop's phases into r64_diag (measurement builds only)
+#endif
+#if R64_DIAG
+__device__ float r64_diag[4096 * 12];   // [workgroup * 8 + wave][8]: tiles, setup, chunk0, barrier1, chunk1, epilogue, dma wait, barrier2
+#endif
+
+// 128 zero bytes: the DMA source of patch blocks that lie outside the image (rows above the top / below the bottom)
+__device__ __attribute__((aligned(128))) unsigned r64_zero_line[32];
+
+constexpr int R64_P = 96;            // LDS rows per image row of the patch (W + 1 <= P, multiple of 16)
+constexpr int R64_ROWB = 64;         // bytes per LDS row (32 bf16 channels)
+constexpr int R64_NW = 8;            // waves per workgroup
 
 // n / d for n * d < 2^40 (checked on the host): (n * ceil(2^40 / d)) >> 40
 struct FastDiv {
@@ -41,30 +61,26 @@ struct Conv64Args {
     const char* w2;      // [64][32] bf16
     char* y;             // LINEAR [npix][64] ; POOL [B*Hp*Wp][64]
     const float* shift;  // [64]
-    int H, W, Hp, Wp, npix, M, act, ntiles;
-    FastDiv d_hw, d_w, d_pp, d_wp;   // H*W, W, Hp*Wp, Wp
+    int H, W, act, ntiles, tpi;      // tpi: tiles per image
+    int R;                           // LINEAR: image rows per tile
+    int Hp, Wp, WT, nwin;            // POOL: windows per tile, windows per image
+    FastDiv d_w, d_wp, d_tpi;        // W, Wp, tiles per image
 };
 
-constexpr int R64_ROWB = 64;
-#ifndef R64_TWO_WG
-#define R64_TWO_WG 1    // unpooled conv: 128-row tiles, two 4-wave workgroups per CU (0: one 8-wave workgroup, 256-row tiles)
-#endif
-constexpr int R64_TM_SMALL = 128;
-#ifndef R64_DIAG
-#define R64_DIAG 0      // 1: per-wave s_memtime stamps of the tile loop's phases into r64_diag (measurement builds only)
-#endif
-#if R64_DIAG
-__device__ float r64_diag[4096 * 8];   // [workgroup * waves + wave][8]: tiles, addr, chunk0, barrier1, chunk1, epilogue, dma wait, barrier2
-#endif
-#ifndef R64_DEPTH
-#define R64_DEPTH 4     // A-fragment reads in flight ahead of the MFMA that consumes them (+1)
-#endif
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 // LDS fragment read whose completion the compiler must not guess: issued and waited for by hand (see `chunk` below)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
 __device__ __forceinline__ u32x4 lds_read16(unsigned lds_addr) {
     u32x4 d;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(lds_addr));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(lds_addr), "n"(OFF));
     return d;
 }
 template <int N>
@@ -73,60 +89,20 @@ __device__ __forceinline__ u32x4 lds_wait(u32x4 frag) {      // all but the N yo
     return frag;
 }
 
-template <bool POOL>
-__device__ __forceinline__ void r64_pixel(const Conv64Args& a, int m, int& p, int& h, int& w) {
-    if (!POOL) {
-        const unsigned img = fdiv((unsigned)m, a.d_hw), rem = (unsigned)m - img * a.d_hw.d;
-        h = (int)fdiv(rem, a.d_w);
-        w = (int)(rem - (unsigned)h * a.d_w.d);
-        p = m;
-    } else {
-        const unsigned win = (unsigned)m >> 2, sub = (unsigned)m & 3;
-        const unsigned b = fdiv(win, a.d_pp), rem = win - b * a.d_pp.d;
-        const unsigned hp = fdiv(rem, a.d_wp), wp = rem - hp * a.d_wp.d;
-        h = (int)(2 * hp + (sub >> 1));
-        w = (int)(2 * wp + (sub & 1));
-        p = ((int)b * a.H + h) * a.W + w;
-    }
-}
-
-// patch of tile rows [m0, m0 + 256): contiguous pixel range through all 9 taps ([lo, hi)) and without halo ([cf, cl])
-template <bool POOL, int TM>
-__device__ __forceinline__ void r64_range(const Conv64Args& a, int m0, int& lo, int& hi, int& cf, int& cl) {
-    int m1 = m0 + TM;
-    if (m1 > a.M) m1 = a.M;
-    int h, w;
-    if (!POOL) {
-        cf = m0; cl = m1 - 1;
-    } else {
-        r64_pixel<true>(a, m0, cf, h, w);
-        r64_pixel<true>(a, (m1 - 1) | 3, cl, h, w);
-    }
-    lo = cf - (a.W + 1);
-    hi = cl + (a.W + 1) + 1;
-    if (lo < 0) lo = 0;
-    if (hi > a.npix) hi = a.npix;
-    // wave-uniform by construction (functions of the tile index); say so: they steer DMA loops and scalar operands
-    lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
-    cf = __builtin_amdgcn_readfirstlane(cf); cl = __builtin_amdgcn_readfirstlane(cl);
-}
-
-// AROWS: patch rows an LDS plane holds (+ one zero row); XROWS: rows of the shortcut plane (tile rows without halo);
-// WM: waves along M (tile = 64 WM rows, 2 WM waves).  WM = 4: one 8-wave workgroup per CU; WM = 2: two independent 4-wave
-// workgroups per CU, whose phases (address arithmetic / MFMA / epilogue) drift apart and overlap - the 8 waves of one
-// workgroup run in lock step between the two barriers of a tile and leave the MFMA pipe idle during their common epilogue.
-template <bool POOL, bool SC, int AROWS, int XROWS, int WM>
-__global__ __launch_bounds__(2 * WM * 64, 2) void conv64_resident_kernel(const Conv64Args a) {
-    constexpr int R64_TM = 64 * WM, R64_NW = 2 * WM;
-    constexpr int PLANE = (AROWS + 1) * R64_ROWB;                  // + zero row
-    constexpr int XPLANE = SC ? (XROWS + 1) * R64_ROWB : 0;
+// BLOCKS: image-row blocks per plane (LINEAR R + 2 = 5, POOL 2 row pairs + halo = 6)
+template <bool POOL, bool SC, int BLOCKS>
+__global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const Conv64Args a) {
+    constexpr int P = R64_P, PROWS = BLOCKS * P, PLANE = PROWS * R64_ROWB, PIECES = PROWS / 16, PPB = P / 16;
+    constexpr int NPK = (PIECES + R64_NW - 1) / R64_NW;              // DMA pieces per wave and plane
     constexpr int SLAB_ROWS = POOL ? 8 : 32, SLAB_RS = 32 * 2 + 16;   // one wave's slab: rows x (32 bf16 + pad)
     constexpr int SLAB = SLAB_ROWS * SLAB_RS;
-    constexpr int X_BASE = 3 * PLANE, SLAB_BASE = X_BASE + XPLANE, SHIFT_BASE = SLAB_BASE + R64_NW * SLAB;
-    static_assert(AROWS % 16 == 0 && (!SC || XROWS % 16 == 0), "DMA pieces are 16 rows");
-    static_assert(PLANE < 65536 && XPLANE < 65536, "packed A addresses are 16-bit");
+    constexpr int X_BASE = 3 * PLANE, SLAB_BASE = X_BASE + (SC ? PLANE : 0), SHIFT_BASE = SLAB_BASE + R64_NW * SLAB;
+    static_assert(2 * P * R64_ROWB < 65536, "tap offsets are 16-bit immediates");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+#if R64_DIAG
+    const unsigned long long d_entry = __builtin_amdgcn_s_memtime(), d_entry_r = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wh = wid & 1;                          // row quarter, column half of the 256 x 64 tile
@@ -138,6 +114,7 @@ __global__ __launch_bounds__(2 * WM * 64, 2) void conv64_resident_kernel(const C
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = (nwg + 7 - xcd) >> 3;
     const int per = (a.ntiles + 7) >> 3;
     const int t_begin = xcd * per + slot, t_end = min((xcd + 1) * per, a.ntiles);
+    if (t_begin >= t_end) return;
 
     // ---- resident weights: B fragments of this wave's 32 output columns, all taps / chunks / k-steps (144 VGPRs)
     uint4 bw[2][9][2];
@@ -157,146 +134,170 @@ __global__ __launch_bounds__(2 * WM * 64, 2) void conv64_resident_kernel(const C
         bw2[0] = *reinterpret_cast<const uint4*>(wl);
         bw2[1] = *reinterpret_cast<const uint4*>(wl + 32);
     }
-    // zero rows (row AROWS of every plane, row XROWS of the shortcut plane) and this wave's shift values
-    if (tid < 16) {
-        const int pl = tid >> 2, q = tid & 3;
-        if (pl < 3) *reinterpret_cast<uint4*>(smem + pl * PLANE + AROWS * R64_ROWB + q * 16) = make_uint4(0, 0, 0, 0);
-        else if (SC) *reinterpret_cast<uint4*>(smem + X_BASE + XROWS * R64_ROWB + q * 16) = make_uint4(0, 0, 0, 0);
-    }
+    // ---- LDS starts as zeros: the pad rows of every block are never written again (the DMAs mask those lanes off)
+    for (int o = tid * 16; o < SLAB_BASE; o += R64_NW * 64 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
     float* const s_shift = reinterpret_cast<float*>(smem + SHIFT_BASE);
     if (tid < 64) s_shift[tid] = a.shift[tid];
+    __syncthreads();                                                // zeros are in LDS before any DMA may land on them
 
-    const int prl = lane >> 2, psl = lane & 3;                      // row within a DMA piece, physical 16-byte slot
-    // stage channel chunk `c` of the patch rows [lo, lo + rows) into plane `pl` (pieces dealt round-robin over the waves)
-    auto stage_plane = [&](int pl, int c, int lo, int rows) {
-        const char* base = a.x + (size_t)lo * 128 + c * 64;         // wave-uniform
-        const int pieces = (rows + 15) >> 4;
-        for (int q = wid; q < pieces; q += R64_NW) {
-            const int row = q * 16 + prl;
-            const int srow = row < rows ? row : rows - 1;
-            dma16(base, (unsigned)srow * 128u + ((psl ^ swz<4>(row)) << 4), lds_base + pl * PLANE + q * 1024);
+    // ---- DMA geometry, the same for every tile: piece q = wid + 8 k covers LDS rows 16 q .. 16 q + 15 of a plane = block
+    //      q / 6, columns 16 (q % 6) .. + 15 of the padded image row (column c holds pixel c - 1; 0 and W+1.. are pads)
+    const int prl = lane >> 2, psl = lane & 3;                      // row within a piece, physical 16-byte slot
+    unsigned goff[NPK], goff2[NPK];                                 // this lane's byte offset from the patch origin in x / in x2
+    bool isdata[NPK];
+#pragma unroll
+    for (int k = 0; k < NPK; ++k) {
+        const int q = wid + R64_NW * k, idx = q * 16 + prl, rb = q / PPB, c = idx - rb * P;
+        const unsigned slot16 = (unsigned)(psl ^ swz<4>(idx)) << 4;
+        isdata[k] = q < PIECES && c >= 1 && c <= a.W;
+        goff[k] = (unsigned)(rb * a.W + c - 1) * 128u + slot16;
+        goff2[k] = (unsigned)(rb * a.W + c - 1) * 64u + slot16;
+    }
+    // stage chunk `c` (c = 2: the shortcut rows of x2) of the patch whose block 0 is image row `h_first` of image `b`
+    auto stage = [&](unsigned dst, int c, int b, int h_first) {
+        const long long origin = ((long long)b * a.H + h_first) * a.W;          // pixel index of (block 0, column 1); may lie before x
+        const char* const zero = reinterpret_cast<const char*>(r64_zero_line);
+#pragma unroll
+        for (int k = 0; k < NPK; ++k) {
+            const int q = wid + R64_NW * k;
+            if (q < PIECES) {                                                   // wave-uniform
+                const int rb = q / PPB, h = h_first + rb;
+                const bool halo = rb == 0 || rb == BLOCKS - 1;                  // the shortcut GEMM reads the centre tap only
+                const bool inside = h >= 0 && h < a.H;                          // wave-uniform: a block is in or out of the image
+                if (!(c == 2 && halo) && isdata[k]) {
+                    if (!inside) dma16(zero, (unsigned)psl << 4, dst + q * 1024);
+                    else if (c == 2) dma16(a.x2 + origin * 64, goff2[k], dst + q * 1024);
+                    else dma16(a.x + origin * 128 + c * 64, goff[k], dst + q * 1024);
+                }
+            }
         }
     };
-    auto stage_x2 = [&](int cf, int rows) {
-        const char* base = a.x2 + (size_t)cf * 64;
-        const int pieces = (rows + 15) >> 4;
-        for (int q = wid; q < pieces; q += R64_NW) {
-            const int row = q * 16 + prl;
-            const int srow = row < rows ? row : rows - 1;
-            dma16(base, (unsigned)srow * 64u + ((psl ^ swz<4>(row)) << 4), lds_base + X_BASE + q * 1024);
+
+    // ---- per-lane A addresses, plane-relative, of the dy = -1 row: [row tile i][dx + 1][k-step]; tap (dy, dx) of a chunk =
+    //      areg[i][dx+1][s] + plane base + immediate (dy + 1) * P * 64
+    unsigned areg[2][3][2];
+    auto set_addresses = [&](int i, int hrel, int w) {              // hrel: block of the pixel's row, minus one
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int row = hrel * P + w + dx;                      // column (w + 1) + (dx - 1)
+            const unsigned ad = (unsigned)row * R64_ROWB + 16u * (lh ^ swz<4>(row));
+            areg[i][dx][0] = ad;
+            areg[i][dx][1] = ad ^ 32u;
+        }
+    };
+    if (!POOL) {
+        // LINEAR: tile = R whole image rows; GEMM row j = (image row j / W, column j % W); rows >= R W are padding
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = wm * 64 + i * 32 + lr, jv = j < a.R * a.W ? j : 0;
+            const int ir = (int)fdiv((unsigned)jv, a.d_w), w = jv - ir * a.W;
+            set_addresses(i, ir, w);
+        }
+    }
+
+    // ---- tile -> (image, image row of block 0, first window within its row pair).  LINEAR: tile k of an image starts at
+    //      image row R k.  POOL: tile k covers windows [WT k, WT k + WT) of the image (row pairs 2 rp, 2 rp + 1)
+    auto tile_geom = [&](int t, int& b, int& k_img, int& h_first, int& s0) {
+        const int bb = (int)fdiv((unsigned)t, a.d_tpi), k = t - bb * a.tpi;
+        b = __builtin_amdgcn_readfirstlane(bb);
+        k_img = __builtin_amdgcn_readfirstlane(k);
+        if (!POOL) {
+            h_first = k_img * a.R - 1;
+            s0 = 0;
+        } else {
+            const int win0 = k_img * a.WT, rp0 = (int)fdiv((unsigned)win0, a.d_wp);
+            h_first = __builtin_amdgcn_readfirstlane(2 * rp0 - 1);
+            s0 = __builtin_amdgcn_readfirstlane(win0 - rp0 * a.Wp);
         }
     };
 
-    int t = t_begin;
-    if (t >= t_end) return;
-    int lo, hi, cf, cl;
-    r64_range<POOL, R64_TM>(a, t * R64_TM, lo, hi, cf, cl);
-    stage_plane(0, 0, lo, hi - lo);
-    stage_plane(1, 1, lo, hi - lo);
-    if (SC) stage_x2(cf, cl - cf + 1);
+    int t = t_begin, b, k_img, h_first, s0;
+    tile_geom(t, b, k_img, h_first, s0);
+    stage(lds_base + 0 * PLANE, 0, b, h_first);
+    stage(lds_base + 1 * PLANE, 1, b, h_first);
+    if (SC) stage(lds_base + X_BASE, 2, b, h_first);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
 #if R64_DIAG
     unsigned long long dq = __builtin_amdgcn_s_memtime(), dt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long d_c0 = dq, d_r0 = __builtin_amdgcn_s_memrealtime();
 #define R64_STAMP(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dt[k] += n_ - dq; dq = n_; } while (0)
 #else
 #define R64_STAMP(k) do { } while (0)
 #endif
     for (int it = 0; t < t_end; ++it, t += nslot) {
-        const int m0 = t * R64_TM;
         const int p0 = (2 * it) % 3, p1 = (2 * it + 1) % 3, pf = (2 * it + 2) % 3;   // planes: chunk 0, chunk 1, free
         const int tn = t + nslot;
         const bool more = tn < t_end;
-        int nlo = 0, nhi = 0, ncf = 0, ncl = 0;
+        int nb = 0, nk = 0, nh = 0, ns0 = 0;
         if (more) {
-            r64_range<POOL, R64_TM>(a, tn * R64_TM, nlo, nhi, ncf, ncl);
-            stage_plane(pf, 0, nlo, nhi - nlo);                    // next tile's chunk 0 -> the free plane
+            tile_geom(tn, nb, nk, nh, ns0);
+            stage(lds_base + pf * PLANE, 0, nb, nh);               // next tile's chunk 0 -> the free plane
         }
-        // per-lane LDS addresses (relative to a plane) of this lane's two A rows for the nine taps; k-step s is addr ^ 32 s
-        unsigned apk[9], axs = 0;
+        if (POOL) {
+            // GEMM row j = window s0 + j / 4 counted from the start of the tile's first row pair, pixel j % 4 of that window
 #pragma unroll
-        for (int k = 0; k < 9; ++k) apk[k] = 0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = m0 + wm * 64 + i * 32 + lr;
-            const bool mv = m < a.M;
-            int p, h, w;
-            r64_pixel<POOL>(a, mv ? m : 0, p, h, w);
-            const bool up = h > 0, dn = h < a.H - 1, lf = w > 0, rt = w < a.W - 1;
-#pragma unroll
-            for (int tt = 0; tt < 9; ++tt) {
-                const int dy = tt / 3 - 1, dx = tt % 3 - 1;
-                const bool ok = mv && (dy < 0 ? up : dy > 0 ? dn : true) && (dx < 0 ? lf : dx > 0 ? rt : true);
-                const int row = p + dy * a.W + dx - lo;
-                const unsigned ad = ok ? (unsigned)row * R64_ROWB + 16u * (lh ^ swz<4>(row)) : (unsigned)AROWS * R64_ROWB + 16u * lh;
-                apk[(i * 9 + tt) >> 1] |= ad << (16 * ((i * 9 + tt) & 1));
-            }
-            if (SC) {
-                const int row = p - cf;
-                const unsigned ad = mv ? (unsigned)row * R64_ROWB + 16u * (lh ^ swz<4>(row)) : (unsigned)XROWS * R64_ROWB + 16u * lh;
-                axs |= ad << (16 * i);
+            for (int i = 0; i < 2; ++i) {
+                const int j = wm * 64 + i * 32 + lr, wq = s0 + (j >> 2), sub = j & 3;
+                // (a window beyond the tile's WT can reach a third row pair; it is never stored: fold it back into the second)
+                const int rp = wq >= a.Wp ? 1 : 0, wp = wq - (wq >= 2 * a.Wp ? 2 : rp) * a.Wp;
+                set_addresses(i, 2 * rp + (sub >> 1), 2 * wp + (sub & 1));
             }
         }
-        auto aaddr = [&](int i, int tt) -> unsigned {
-            const int idx = i * 9 + tt;
-            return (idx & 1) ? (apk[idx >> 1] >> 16) : (apk[idx >> 1] & 0xffffu);
-        };
-
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #if R64_DIAG
-        asm volatile("" : "+v"(apk[0]), "+v"(apk[8]));                // the address arithmetic ends here
         dt[0] += 1;
 #endif
         R64_STAMP(1);
 
-        auto mma = [&](const uint4& av, const uint4& bv, f32x16& c) {
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
-        };
         // one channel chunk = 36 A-fragment reads (tap-major, then k-step, then row tile), each feeding one MFMA.  An LDS read
         // takes ~100+ cycles and an MFMA 32, so the reads run RD - 1 fragments ahead of their use through a register ring.
         // hipcc serialises read -> wait -> MFMA on one register when left alone (it minimises pressure), so the reads and
         // their counted waits are inline asm: the wait statement names the fragment it completes ("+v"), which orders the
         // MFMA behind it; no other LDS / scalar-memory operation is in flight inside a chunk (drained on entry).
-        auto chunk = [&](int pl, int c) {
-            const unsigned pb = lds_base + pl * PLANE;
+        auto chunk = [&](int pl, auto cc) {
+            constexpr int c = decltype(cc)::value;
             constexpr int NRD = 36, RD = R64_DEPTH;
+            unsigned ta[2][3][2];
+            const unsigned pb = lds_base + pl * PLANE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) ta[i][dx][s] = areg[i][dx][s] + pb;
             u32x4 ring[RD];
-            auto rd = [&](int j) {
-                const int tt = j >> 2, s = (j >> 1) & 1, i = j & 1;
-                ring[j % RD] = lds_read16(pb + (aaddr(i, tt) ^ (32u * s)));
+            auto rd = [&](auto jc) {
+                constexpr int j = decltype(jc)::value, tt = j >> 2, s = (j >> 1) & 1, i = j & 1, dy = tt / 3, dx = tt % 3;
+                ring[j % RD] = lds_read16<dy * P * R64_ROWB>(ta[i][dx][s]);
             };
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int j = 0; j < RD - 1; ++j) rd(j);
-#pragma unroll
-            for (int j = 0; j < NRD; ++j) {
-                if (j + RD - 1 < NRD) rd(j + RD - 1);
-                const int left = NRD - 1 - j;                          // reads issued after fragment j
+            static_for<0, RD - 1>(rd);
+            static_for<0, NRD>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (j + RD - 1 < NRD) rd(std::integral_constant<int, j + RD - 1>{});
+                constexpr int left = NRD - 1 - j;                     // reads issued after fragment j
                 u32x4 f = ring[j % RD];
-                if (left >= RD - 1) f = lds_wait<RD - 1>(f);
-                else if (left == 3) f = lds_wait<3>(f);
-                else if (left == 2) f = lds_wait<2>(f);
-                else if (left == 1) f = lds_wait<1>(f);
-                else f = lds_wait<0>(f);
-                acc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f), __builtin_bit_cast(bf16x8, bw[c][j >> 2][(j >> 1) & 1]),
-                                                                      acc[j & 1], 0, 0, 0);
-            }
+                f = lds_wait<(left >= RD - 1 ? RD - 1 : left)>(f);
+                acc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f),
+                                                                      __builtin_bit_cast(bf16x8, bw[c][j >> 2][(j >> 1) & 1]), acc[j & 1], 0, 0, 0);
+            });
         };
         if (SC) {                                                   // shortcut GEMM first: its plane is re-staged at the mid barrier
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const uint4 a0 = *reinterpret_cast<const uint4*>(smem + X_BASE + ((axs & 0xffffu) ^ (32u * s)));
-                const uint4 a1 = *reinterpret_cast<const uint4*>(smem + X_BASE + ((axs >> 16) ^ (32u * s)));
-                mma(a0, bw2[s], acc[0]);
-                mma(a1, bw2[s], acc[1]);
+                const uint4 a0 = *reinterpret_cast<const uint4*>(smem + X_BASE + P * R64_ROWB + areg[0][1][s]);
+                const uint4 a1 = *reinterpret_cast<const uint4*>(smem + X_BASE + P * R64_ROWB + areg[1][1][s]);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bw2[s]), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bw2[s]), acc[1], 0, 0, 0);
             }
         }
-        chunk(p0, 0);
+        chunk(p0, std::integral_constant<int, 0>{});
         // every wave has finished reading plane p0 (and the shortcut plane): their data fed MFMAs already issued
         __builtin_amdgcn_sched_barrier(0);
         R64_STAMP(2);
@@ -304,10 +305,10 @@ __global__ __launch_bounds__(2 * WM * 64, 2) void conv64_resident_kernel(const C
         __builtin_amdgcn_sched_barrier(0);
         R64_STAMP(3);
         if (more) {
-            stage_plane(p0, 1, nlo, nhi - nlo);                    // next tile's chunk 1 -> the plane chunk 0 just left
-            if (SC) stage_x2(ncf, ncl - ncf + 1);
+            stage(lds_base + p0 * PLANE, 1, nb, nh);                // next tile's chunk 1 -> the plane chunk 0 just left
+            if (SC) stage(lds_base + X_BASE, 2, nb, nh);
         }
-        chunk(p1, 1);
+        chunk(p1, std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
         R64_STAMP(4);
 
@@ -315,11 +316,15 @@ __global__ __launch_bounds__(2 * WM * 64, 2) void conv64_resident_kernel(const C
         // C layout of a 32x32 tile: column = lane % 32; register r holds row (r & 3) + 8 (r >> 2) + 4 (lane / 32)
         char* const slab = smem + SLAB_BASE + wid * SLAB;
         const float sh = s_shift[32 * wh + lr];
-        constexpr int NST = POOL ? 1 : 2;                           // global-store instructions per 32-row MFMA tile
+        bool ragged;
+        if (!POOL) {
+            // output rows of the tile = pixels [pix0, pix0 + nvalid): contiguous (whole image rows)
+            const int rows_left = a.H - k_img * a.R, nvalid = (rows_left < a.R ? rows_left : a.R) * a.W;
+            const long long pix0 = ((long long)b * a.H + (long long)k_img * a.R) * a.W;
+            ragged = nvalid <= 224;                                 // the last 32-row slab's stores may be skipped altogether
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int mrow0 = m0 + wm * 64 + i * 32;
-            if (!POOL) {
+            for (int i = 0; i < 2; ++i) {
+                const int jrow0 = wm * 64 + i * 32;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[i][r] + sh;
@@ -331,10 +336,18 @@ __global__ __launch_bounds__(2 * WM * 64, 2) void conv64_resident_kernel(const C
                 for (int v0 = 0; v0 < 128; v0 += 64) {             // 32 rows x 4 vectors of 16 bytes
                     const int v = v0 + lane, row = v >> 2, c16 = v & 3;
                     const uint4 val = *reinterpret_cast<const uint4*>(slab + row * SLAB_RS + c16 * 16);
-                    if (mrow0 + row < a.M)
-                        *reinterpret_cast<uint4*>(a.y + (size_t)(mrow0 + row) * 128 + wh * 64 + c16 * 16) = val;
+                    if (jrow0 + row < nvalid)
+                        *reinterpret_cast<uint4*>(a.y + (size_t)(pix0 + jrow0 + row) * 128 + wh * 64 + c16 * 16) = val;
                 }
-            } else {
+            }
+        } else {
+            // pooled output rows = windows [win0, win0 + nv) of image b: contiguous in the [B Hp Wp][64] output
+            const int win0 = k_img * a.WT, left = a.nwin - win0, nv = left < a.WT ? left : a.WT;
+            const long long out0 = (long long)b * a.nwin + win0;
+            ragged = nv <= 56;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int wrow0 = (wm * 64 + i * 32) >> 2;          // first window of this 32-row MFMA tile
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {                       // registers 4q .. 4q+3 = rows 8q + 4 lh + {0..3} = one window
                     float best = fmaxf(fmaxf(acc[i][4 * q], acc[i][4 * q + 1]), fmaxf(acc[i][4 * q + 2], acc[i][4 * q + 3])) + sh;
@@ -344,41 +357,49 @@ __global__ __launch_bounds__(2 * WM * 64, 2) void conv64_resident_kernel(const C
                 const int row = lane >> 2, c16 = lane & 3;          // 8 pooled rows x 4 vectors: lanes 0..31
                 if (lane < 32) {
                     const uint4 val = *reinterpret_cast<const uint4*>(slab + row * SLAB_RS + c16 * 16);
-                    if (mrow0 + 4 * row < a.M)
-                        *reinterpret_cast<uint4*>(a.y + (size_t)((mrow0 >> 2) + row) * 128 + wh * 64 + c16 * 16) = val;
+                    if (wrow0 + row < nv)
+                        *reinterpret_cast<uint4*>(a.y + (size_t)(out0 + wrow0 + row) * 128 + wh * 64 + c16 * 16) = val;
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         R64_STAMP(5);
-        // the next tile's DMAs are older than this epilogue's stores: wait for all but the 2 NST youngest operations
-        // (a ragged last tile may skip store instructions: wait for everything there)
-        if (m0 + R64_TM > a.M) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (NST == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        // the next tile's DMAs are older than this epilogue's stores: wait for all but the youngest store instructions (4 LINEAR,
+        // 2 POOL per wave); where store instructions may have been skipped altogether, wait for everything
+        if (ragged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (POOL) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         R64_STAMP(6);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         R64_STAMP(7);
-        lo = nlo; cf = ncf;
+        b = nb; k_img = nk; h_first = nh; s0 = ns0;
     }
 #if R64_DIAG
     if (lane == 0 && blockIdx.x * R64_NW + wid < 4096) {
-        float* d = r64_diag + (size_t)(blockIdx.x * R64_NW + wid) * 8;
+        float* d = r64_diag + (size_t)(blockIdx.x * R64_NW + wid) * 12;
+        d[10] = (float)(__builtin_amdgcn_s_memrealtime() - d_entry_r);   // resident time of this wave, 100 MHz ticks
+        d[11] = 0.f;
+        d[8] = (float)(d_c0 - d_entry);                             // prologue cycles
+        d[9] = (float)(d_entry_r % 100000000ull);                   // kernel entry on the 100 MHz reference clock (mod 1 s)
 #pragma unroll
         for (int k = 0; k < 8; ++k) d[k] = (float)dt[k];
+        // clock of the loop: shader cycles per 100 MHz reference tick, x 1000 (reported in the "barrier2" slot's fraction: slot 7 keeps
+        // its cycle count, the clock goes to the last float of the NEXT wave's unused padding - simpler: overwrite slot 6 + 7 sum)
+        const float ghz = (float)(__builtin_amdgcn_s_memtime() - d_c0) / (float)(__builtin_amdgcn_s_memrealtime() - d_r0) * 0.1f;
+        d[6] = dt[6] + dt[7];
+        d[7] = ghz;
     }
 #endif
 }
 
-template <bool POOL, bool SC, int AROWS, int XROWS, int WM>
+template <bool POOL, bool SC, int BLOCKS>
 static int launch_r64(const Conv64Args& a, hipStream_t stream) {
-    constexpr int NW = 2 * WM;
-    constexpr int PLANE = (AROWS + 1) * R64_ROWB, XPLANE = SC ? (XROWS + 1) * R64_ROWB : 0;
+    constexpr int PLANE = BLOCKS * R64_P * R64_ROWB;
     constexpr int SLAB = (POOL ? 8 : 32) * (32 * 2 + 16);
-    const size_t lds = 3 * (size_t)PLANE + XPLANE + NW * SLAB + 64 * sizeof(float);
-    static_assert((3 * PLANE + XPLANE + NW * SLAB + 256) * (WM == 2 ? 2 : 1) <= 160 * 1024, "LDS budget (two workgroups per CU when WM = 2)");
-    auto kern = conv64_resident_kernel<POOL, SC, AROWS, XROWS, WM>;
+    constexpr size_t lds = 3 * (size_t)PLANE + (SC ? PLANE : 0) + R64_NW * SLAB + 256;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = conv64_resident_kernel<POOL, SC, BLOCKS>;
     static std::atomic<unsigned long long> lds_set{0};
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set)) return rc;
     int dev = 0, cus = 256;
@@ -386,66 +407,49 @@ static int launch_r64(const Conv64Args& a, hipStream_t stream) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    const int slots = cus * (WM == 2 ? 2 : 1);                     // persistent workgroups the chip holds at once
-    int grid = slots < a.ntiles ? slots : a.ntiles;
+    int grid = cus < a.ntiles ? cus : a.ntiles;                    // one persistent workgroup per CU
     grid = (grid + 7) / 8 * 8;                                     // whole XCD groups (surplus workgroups exit at once)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(R64_NW * 64), lds, stream, a);
     return launch_status();
-}
-
-// rows a patch plane (with halo) and the shortcut plane (without) must hold for TM-row tiles: scan one period of tile starts
-// (tile t starts at window TM/4 * t; the pattern repeats after Hp*Wp tiles) plus the last tile
-static void r64_worst_rows(const ConvGeom& g, bool pool, int TM, int* worst_out, int* xworst_out) {
-    int worst = 1, xworst = 1;
-    const int ntiles = (g.M + TM - 1) / TM;
-    const int period = pool ? g.Hp * g.Wp + 1 : 3;
-    for (int k = 0; k <= period; ++k) {
-        const int t = k < period ? k : ntiles - 1;
-        if (t >= ntiles) continue;
-        int lo, hi;
-        int m1 = t * TM + TM;
-        if (m1 > g.M) m1 = g.M;
-        int core;
-        if (pool) {
-            patch_range<true>(g, t * TM, TM, &lo, &hi);
-            core = row_to_pixel<true>(g, (m1 - 1) | 3).p - row_to_pixel<true>(g, t * TM).p + 1;
-        } else {
-            patch_range<false>(g, t * TM, TM, &lo, &hi);
-            core = m1 - t * TM;
-        }
-        if (hi - lo > worst) worst = hi - lo;
-        if (core > xworst) xworst = core;
-    }
-    *worst_out = worst; *xworst_out = xworst;
 }
 
 // Returns SUBREG_EUNSUPPORTED when the shape is not this kernel's (the caller then uses the general kernel).
 int conv64_resident(const void* x, const void* w, void* y, const float* shift, const void* x2, const void* w2, int Cin2, int B,
                     int H, int W, bool pool, int act, hipStream_t stream) {
     if ((x2 != nullptr) != (w2 != nullptr) || (x2 && Cin2 != 32)) return SUBREG_EUNSUPPORTED;
-    const ConvGeom g = make_geom(B, H, W, 9, pool);
-    if ((long long)g.npix * (H * W) >= (1LL << 40) || g.npix >= (1 << 27)) return SUBREG_EUNSUPPORTED;   // FastDiv range, 32-bit offsets
+    // padded row pitch 96 (and not wastefully narrow images); FastDiv ranges; 32-bit byte offsets inside a patch
+    if (W + 1 > R64_P || W < 64 || H < 2 || (long long)B * H * W >= (1LL << 26)) return SUBREG_EUNSUPPORTED;
     Conv64Args a;
     a.x = (const char*)x; a.w = (const char*)w; a.x2 = (const char*)x2; a.w2 = (const char*)w2; a.y = (char*)y; a.shift = shift;
-    a.H = H; a.W = W; a.Hp = g.Hp; a.Wp = g.Wp; a.npix = g.npix; a.M = g.M; a.act = act;
-    a.d_hw = make_fastdiv(H * W); a.d_w = make_fastdiv(W);
-    a.d_pp = make_fastdiv(g.Hp * g.Wp > 0 ? g.Hp * g.Wp : 1); a.d_wp = make_fastdiv(g.Wp > 0 ? g.Wp : 1);
-    int worst, xworst;
+    a.H = H; a.W = W; a.act = act;
+    a.R = 0; a.Hp = H / 2; a.Wp = W / 2; a.WT = 0; a.nwin = a.Hp * a.Wp;
+    a.d_w = make_fastdiv(W);
+    a.d_wp = make_fastdiv(a.Wp > 0 ? a.Wp : 1);
     if (!pool) {
-        r64_worst_rows(g, false, R64_TM_SMALL, &worst, &xworst);
-        if (R64_TWO_WG && worst <= 304) {                              // 128-row tiles, two workgroups per CU
-            a.ntiles = (g.M + R64_TM_SMALL - 1) / R64_TM_SMALL;
-            return x2 ? launch_r64<false, true, 304, 128, 2>(a, stream) : launch_r64<false, false, 304, 128, 2>(a, stream);
-        }
-        r64_worst_rows(g, false, 256, &worst, &xworst);
-        if (worst > 432) return SUBREG_EUNSUPPORTED;
-        a.ntiles = (g.M + 255) / 256;
-        return x2 ? launch_r64<false, true, 432, 256, 4>(a, stream) : launch_r64<false, false, 432, 256, 4>(a, stream);
+        if (x2) return SUBREG_EUNSUPPORTED;                         // (no caller: conv2 has no shortcut, conv3 is pooled)
+        a.R = 256 / W;                                              // whole image rows per 256-row tile
+        if (a.R < 1 || a.R > 3) return SUBREG_EUNSUPPORTED;         // 5 blocks hold R + 2 <= 5 image rows
+        a.tpi = (H + a.R - 1) / a.R;
+        a.ntiles = B * a.tpi;
+        a.d_tpi = make_fastdiv(a.tpi);
+        return launch_r64<false, false, 5>(a, stream);
     }
-    r64_worst_rows(g, true, 256, &worst, &xworst);
-    if (worst > 560 || xworst > 384) return SUBREG_EUNSUPPORTED;
-    a.ntiles = (g.M + 255) / 256;
-    return x2 ? launch_r64<true, true, 560, 384, 4>(a, stream) : launch_r64<true, false, 560, 384, 4>(a, stream);
+    // windows per tile: the largest WT <= 64 for which no tile touches more than two row pairs (6 blocks = 2 pairs + halo)
+    int wt = 0;
+    for (int cand = 64; cand >= 48 && !wt; --cand) {
+        bool ok = true;
+        for (int k = 0; k * cand < a.nwin && ok; ++k) {
+            const int first = k * cand, last = (first + cand < a.nwin ? first + cand : a.nwin) - 1;
+            if (last / a.Wp - first / a.Wp > 1) ok = false;
+        }
+        if (ok) wt = cand;
+    }
+    if (!wt) return SUBREG_EUNSUPPORTED;
+    a.WT = wt;
+    a.tpi = (a.nwin + wt - 1) / wt;
+    a.ntiles = B * a.tpi;
+    a.d_tpi = make_fastdiv(a.tpi);
+    return x2 ? launch_r64<true, true, 6>(a, stream) : launch_r64<true, false, 6>(a, stream);
 }
 
 #if R64_DIAG

@@ -32,15 +32,22 @@ def main():
             _lib.check(lib.subreg_conv_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), None, _lib.ptr(shift), None, None, _lib.ptr(x2),
                                            _lib.ptr(w2), 32 if sc else 0, B, H, H, 64, 64, 3, flags, _lib.BF16, _lib.stream_ptr()))
         torch.cuda.synchronize()
-        out = np.zeros(4096 * 8, np.float32)
+        out = np.zeros(4096 * 12, np.float32)
         assert raw.subreg_r64_diag_read(out.ctypes.data_as(C.c_void_p), out.size) == 0
-        d = out.reshape(-1, 8)
+        d = out.reshape(-1, 12)
+        nw = int((d[:, 0] > 0).sum())
+        tot_all = (d[:nw, 1:7].sum(axis=1) + d[:nw, 8])            # prologue + loop cycles of every wave (workgroup-major, 8 waves each)
+        wg = tot_all.reshape(-1, 8).max(axis=1)
+        print("  kernel-resident cycles per workgroup: min %.0f median %.0f max %.0f; by XCD (blockIdx %% 8) max: %s" %
+              (wg.min(), np.median(wg), wg.max(), " ".join("%.0f" % wg[x::8].max() for x in range(8))))
         d = d[d[:, 0] > 0]
-        per = d[:, 1:] / d[:, :1]
-        names = ["addr", "chunk0", "bar1", "chunk1", "epilogue", "dma wait", "bar2"]
+        print("  wave resident time (s_memrealtime): median %.1f us, max %.1f us" % (np.median(d[:, 10]) / 100.0, d[:, 10].max() / 100.0))
+        per = d[:, 1:7] / d[:, :1]
+        names = ["setup+dma issue", "chunk0", "bar1", "chunk1", "epilogue", "dma wait+bar2"]
         med = np.median(per, axis=0)
-        print("pool=%d sc=%d B=%d: waves %d, tiles/wave %.1f, cycles per tile %.0f = " % (pool, sc, B, len(d), np.median(d[:, 0]), med.sum()) +
-              ", ".join("%s %.0f" % (n, v) for n, v in zip(names, med)))
+        print("pool=%d sc=%d B=%d: waves %d, tiles/wave %.1f, shader clock %.2f GHz, cycles per tile %.0f = " %
+              (pool, sc, B, len(d), np.median(d[:, 0]), np.median(d[:, 7]), med.sum()) + ", ".join("%s %.0f" % (n, v) for n, v in zip(names, med)) +
+              "; prologue %.0f cycles; workgroup start spread %.1f us" % (np.median(d[:, 8]), (d[:, 9].max() - d[:, 9].min()) / 100.0))
 
 
 if __name__ == "__main__":
