@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUBREG_ABI_VERSION 2
+#define SUBREG_ABI_VERSION 3
 
 #define SUBREG_OK 0
 #define SUBREG_EINVAL (-1)       /* bad argument (null pointer, shape not supported by contract) */
@@ -213,9 +213,30 @@ typedef struct subreg_train_desc {
 /* train-mode forward that keeps what the backward needs (raw conv outputs, activations, batch statistics) */
 int subreg_backbone_forward_stash(const subreg_backbone_desc* d, const subreg_train_desc* t, const float* x_nchw, int B,
                                   int H, int W, float* feat, void* stream);
+/* After an optimiser step (train_supervised.py:243-244 `optimizer.step()`): re-pack EVERY conv weight for the next step in
+ * ONE launch - the raw copies `w` of `d` (what subreg_backbone_pack_raw writes) and the flipped / transposed dX copies
+ * `w_dgrad` of `t` (what subreg_pack_conv_weight_dgrad writes; convs with w_dgrad == NULL are skipped). */
+int subreg_backbone_pack_train(const subreg_backbone_desc* d, const subreg_train_desc* t, void* stream);
+/* The optimiser step of every conv weight AND its re-packing in ONE launch (train_supervised.py:243-244 `optimizer.step()`,
+ * torch.optim.SGD with momentum / weight decay, no dampening, no nesterov): per 32x32-channel tile the fp32 weight, its
+ * gradient and its momentum buffer are read once in OIHW order, updated, written back, and the two packed copies the
+ * next step's kernels read (raw forward layout `w` of `d`, dX layout `w_dgrad` of `t`) are written from the same tile.
+ * Gradients: t->blocks[i].convX.grad_w, taken relative to `grad_origin` and read at the same offset from `grad_base`
+ * (the buffer the caller's gradient views live in; pass the same pointer twice when they are the stash's own).
+ * Momentum buffers: `mom_base` + the same offsets (one flat fp32 buffer laid out like the gradients).
+ * Updates d->blocks[i].convX.w_oihw IN PLACE (the fp32 master weights). */
+int subreg_sgd_pack_train(const subreg_backbone_desc* d, const subreg_train_desc* t, const float* grad_base,
+                          const float* grad_origin, float* mom_base, float lr, float momentum, float weight_decay,
+                          int first_step, void* stream);
 /* gradients of every conv weight and BN affine parameter given d(loss)/d(feat) [B][C_last] */
 int subreg_backbone_backward(const subreg_backbone_desc* d, const subreg_train_desc* t, const float* dfeat, int B, int H,
                              int W, void* stream);
+/* The same backward issued block range by block range: blocks last_block .. first_block (descending).  Call with
+ * contiguous, descending ranges that start at n_blocks-1 and end at 0; after each call the gradients of that range's
+ * parameters are complete on `stream` - a data-parallel caller starts their all-reduce there while the next range runs
+ * (train_supervised.py:141-142 nn.DataParallel reduces gradients; here: one process per GPU over RCCL). */
+int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, const subreg_train_desc* t, const float* dfeat, int B,
+                                    int H, int W, int first_block, int last_block, void* stream);
 
 /* ---- classifier head: nn.Linear (:138-140,187) ----------------------------------------------------------- */
 int subreg_linear_fwd(const float* feat, const float* weight, const float* bias, float* logits, int B, int N, int D,

@@ -69,18 +69,21 @@ extern "C" int subreg_backbone_forward_stash(const subreg_backbone_desc* d, cons
     return subreg_avgpool(cur, feat, B, h, w, d->blocks[d->n_blocks - 1].conv3.cout, dt, stream);
 }
 
-extern "C" int subreg_backbone_backward(const subreg_backbone_desc* d, const subreg_train_desc* t, const float* dfeat, int B, int H,
-                                        int W, void* stream) {
+extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, const subreg_train_desc* t, const float* dfeat, int B,
+                                              int H, int W, int first_block, int last_block, void* stream) {
     SUBREG_CHECK_ARG(d && t && d->blocks && t->blocks && d->n_blocks > 0 && dfeat && B > 0 && H > 0 && W > 0);
     SUBREG_CHECK_ARG(t->g[0] && t->g[1] && t->dv && t->dr && t->dt && t->dr2 && t->bn_partial && t->zero_shift);
     const int dt = d->dtype, nb = d->n_blocks;
+    SUBREG_CHECK_ARG(0 <= first_block && first_block <= last_block && last_block < nb);
     int hs[64], ws[64];                    // input spatial size of every block
     SUBREG_CHECK_ARG(nb <= 64);
     int h = H, w = W;
     for (int i = 0; i < nb; ++i) { hs[i] = h; ws[i] = w; if (d->blocks[i].stride == 2) { h /= 2; w /= 2; } }
-    int gi = 0;
-    TRY(subreg_avgpool_bwd(dfeat, t->g[gi], B, h, w, d->blocks[nb - 1].conv3.cout, dt, stream));
-    for (int i = nb - 1; i >= 0; --i) {
+    // d(loss)/d(output of block i) lives in g[(nb - 1 - i) & 1]: the ping-pong index is a function of the block, so the
+    // backward can be issued in several calls (descending, contiguous block ranges)
+    if (last_block == nb - 1) TRY(subreg_avgpool_bwd(dfeat, t->g[0], B, h, w, d->blocks[nb - 1].conv3.cout, dt, stream));
+    for (int i = last_block; i >= first_block; --i) {
+        const int gi = (nb - 1 - i) & 1;
         const subreg_block_desc& b = d->blocks[i];
         const subreg_block_train& tb = t->blocks[i];
         const void* xin = i == 0 ? d->col : t->blocks[i - 1].out;
@@ -116,7 +119,12 @@ extern "C" int subreg_backbone_backward(const subreg_backbone_desc* d, const sub
             TRY(subreg_conv_fwd(t->dr, tb.conv1.w_dgrad, t->g[go], nullptr, t->zero_shift, t->dv, nullptr, nullptr, nullptr, 0, B, bh,
                                 bw, b.conv1.cout, b.conv1.cin, b.conv1.ksize_raw, 0, dt, stream));
         }
-        gi = go;
     }
     return SUBREG_OK;
+}
+
+extern "C" int subreg_backbone_backward(const subreg_backbone_desc* d, const subreg_train_desc* t, const float* dfeat, int B, int H,
+                                        int W, void* stream) {
+    SUBREG_CHECK_ARG(d && d->n_blocks > 0);
+    return subreg_backbone_backward_blocks(d, t, dfeat, B, H, W, 0, d->n_blocks - 1, stream);
 }

@@ -513,6 +513,116 @@ __global__ void pack_weight_dgrad_kernel(const float* __restrict__ w, T* __restr
     out[i] = ElemTraits<T>::from_float(w[((size_t)(ch * 32 + o32) * Cin + c) * taps + (taps - 1 - t)]);
 }
 
+// Every conv of the backbone in one launch: raw forward layout (pack_weight_kernel, elementwise.hip) and dX layout (above).
+// The job table travels as a kernel argument (no device-side table to build or keep).
+constexpr int PACK_MAX_JOBS = 32;
+struct PackJobs {
+    const float* src[PACK_MAX_JOBS];      // OIHW fp32
+    void* raw[PACK_MAX_JOBS];             // [taps][Cin/32][Cout][32] (first conv: [Cout][32] im2col rows)
+    void* dgrad[PACK_MAX_JOBS];           // [taps][Cout/32][Cin][32], taps flipped; may be null
+    int cout[PACK_MAX_JOBS], cin[PACK_MAX_JOBS], ks[PACK_MAX_JOBS], mode[PACK_MAX_JOBS];
+    unsigned begin[PACK_MAX_JOBS + 1];    // element ranges of the jobs in the 1-D grid
+    int n;
+};
+template <typename T>
+__global__ void pack_train_kernel(const PackJobs jobs) {
+    const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= jobs.begin[jobs.n]) return;
+    int j = 0;
+    while (j + 1 < jobs.n && g >= jobs.begin[j + 1]) ++j;
+    const size_t i = g - jobs.begin[j];
+    const float* __restrict__ w = jobs.src[j];
+    const int Cout = jobs.cout[j], Cin = jobs.cin[j], ks = jobs.ks[j], taps = ks * ks;
+    if (jobs.mode[j] == 1) {                                   // the 3-channel first layer as K=32 im2col rows (k = 3*tap + c)
+        if (i >= (size_t)Cout * 32) return;
+        const int k = i % 32, o = i / 32;
+        float v = 0.f;
+        if (k < 27) {
+            const int t = k / 3, c = k % 3;
+            if (ks == 3) v = w[((size_t)o * 3 + c) * 9 + t];
+            else if (t == 4) v = w[(size_t)o * 3 + c];
+        }
+        reinterpret_cast<T*>(jobs.raw[j])[i] = ElemTraits<T>::from_float(v);
+        return;
+    }
+    {
+        const int nch = Cin / 32;
+        const int c32 = i % 32, o = (i / 32) % Cout, ch = (i / ((size_t)32 * Cout)) % nch, t = i / ((size_t)32 * Cout * nch);
+        reinterpret_cast<T*>(jobs.raw[j])[i] = ElemTraits<T>::from_float(w[((size_t)o * Cin + ch * 32 + c32) * taps + t]);
+    }
+    if (jobs.dgrad[j]) {
+        const int nch = Cout / 32;
+        const int o32 = i % 32, c = (i / 32) % Cin, ch = (i / ((size_t)32 * Cin)) % nch, t = i / ((size_t)32 * Cin * nch);
+        reinterpret_cast<T*>(jobs.dgrad[j])[i] = ElemTraits<T>::from_float(w[((size_t)(ch * 32 + o32) * Cin + c) * taps + (taps - 1 - t)]);
+    }
+}
+
+// SGD(momentum, weight decay) + both re-packings of every conv weight, one 32 x 32-channel tile (all taps) per workgroup.
+struct SgdPackJobs {
+    float* p[PACK_MAX_JOBS];              // OIHW fp32 master weight (updated in place)
+    const float* g[PACK_MAX_JOBS];        // gradient, OIHW
+    float* m[PACK_MAX_JOBS];              // momentum buffer, OIHW
+    void* raw[PACK_MAX_JOBS];
+    void* dgrad[PACK_MAX_JOBS];           // may be null
+    int cout[PACK_MAX_JOBS], cin[PACK_MAX_JOBS], ks[PACK_MAX_JOBS], mode[PACK_MAX_JOBS];
+    unsigned begin[PACK_MAX_JOBS + 1];    // first workgroup of every job
+    int n;
+    float lr, momentum, wd;
+    int first;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void sgd_pack_train_kernel(const SgdPackJobs jobs) {
+    __shared__ float tile[32][32 * 9 + 1];                      // [o][c * taps + t]
+    int j = 0;
+    while (j + 1 < jobs.n && blockIdx.x >= jobs.begin[j + 1]) ++j;
+    const int blk = blockIdx.x - jobs.begin[j], tid = threadIdx.x;
+    const int Cout = jobs.cout[j], Cin = jobs.cin[j], ks = jobs.ks[j], taps = ks * ks;
+    float* __restrict__ p = jobs.p[j];
+    const float* __restrict__ g = jobs.g[j];
+    float* __restrict__ m = jobs.m[j];
+    auto update = [&](size_t i) -> float {
+        const float w = p[i], d = g[i] + jobs.wd * w;
+        const float b = jobs.first ? d : jobs.momentum * m[i] + d;
+        m[i] = b;
+        const float nw = w - jobs.lr * b;
+        p[i] = nw;
+        return nw;
+    };
+    if (jobs.mode[j] == 1) {
+        // the 3-channel first layer (one workgroup): update, then its K=32 im2col rows (k = 3*tap + c; 1x1: centre tap only)
+        float* flat = &tile[0][0];                              // Cout * 3 * taps <= 32 * 289 floats
+        const int n = Cout * 3 * taps;
+        for (int i = tid; i < n; i += 256) flat[i] = update((size_t)i);
+        __syncthreads();
+        for (int i = tid; i < Cout * 32; i += 256) {
+            const int k = i % 32, o = i / 32;
+            float v = 0.f;
+            if (k < 27) {
+                const int t = k / 3, c = k % 3;
+                if (ks == 3) v = flat[(o * 3 + c) * 9 + t];
+                else if (t == 4) v = flat[o * 3 + c];
+            }
+            reinterpret_cast<T*>(jobs.raw[j])[i] = ElemTraits<T>::from_float(v);
+        }
+        return;
+    }
+    const int ncb = Cin / 32, o0 = (blk / ncb) * 32, c0 = (blk % ncb) * 32, run = 32 * taps;
+    for (int e = tid; e < 32 * run; e += 256) {
+        const int o = e / run, r = e - o * run;                 // r = c * taps + t: contiguous in OIHW for a fixed o
+        tile[o][r] = update(((size_t)(o0 + o) * Cin + c0) * taps + r);
+    }
+    __syncthreads();
+    T* const raw = reinterpret_cast<T*>(jobs.raw[j]);
+    T* const dg = reinterpret_cast<T*>(jobs.dgrad[j]);
+    for (int e = tid; e < taps * 1024; e += 256) {
+        const int t = e >> 10, a = (e >> 5) & 31, b = e & 31;
+        // raw: [tap][Cin/32][Cout][32]: a = o, b = c32 -> 2 KB contiguous per tap
+        raw[(((size_t)t * ncb + c0 / 32) * Cout + o0 + a) * 32 + b] = ElemTraits<T>::from_float(tile[a][b * taps + t]);
+        // dX: [flipped tap][Cout/32][Cin][32]: a = c, b = o32 -> 2 KB contiguous per tap
+        if (dg) dg[(((size_t)(taps - 1 - t) * (Cout / 32) + o0 / 32) * Cin + c0 + a) * 32 + b] = ElemTraits<T>::from_float(tile[b][a * taps + t]);
+    }
+}
+
 // torch.optim.SGD (dampening 0, no nesterov): d = g + wd*p; buf = first ? d : m*buf + d; p -= lr*buf
 __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, size_t n,
                                     float lr, float momentum, float wd, int first) {
@@ -690,6 +800,72 @@ extern "C" int subreg_pack_conv_weight_dgrad(const float* w_oihw, void* out, int
     const size_t n = (size_t)Cout * Cin * ksize * ksize;
     DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_dgrad_kernel<float>, bw_blocks(n), BW_THREADS, 0, s, w_oihw, (float*)out, Cout, Cin, ksize),
                hipLaunchKernelGGL(pack_weight_dgrad_kernel<__bf16>, bw_blocks(n), BW_THREADS, 0, s, w_oihw, (__bf16*)out, Cout, Cin, ksize));
+    return launch_status();
+}
+
+extern "C" int subreg_backbone_pack_train(const subreg_backbone_desc* d, const subreg_train_desc* t, void* stream) {
+    SUBREG_CHECK_ARG(d && t && d->blocks && t->blocks && d->n_blocks > 0);
+    PackJobs jobs;
+    jobs.n = 0;
+    unsigned long long total = 0;
+    for (int i = 0; i < d->n_blocks; ++i) {
+        const subreg_block_desc& b = d->blocks[i];
+        const subreg_block_train& tb = t->blocks[i];
+        const subreg_conv_desc* cs[4] = {&b.conv1, &b.conv2, &b.conv3, &b.down};
+        const subreg_conv_train* ts[4] = {&tb.conv1, &tb.conv2, &tb.conv3, &tb.down};
+        for (int k = 0; k < 4; ++k) {
+            const subreg_conv_desc& c = *cs[k];
+            if (!c.w) continue;
+            SUBREG_CHECK_ARG(jobs.n < PACK_MAX_JOBS && c.w_oihw);
+            const int j = jobs.n++;
+            const bool first = c.cin_raw == 3;
+            jobs.src[j] = c.w_oihw; jobs.raw[j] = const_cast<void*>(c.w); jobs.dgrad[j] = first ? nullptr : const_cast<void*>(ts[k]->w_dgrad);
+            jobs.cout[j] = c.cout; jobs.cin[j] = c.cin_raw; jobs.ks[j] = c.ksize_raw; jobs.mode[j] = first ? 1 : 0;
+            SUBREG_CHECK_ARG(first || (c.cin_raw % 32 == 0 && c.cout % 32 == 0));
+            jobs.begin[j] = (unsigned)total;
+            total += first ? (unsigned long long)c.cout * 32 : (unsigned long long)c.cout * c.ksize_raw * c.ksize_raw * c.cin_raw;
+            SUBREG_CHECK_ARG(total < (1ull << 32));
+        }
+    }
+    jobs.begin[jobs.n] = (unsigned)total;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL(pack_train_kernel<float>, bw_blocks((size_t)total), BW_THREADS, 0, s, jobs),
+               hipLaunchKernelGGL(pack_train_kernel<__bf16>, bw_blocks((size_t)total), BW_THREADS, 0, s, jobs));
+    return launch_status();
+}
+
+extern "C" int subreg_sgd_pack_train(const subreg_backbone_desc* d, const subreg_train_desc* t, const float* grad_base,
+                                     const float* grad_origin, float* mom_base, float lr, float momentum, float weight_decay,
+                                     int first_step, void* stream) {
+    SUBREG_CHECK_ARG(d && t && d->blocks && t->blocks && d->n_blocks > 0 && grad_base && grad_origin && mom_base);
+    SgdPackJobs jobs;
+    jobs.n = 0;
+    jobs.lr = lr; jobs.momentum = momentum; jobs.wd = weight_decay; jobs.first = first_step;
+    unsigned blocks = 0;
+    for (int i = 0; i < d->n_blocks; ++i) {
+        const subreg_block_desc& b = d->blocks[i];
+        const subreg_block_train& tb = t->blocks[i];
+        const subreg_conv_desc* cs[4] = {&b.conv1, &b.conv2, &b.conv3, &b.down};
+        const subreg_conv_train* ts[4] = {&tb.conv1, &tb.conv2, &tb.conv3, &tb.down};
+        for (int k = 0; k < 4; ++k) {
+            const subreg_conv_desc& c = *cs[k];
+            if (!c.w) continue;
+            SUBREG_CHECK_ARG(jobs.n < PACK_MAX_JOBS && c.w_oihw && ts[k]->grad_w);
+            const int j = jobs.n++;
+            const bool first = c.cin_raw == 3;
+            const ptrdiff_t off = ts[k]->grad_w - grad_origin;
+            jobs.p[j] = const_cast<float*>(c.w_oihw); jobs.g[j] = grad_base + off; jobs.m[j] = mom_base + off;
+            jobs.raw[j] = const_cast<void*>(c.w); jobs.dgrad[j] = first ? nullptr : const_cast<void*>(ts[k]->w_dgrad);
+            jobs.cout[j] = c.cout; jobs.cin[j] = c.cin_raw; jobs.ks[j] = c.ksize_raw; jobs.mode[j] = first ? 1 : 0;
+            SUBREG_CHECK_ARG(first ? c.cout * 27 <= 32 * 289 : (c.cin_raw % 32 == 0 && c.cout % 32 == 0));
+            jobs.begin[j] = blocks;
+            blocks += first ? 1u : (unsigned)((c.cout / 32) * (c.cin_raw / 32));
+        }
+    }
+    jobs.begin[jobs.n] = blocks;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL(sgd_pack_train_kernel<float>, dim3(blocks), dim3(256), 0, s, jobs),
+               hipLaunchKernelGGL(sgd_pack_train_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, jobs));
     return launch_status();
 }
 

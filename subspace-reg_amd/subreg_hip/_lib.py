@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SUBREG_LIB") or os.path.join(_HERE, "libsubreg_hip.so
 F32, BF16 = 0, 1
 CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
 FWD_TRAIN = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_QUERY_SETS = 32                          # SUBREG_MAX_QUERY_SETS
 
 c_void_p, c_int, c_float, c_longlong = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -102,6 +102,9 @@ SIGNATURES = {
     "subreg_sgd_momentum": (_I, [_P, _P, _P, _L, _F, _F, _F, _I, _P]),
     "subreg_backbone_forward_stash": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P, _I, _I, _I, _P, _P]),
     "subreg_backbone_backward": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P, _I, _I, _I, _P]),
+    "subreg_backbone_backward_blocks": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P, _I, _I, _I, _I, _I, _P]),
+    "subreg_backbone_pack_train": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P]),
+    "subreg_sgd_pack_train": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P, _P, _P, _F, _F, _F, _I, _P]),
     "subreg_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P]),
     "subreg_mask_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_random_keep_mask": (_I, [_P, _L, C.c_ulonglong, _F, _P, _P]),

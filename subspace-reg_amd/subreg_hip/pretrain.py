@@ -5,9 +5,9 @@
   train                  train_supervised.py:205-268   one epoch: forward, CE (+ label-pull penalty), meters, backward, SGD step
   validate               eval/util.py:185-232          one pass in eval mode: loss, top-1, top-5
   fit                    train_supervised.py:150-202   epochs, periodic + last checkpoint in the reference's format
-  GradientAverager       replaces nn.DataParallel (:139-140): one process per GPU, every rank takes its share of the batch,
-                         gradients averaged with ONE all-reduce per gradient storage (RCCL over xGMI; the backbone's
-                         gradients are views of a single flat buffer, see train.BackboneTrainFn.backward)
+  GradientSync           replaces nn.DataParallel (:139-140): one process per GPU, every rank takes its share of the batch and
+                         back-propagates loss * n_local / n_global; the backbone's flat gradient buffer is SUM-all-reduced
+                         stage by stage, overlapped with the backward (RCCL over xGMI), the classifier's at the end
 The model is `subreg_hip.resnet_language.ResNet`; its train-mode forward/backward run on the kernels of csrc/backward.hip.
 """
 import math
@@ -66,37 +66,75 @@ def set_epoch_lr(epoch, opt, optimizer):
         adjust_learning_rate(epoch, opt, optimizer)
 
 
-class GradientAverager:
-    """Average parameter gradients over the ranks of a process group: one all-reduce per distinct gradient storage."""
+class GradientSync:
+    """Data-parallel gradient reduction, one process per GPU (replaces nn.DataParallel, train_supervised.py:141-142).
+
+    Every rank back-propagates its local mean loss times n_local / n_global (`train` below), so the SUM over ranks is exactly
+    the gradient of the global-batch mean loss - also for uneven shards - and nothing is divided afterwards.
+    The backbone's gradients are views of one flat buffer; `stage_ready` (hooked into the staged backward,
+    train.BackboneTrainFn.backward) starts the all-reduce of a stage's range asynchronously while the backward of the earlier
+    blocks is still running (RCCL over xGMI: the collective runs on its own stream behind an event of the compute stream).
+    `finish` reduces every gradient storage not covered that way (the classifier) and waits for all collectives."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.calls = 0
+        self.pending, self.covered = [], []
 
-    def __call__(self, params):
+    def stage_ready(self, flat_slice):
         if self.world == 1:
             return
-        seen = {}
+        self.pending.append(self.dist.all_reduce(flat_slice, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.covered.append((flat_slice.data_ptr(), flat_slice.data_ptr() + flat_slice.numel() * flat_slice.element_size()))
+        self.calls += 1
+
+    def finish(self, params):
+        if self.world == 1:
+            return
+        todo, partly = {}, set()
         for p in params:
             if p.grad is None:
                 continue
+            a = p.grad.data_ptr()
             base = p.grad._base if p.grad._base is not None else p.grad
-            seen.setdefault(id(base), base)
-        for base in seen.values():
-            self.dist.all_reduce(base, op=self.dist.ReduceOp.SUM, group=self.group)
-            base.div_(self.world)
-            self.calls += 1
+            if any(lo <= a < hi for lo, hi in self.covered):
+                partly.add(id(base))                           # part of a stage range already in flight
+                continue
+            todo.setdefault(id(base), (base, []))[1].append(p.grad)
+        for key, (base, views) in todo.items():
+            # a storage none of whose views went out with a stage: ONE collective for the whole storage; otherwise view by view
+            for t in ([base] if key not in partly else [v.contiguous() if not v.is_contiguous() else v for v in views]):
+                self.pending.append(self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.calls += 1
+        for w in self.pending:
+            w.wait()
+        self.pending, self.covered = [], []
+
+    __call__ = finish
+
+
+GradientAverager = GradientSync      # (round-1 name)
+
+
+def shard_sizes(n, world):
+    """Balanced split of a batch of n over `world` ranks (sizes differ by at most one; DataParallel scatters in chunks too)."""
+    base, extra = divmod(n, world)
+    return [base + (1 if r < extra else 0) for r in range(world)]
 
 
 def shard_batch(input, target, rank, world):
-    """This rank's contiguous share of a global batch (DataParallel scatters along dim 0 the same way)."""
+    """This rank's contiguous share of a global batch.  Every rank must get at least one sample (all ranks see the same
+    n and world, so all of them raise together otherwise - nobody is left waiting in a collective)."""
     if world == 1:
         return input, target
     n = input.shape[0]
-    per = (n + world - 1) // world
-    return input[rank * per:(rank + 1) * per], target[rank * per:(rank + 1) * per]
+    if n < world:
+        raise ValueError("batch of %d samples cannot be sharded over %d ranks" % (n, world))
+    sizes = shard_sizes(n, world)
+    lo = sum(sizes[:rank])
+    return input[lo:lo + sizes[rank]], target[lo:lo + sizes[rank]]
 
 
 def _batch_metrics(output, target, counters):
@@ -118,6 +156,7 @@ def train(epoch, train_loader, model, criterion, optimizer, opt, lang_puller=Non
     end = time.time()
     for idx, (input, target, *_rest) in enumerate(train_loader):
         data_time.update(time.time() - end)
+        n_global = input.shape[0]
         input, target = shard_batch(input.float(), target, rank, world)
         input, target = input.to(dev), target.to(dev).long()
         output = model(input)
@@ -128,9 +167,13 @@ def train(epoch, train_loader, model, criterion, optimizer, opt, lang_puller=Non
         top1.update(acc1, input.size(0))
         top5.update(acc5, input.size(0))
         optimizer.zero_grad()
-        loss.backward()
+        if world > 1:
+            # SUM over ranks of d(local mean * n_local / n_global) = d(global mean): DataParallel's gradient, no division after
+            (loss * (float(input.shape[0]) / float(n_global))).backward()
+        else:
+            loss.backward()
         if grad_sync is not None:
-            grad_sync(optimizer.param_groups[0]["params"])
+            grad_sync.finish(optimizer.param_groups[0]["params"])
         optimizer.step()
         batch_time.update(time.time() - end)
         end = time.time()
@@ -179,7 +222,12 @@ def fit(model, opt, train_loader, val_loader=None, lang_puller=None, rank=0, wor
     if getattr(opt, "adam", False):
         raise NotImplementedError("the HIP train step implements SGD(momentum, weight_decay) (train_supervised.py:133-136)")
     optimizer = SGD(model.parameters(), lr=opt.learning_rate, momentum=opt.momentum, weight_decay=opt.weight_decay)
-    sync = GradientAverager(group) if world > 1 else None
+    sync = None
+    if world > 1:
+        from . import sweep
+        sweep.broadcast_module(model, 0, group)                 # every replica starts from rank 0's parameters and buffers
+        sync = GradientSync(group)
+        model.hip_backbone().grad_stage_hook = sync.stage_ready   # overlap the all-reduce with the backward, stage by stage
     history = []
     for epoch in range(1, opt.epochs + 1):
         set_epoch_lr(epoch, opt, optimizer)

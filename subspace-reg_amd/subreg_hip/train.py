@@ -72,7 +72,7 @@ class TrainStash:
             self.desc.g[i] = buf(amax).data_ptr()
         for f in ("dv", "dr", "dt", "dr2"):
             setattr(self.desc, f, buf(amax).data_ptr())
-        # every parameter gradient lives in ONE flat buffer: backward hands autograd a single clone of it (views), not 66
+        # every parameter gradient lives in ONE flat buffer; .grad of every backbone parameter is a view of it
         total = sum(int(np.prod(shape)) + 2 * c for _tc, _n, shape, _g, _b, c in grad_slots)
         self.flat_grads = torch.zeros(total, dtype=f32, device=dev)
         self.grad_views = []                                   # (name, offset, shape)
@@ -84,6 +84,18 @@ class TrainStash:
                 self.grads[name] = self.flat_grads[off:off + n].view(shp)
                 setattr(tc, field, self.grads[name].data_ptr())
                 off += n
+        # contiguous range of every block's parameter gradients in the flat buffer (conv weights + BN affine, block order):
+        # a data-parallel caller all-reduces a stage's range while the backward of the earlier blocks is still running
+        self.block_ranges, off = [], 0
+        per_block = {}
+        for name, o, shp in self.grad_views:
+            bi = [i for i, (bn, *_r) in enumerate(hb.blocks) if name.startswith(bn + ".")][0]
+            lo, hi = per_block.get(bi, (o, o))
+            per_block[bi] = (min(lo, o), max(hi, o + int(np.prod(shp))))
+        self.block_ranges = [per_block[i] for i in range(len(hb.blocks))]
+        self.flat_grads._subreg_stash = self     # lets the optimiser recognise gradients that are views of this buffer
+        self.conv_weight_offsets = {off: name for name, off, shp in self.grad_views if len(shp) == 4}
+        self.opt_packed = None                   # conv-weight versions for which the optimiser already wrote the packed copies
         gw_shared = buf(gw_need, f32)           # one scratch for every conv's per-split partial dW (used one conv at a time)
         for tc in gw_users:
             tc.gw_packed = gw_shared.data_ptr()
@@ -102,6 +114,28 @@ class TrainStash:
                                                                  self.hb.dtype, s), "pack_conv_weight_dgrad")
 
 
+def backward_stages(n_blocks):
+    """(first_block, last_block) ranges of the staged backward, last stage first.  resnet18's six blocks -> [5], [4], [2, 3],
+    [0, 1]: 44 MB / 37 MB / 24 MB / 2.6 MB of fp32 gradients - collectives large enough for the xGMI rings, and the largest
+    ones start while four more blocks of backward work remain to hide them."""
+    if n_blocks <= 2:
+        return [(0, n_blocks - 1)]
+    stages = [(n_blocks - 1, n_blocks - 1), (n_blocks - 2, n_blocks - 2)]
+    rest = n_blocks - 2
+    if rest > 2:
+        stages.append((rest // 2, rest - 1))
+        stages.append((0, rest // 2 - 1))
+    else:
+        stages.append((0, rest - 1))
+    return stages
+
+
+def conv_weight_versions(hb):
+    """(data_ptr, _version) of every conv weight: changes whenever torch code rebinds or writes one of them (the library's own
+    in-place optimiser step goes through raw pointers and does not count)."""
+    return tuple((hb.params[c + ".weight"].data_ptr(), hb.params[c + ".weight"]._version) for _bi, _slot, c, *_r in hb._convs())
+
+
 class BackboneTrainFn(torch.autograd.Function):
     """feat = backbone(x) in train mode; backward -> gradients of every backbone parameter (`names` order)."""
 
@@ -109,7 +143,6 @@ class BackboneTrainFn(torch.autograd.Function):
     def forward(ctx, x, hb, masks, names, *params):
         B, _, H, W = x.shape
         x = x.contiguous().float()
-        hb.refresh_raw()                     # weights moved since the last step; the eval-mode folded copies are not needed here
         for i in range(len(hb.nbt)):
             hb.nbt[i] += 1
         stash = getattr(hb, "_train_stash", None)
@@ -118,12 +151,19 @@ class BackboneTrainFn(torch.autograd.Function):
         hb._train_stash = stash
         hb._ensure_workspace(B, H, W)
         hb._prepare_masks(B, H, W, masks)
-        stash.repack_dgrad()
+        # weights moved since the last step: every conv's raw forward copy and dX copy in ONE launch (the eval-mode folded
+        # copies are not needed here and are rebuilt by the next eval-mode forward) - unless the optimiser's fused step
+        # (SGD.step -> subreg_sgd_pack_train) already wrote them for exactly these weights
+        hb._bind_pointers()
+        if stash.opt_packed is None or stash.opt_packed != conv_weight_versions(hb):
+            _lib.check(hb.lib.subreg_backbone_pack_train(C.byref(hb._desc), C.byref(stash.desc), _lib.stream_ptr()), "backbone_pack_train")
+        stash.opt_packed = None
         feat = torch.empty(B, hb.out_dim, dtype=torch.float32, device=x.device)
         _lib.check(hb.lib.subreg_backbone_forward_stash(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(x), B, H, W,
                                                         _lib.ptr(feat), _lib.stream_ptr()), "backbone_forward_stash")
         hb._fold_versions = None             # running statistics moved
         ctx.hb, ctx.stash, ctx.names, ctx.bhw = hb, stash, names, (B, H, W)
+        ctx.param_objs = params              # the Parameter objects themselves: backward assigns their .grad (see there)
         return feat
 
     @staticmethod
@@ -131,11 +171,34 @@ class BackboneTrainFn(torch.autograd.Function):
         hb, stash = ctx.hb, ctx.stash
         B, H, W = ctx.bhw
         dfeat = dfeat.contiguous().float()
-        _lib.check(hb.lib.subreg_backbone_backward(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(dfeat), B, H, W,
-                                                   _lib.stream_ptr()), "backbone_backward")
-        flat = stash.flat_grads.clone()
+        hook = getattr(hb, "grad_stage_hook", None)
+        if hook is None:
+            _lib.check(hb.lib.subreg_backbone_backward(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(dfeat), B, H, W,
+                                                       _lib.stream_ptr()), "backbone_backward")
+        else:
+            # data parallel: the backward is issued stage by stage (last blocks first); as soon as a stage's launches are queued
+            # its gradient range goes to the hook (pretrain.GradientSync: asynchronous all-reduce on RCCL's stream, which waits
+            # for exactly those launches) while this stream continues with the earlier blocks
+            nb = len(hb.blocks)
+            for first, last in backward_stages(nb):
+                _lib.check(hb.lib.subreg_backbone_backward_blocks(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(dfeat), B, H, W,
+                                                                  first, last, _lib.stream_ptr()), "backbone_backward_blocks")
+                lo, hi = stash.block_ranges[first][0], stash.block_ranges[last][1]
+                hook(stash.flat_grads[lo:hi])
+        # Every parameter gradient is a view of the stash's ONE flat buffer (valid until the next backward of this model
+        # overwrites it, i.e. for the optimiser step that follows).  The views are assigned to `.grad` here, directly:
+        # handing them to autograd as return values makes AccumulateGrad copy each of the 66 tensors (a returned view is never
+        # "stolen"), and the optimiser would then see 66 unrelated tensors instead of one buffer it can update with one launch.
+        flat = stash.flat_grads
         views = {name: flat[off:off + int(np.prod(shp))].view(shp) for name, off, shp in stash.grad_views}
-        return (None, None, None, None) + tuple(views[n] for n in ctx.names)
+        for n, p in zip(ctx.names, ctx.param_objs):
+            if not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = views[n]
+            else:
+                p.grad = p.grad + views[n]   # a second backward without zero_grad(): accumulate like autograd does
+        return (None, None, None, None) + (None,) * len(ctx.names)
 
 
 class SGD:
@@ -148,6 +211,7 @@ class SGD:
         self.param_groups = [{"params": self.params, "lr": lr}]
         self.bufs = [None] * len(self.params)
         self._multi = {}                     # device pointer tables of the fused update, per parameter group
+        self._stash_mom = {}                 # flat momentum buffer per backbone (laid out like a train stash's flat gradient buffer)
 
     @property
     def lr(self):
@@ -160,6 +224,30 @@ class SGD:
     def zero_grad(self):
         for p in self.params:
             p.grad = None
+
+    def _fused_conv_step(self, lib, stash, items, first):
+        """Conv weights whose gradients are views of a train stash's flat buffer: update + both re-packings in ONE launch
+        (subreg_sgd_pack_train).  Needs every conv weight of the backbone in this group, bound to the stash's backbone.
+        Returns the items it did not handle."""
+        base, hb = items[0][2], stash.hb
+        off_of = {i: (p.grad.data_ptr() - base.data_ptr()) // 4 for i, p, _b in items}
+        conv = [(i, p) for i, p, _b in items if p.dim() == 4 and off_of[i] in stash.conv_weight_offsets]
+        if len(conv) != len(stash.conv_weight_offsets):
+            return items
+        for i, p in conv:
+            if hb.params[stash.conv_weight_offsets[off_of[i]]].data_ptr() != p.data.data_ptr():
+                return items                                   # these parameters are not the stash's backbone
+        mom = self._stash_mom.get(id(hb))                      # keyed by the backbone: a new stash (another batch size) keeps its momentum
+        if mom is None or mom.shape != base.shape:
+            mom = self._stash_mom[id(hb)] = torch.zeros_like(base)
+        for i, p, _b in items:                                 # momentum buffers = views of one flat buffer laid out like the gradients
+            self.bufs[i] = mom[off_of[i]:off_of[i] + p.numel()].view_as(p)
+        hb._bind_pointers()
+        _lib.check(lib.subreg_sgd_pack_train(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(base), _lib.ptr(stash.flat_grads), _lib.ptr(mom),
+                                             self.lr, self.momentum, self.weight_decay, int(first), _lib.stream_ptr()), "sgd_pack_train")
+        stash.opt_packed = conv_weight_versions(hb)
+        done = {i for i, _p in conv}
+        return [it for it in items if it[0] not in done]
 
     def step(self):
         """One fused launch for all parameters whose gradients are views of ONE flat buffer (what BackboneTrainFn.backward
@@ -176,6 +264,11 @@ class SGD:
             base = g._base if (g._base is not None and g.is_contiguous() and g.dtype == torch.float32) else None
             groups.setdefault((id(base) if base is not None else None, first), []).append((i, p, base))
         for (bid, first), items in groups.items():
+            stash = getattr(items[0][2], "_subreg_stash", None) if bid is not None else None
+            if stash is not None:
+                items = self._fused_conv_step(lib, stash, items, first)      # conv weights done; BN affine parameters remain
+                if not items:
+                    continue
             if bid is None or len(items) < 4:
                 for i, p, _b in items:
                     g = p.grad.contiguous()

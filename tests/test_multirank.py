@@ -51,8 +51,9 @@ def test_seed_assignment_and_makespan():
 
 
 def _grad_worker(rank, world, port, q):
-    """Pretraining's data-parallel step on 2 ranks: the backbone's gradients are views of ONE flat buffer (as
-    train.BackboneTrainFn.backward hands them to autograd), the classifier's is a tensor of its own."""
+    """Pretraining's data-parallel step on 2 ranks: the backbone's gradients are views of ONE flat buffer whose stage ranges
+    are all-reduced asynchronously while the backward continues (train.BackboneTrainFn.backward -> GradientSync.stage_ready),
+    the classifier's is a tensor of its own (GradientSync.finish).  SUM, not mean: the ranks pre-scale their losses."""
     from subreg_hip import pretrain as pt
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -61,15 +62,22 @@ def _grad_worker(rank, world, port, q):
     ps[0].grad, ps[1].grad = flat[0:6].view(2, 3), flat[6:10].view(4)
     ps[2].grad = torch.full((5,), float(rank))
     frozen = torch.nn.Parameter(torch.zeros(3))               # no gradient: skipped
-    sync = pt.GradientAverager()
-    sync(ps + [frozen])
-    x, y = pt.shard_batch(torch.arange(8)[:, None], torch.arange(8), rank, world)
+    sync = pt.GradientSync()
+    sync.stage_ready(flat[6:10])                              # "layer 4" first, in flight ...
+    sync.stage_ready(flat[0:6])                               # ... then the earlier stage
+    sync.finish(ps + [frozen])                                # the classifier, then wait for everything
+    # a second step WITHOUT stage hooks: one collective per gradient storage
+    flat2 = torch.ones(10) * (rank + 1)
+    ps[0].grad, ps[1].grad, ps[2].grad = flat2[0:6].view(2, 3), flat2[6:10].view(4), torch.ones(5)
+    calls1 = sync.calls
+    sync.finish(ps)
+    x, y = pt.shard_batch(torch.arange(7)[:, None], torch.arange(7), rank, world)
     if rank == 0:
-        q.put((sync.calls, ps[0].grad.tolist(), ps[1].grad.tolist(), ps[2].grad.tolist(), y.tolist()))
+        q.put((calls1, sync.calls - calls1, ps[0].grad.tolist(), flat.tolist(), ps[2].grad.tolist(), y.tolist(), pt.shard_sizes(7, 2)))
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_averaging_gloo():
+def test_two_rank_gradient_sync_gloo():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -79,13 +87,17 @@ def test_two_rank_gradient_averaging_gloo():
     procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    calls, g0, g1, g2, y = q.get(timeout=120)
+    calls1, calls2, g0, flat, g2, y, sizes = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert calls == 2                                         # one collective for the flat buffer, one for the classifier
-    assert g0 == [[0.0, 1.5, 3.0], [4.5, 6.0, 7.5]] and g1 == [9.0, 10.5, 12.0, 13.5]     # mean of 1x and 2x arange
-    assert g2 == [0.5] * 5 and y == [0, 1, 2, 3]
+    assert calls1 == 3 and calls2 == 2                        # two stage ranges + the classifier; then flat buffer + classifier
+    assert flat == [3.0 * i for i in range(10)]               # SUM of 1x and 2x arange, every element reduced exactly once
+    assert g0 == [[3.0] * 3] * 2 and g2 == [2.0] * 5          # second step: 1 + 2, 1 + 1
+    assert y == [0, 1, 2, 3] and sizes == [4, 3]              # balanced uneven shards: nobody gets an empty slice
+    with pytest.raises(ValueError):
+        from subreg_hip import pretrain as pt
+        pt.shard_batch(torch.zeros(1, 1), torch.zeros(1), 0, 2)
 
 
 def _shard_worker(rank, world, port, q):
