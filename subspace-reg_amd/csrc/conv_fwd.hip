@@ -185,18 +185,23 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of smem
     // piece group `grp` of a patch = pieces grp*NW .. grp*NW+NW-1, one per wave (the last group re-loads the last
     // piece on the surplus waves so that every wave issues the same number of DMAs: counted vmcnt waits rely on it)
-    auto stage_patch_group = [&](const char* xsrc, int cin, int chunk, int buf, int grp) {
-        const unsigned xrow = (unsigned)cin * ELEM;
-        const char* base = xsrc + (size_t)plo * xrow + (size_t)chunk * 32 * ELEM;     // wave-uniform
+    // All DMA source addresses are (kernel-argument base pointer) + 32-bit byte offset: the wave-uniform part of the offset
+    // (patch origin, channel chunk, weight tile) is a handful of 32-bit scalar operations per step.  (Spelled as 64-bit
+    // pointer arithmetic per piece it cost ~130 scalar instructions per step - the "DMA issue" share of the in-kernel stamps.)
+    const unsigned xrow0 = (unsigned)a.Cin * ELEM, xrow1 = (unsigned)a.Cin2 * ELEM;
+    const unsigned porg0 = (unsigned)plo * xrow0, porg1 = (unsigned)plo * xrow1;       // byte offset of the patch origin in x / x2
+    auto stage_patch_group = [&](bool second, int chunk, int buf, int grp) {
+        const unsigned xrow = second ? xrow1 : xrow0;
+        const unsigned uoff = (second ? porg1 : porg0) + (unsigned)chunk * (32 * ELEM);   // wave-uniform
         int q = grp * NW + wid;
         q = q < apieces ? q : apieces - 1;
         const int row = q * RPP + prl;
         const int srow = row < prow ? row : prow - 1;                // tail rows of the last piece: any valid source
-        dma16(base, (unsigned)srow * xrow + ((psl ^ swz_tr<SLOTS, TR>(row)) << 4), lds_base + buf * ABUF + q * 1024);
+        dma16(second ? a.x2 : a.x, uoff + (unsigned)srow * xrow + ((psl ^ swz_tr<SLOTS, TR>(row)) << 4), lds_base + buf * ABUF + q * 1024);
     };
     const int agroups = (apieces + NW - 1) / NW;                     // piece groups of one patch
-    auto stage_patch = [&](const char* xsrc, int cin, int chunk, int buf) {
-        for (int grp = 0; grp < agroups; ++grp) stage_patch_group(xsrc, cin, chunk, buf, grp);
+    auto stage_patch = [&](bool second, int chunk, int buf) {
+        for (int grp = 0; grp < agroups; ++grp) stage_patch_group(second, chunk, buf, grp);
     };
     // weight tiles of `ntaps` consecutive taps starting at `tap` into weight buffer `buf`.  The per-lane part of the
     // source address (output channel row, swizzled slot) does not depend on the step: precomputed once.
@@ -217,23 +222,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     unsigned long long t_begin = 0, t_loop = 0, t_issue = 0, t_wait = 0, t_bar = 0, t_mma = 0, tq = 0, r_begin = 0;
     if (STAMPS) { t_begin = __builtin_amdgcn_s_memtime(); r_begin = __builtin_amdgcn_s_memrealtime(); }
     // one weight piece (tap-in-step tt, piece kw of this wave) of the step at (chunk sc, tap group stg) into ring slot wb
+    const unsigned wtile = (unsigned)a.Cout * ROWB, wtap = (unsigned)nch0 * wtile;     // bytes of one (tap, chunk) tile / of one tap
     auto stage_w_piece = [&](int sc, int stg, int tt, int kw, int wb) {
         const int q = kw * NW + wid;
         if (sc >= nchunks || q >= TN / RPP) return 0;
         const unsigned dst = lds_base + B_BASE + wb * BBUF + tt * BTAP + q * 1024;
         if (sc < nch0) {                                              // tile (tap, chunk): Cout contiguous rows
-            dma16(a.w + ((size_t)(stg * TPS + tt) * nch0 + sc) * a.Cout * ROWB, wvoff[kw], dst);
+            dma16(a.w, (unsigned)(stg * TPS + tt) * wtap + (unsigned)sc * wtile + wvoff[kw], dst);
             return 1;
         }
         if (tt != 0) return 0;                                        // the shortcut GEMM has a single tap
-        dma16(a.w2 + (size_t)(sc - nch0) * a.Cout * ROWB, wvoff[kw], dst);
+        dma16(a.w2, (unsigned)(sc - nch0) * wtile + wvoff[kw], dst);
         return 1;
     };
     // the step after (sc, stg)
     auto advance = [&](int& sc, int& stg) {
         if (sc >= nch0 || stg == NG - 1) { ++sc; stg = 0; } else { ++stg; }
     };
-    stage_patch(a.x, a.Cin, 0, 0);
+    stage_patch(false, 0, 0);
 #pragma unroll
     for (int k = 0; k < TPS * PW; ++k) stage_w_piece(0, 0, k / PW, k % PW, 0);
     // per-lane LDS addresses of this lane's A rows for every tap (k-step 0; k-step s is addr ^ 16*LG*s): logical slot
@@ -281,8 +287,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     for (int c = 0; c < nchunks; ++c) {
         const bool ph1 = c >= nch0;
         const bool more = c + 1 < nchunks;
-        const char* nx = c + 1 < nch0 ? a.x : a.x2;
-        const int ncin = c + 1 < nch0 ? a.Cin : a.Cin2, nck = c + 1 < nch0 ? c + 1 : c + 1 - nch0;
+        const bool nsecond = c + 1 >= nch0;                           // the next chunk belongs to the shortcut GEMM
+        const int nck = nsecond ? c + 1 - nch0 : c + 1;
         const int nbuf = (c + 1) & 1;                                 // patch buffer of the next chunk
         const int aoff = (c & 1) * ABUF;
 #pragma unroll
@@ -305,12 +311,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
                     for (int k = 0; k < PA; ++k) {
                         const int grp = tg * PA + k;
                         if (more && (NG == 1 || tg < PSTEPS) && grp < agroups) {
-                            stage_patch_group(nx, ncin, nck, nbuf, grp);
+                            stage_patch_group(nsecond, nck, nbuf, grp);
                             ++n_patch;
                         }
                     }
                 } else if (more) {                                    // a shortcut step consumes a whole patch: stage all of the next
-                    for (int grp = 0; grp < agroups; ++grp) stage_patch_group(nx, ncin, nck, nbuf, grp);
+                    for (int grp = 0; grp < agroups; ++grp) stage_patch_group(nsecond, nck, nbuf, grp);
                 }
             }
             if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_issue += n - tq; tq = n; }
@@ -652,6 +658,10 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
 template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AR_S, int AR_L, int MINW, int WK = 1>
 static int launch_rows(const ConvArgs& a, hipStream_t s) {
     if ((long long)a.g.M * a.Cout >= (1LL << 31) || (long long)a.g.npix * a.Cout >= (1LL << 31)) return SUBREG_EUNSUPPORTED;
+    // DMA sources are addressed as base pointer + 32-bit byte offset
+    if ((long long)a.g.npix * a.Cin * KT<T>::ELEM >= (1LL << 32) || (long long)a.g.npix * a.Cin2 * KT<T>::ELEM >= (1LL << 32) ||
+        (long long)a.g.taps * a.Cin * a.Cout * KT<T>::ELEM >= (1LL << 32))
+        return SUBREG_EUNSUPPORTED;
     const int worst = worst_patch_rows<POOL>(a.g, WM * NI * 32);
     if (worst <= AR_S) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_S, MINW, WK>(a, s);
     if (worst <= AR_L) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_L, MINW, WK>(a, s);
