@@ -250,6 +250,10 @@ def main():
     ap.add_argument("--sweep-deadline", type=int, default=900, help="seconds after which the sweep leg is abandoned")
     ap.add_argument("--reuse-features", action="store_true",
                     help="NOT the headline: opt-in frozen-feature reuse (reported in DESIGN.md only)")
+    ap.add_argument("--selftest-one-gpu", action="store_true",
+                    help="run all ranks on cuda:0 over gloo (the pool's boxes have one GPU and RCCL does not put two ranks on one "
+                         "device): exercises the real multi-rank code path - barriers, sweep plan, group broadcast, row-sharded "
+                         "forwards, feature gather - with real kernels; throughput numbers of such a run mean nothing")
     ap.add_argument("--selftest-host", action="store_true",
                     help="control-path self-test WITHOUT a GPU (gloo): launch, rendezvous, sweep plan, collectives, JSON relay; "
                          "computes nothing and reports value 0")
@@ -275,10 +279,15 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    if args.selftest_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)       # RCCL; the timed region uses it only for the barrier and the max-over-ranks time
+        if args.selftest_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL; the timed region uses it only for the barrier and the max-over-ranks time
 
     from subreg_hip.incremental import IncrementalRunner
     seed = rank + 1                                           # one seed per GPU, like the SLURM array
@@ -327,7 +336,7 @@ def main():
         "metric": "incremental episodes/sec, ResNet18 miniImageNet 5w5s", "value": args.steps * world / dt,
         "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic" if not args.selftest_one_gpu else "synthetic (SELF-TEST: all ranks share one GPU; not a measurement)",
         "config": {"workload": "8-session FSCIL, subspace regularizer, -M (BASELINE.json configs[1]); one seed per GPU",
                    "epochs_per_episode": args.epochs, "images_per_gpu": imgs, "base_batch": args.base_batch,
                    "feature_reuse": bool(args.reuse_features), "backbone": "ResNet18 (RFS ResNet-12 family, 8.1219 GFLOP/img)",
