@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUBREG_ABI_VERSION 3
+#define SUBREG_ABI_VERSION 4
 
 #define SUBREG_OK 0
 #define SUBREG_EINVAL (-1)       /* bad argument (null pointer, shape not supported by contract) */
@@ -295,10 +295,12 @@ typedef struct subreg_step_desc {
 
 /* the validation of ALL query sets so far (language_eval.py:321-326: one `validate` call over the list of sets) in one
  * launch: the rows of set j follow those of set j-1 in feat / labels; set_rows[n_sets] is a HOST array of row counts;
- * correct[slot*n_sets_max + j] += hits of set j, as subreg_validate does per set */
+ * correct[slot*n_sets_max + j] += hits of set j, as subreg_validate does per set; correct_top5 (same layout, may be NULL)
+ * counts the rows whose label is among the five largest logits (eval/util.py:26-40, topk=(1, 5)) */
 #define SUBREG_MAX_QUERY_SETS 32
 int subreg_validate_sets(const float* feat, const long long* labels, const float* weight, const int* set_rows, int n_sets, int N,
-                         int D, subreg_loop_state* state, int* correct, int n_sets_max, int mark_done, void* stream);
+                         int D, subreg_loop_state* state, int* correct, int* correct_top5, int n_sets_max, int mark_done,
+                         void* stream);
 /* nn.CrossEntropyLoss() (mean) + eval/util.py:26-40 accuracy counters of one batch: rowloss[B] (scratch, required with
  * loss), loss[1] = mean, dlogits[B][N] = (softmax - onehot)/B, correct[0] += #(label is the argmax),
  * correct[1] += #(label within the topk largest).  Every output pointer may be NULL. */

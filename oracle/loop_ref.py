@@ -44,6 +44,14 @@ def accuracy_top1(logits, labels):
     return float(np.float32((pred == labels).sum() * (100.0 / labels.shape[0]))), pred
 
 
+def accuracy_topk(logits, labels, k=5):
+    """eval/util.py:26-40 with topk=(..., k): the label is among the k largest logits (torch.topk breaks ties towards the lower
+    index; a stable descending argsort does the same)."""
+    order = np.argsort(-logits, axis=1, kind="stable")[:, :k]
+    hit = (order == np.asarray(labels)[:, None]).any(axis=1)
+    return float(np.float32(hit.sum() * (100.0 / len(labels))))
+
+
 def memory_indices(pick, n_shots=5):
     """language_eval.py:354-358 for `inds = np.random.choice(n_shots, memory_replay)` == pick."""
     inds = np.asarray(pick)
@@ -72,7 +80,7 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
     W = net.sd["classifier.weight"].astype(f32).copy()          # live classifier.weight
     base_weight = W.copy()                                      # basenet._get_base_weights(), :106-107
     base_x, base_y = base_batch
-    out = dict(loss=[], test_acc=[], acc_base=[], weighted_avg=[], epochs=[], novel_acc=[],
+    out = dict(loss=[], test_acc=[], test_acc_top5=[], acc_base=[], weighted_avg=[], epochs=[], novel_acc=[],
                memory_inds=[], train_acc=[], novel_vals=[], base_vals=[])
 
     def eval_feats(x):
@@ -177,7 +185,7 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
                 go = False
             # ---- validation on every query set so far (eval mode from here on), :321-326
             net.eval()
-            test_acc = []
+            test_acc, test_acc5 = [], []
             for j, (xq, yq) in enumerate(zip(query_x, query_ids)):
                 key = ("q", j)
                 if reuse_features and key in feat_cache:
@@ -186,6 +194,7 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
                     feat_cache[key] = net.features(xq)
                 a, _ = accuracy_top1(linear(feat_cache[key], W), yq)
                 test_acc.append(a)
+                test_acc5.append(accuracy_topk(linear(feat_cache[key], W), yq, 5))   # validate's acc5, language_eval.py:40
             epoch += 1
         # ---- memory pick, :353-359
         if opt.memory_replay:
@@ -205,6 +214,7 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
         out["loss"].append(losses)
         out["train_acc"].append(tr_acc)
         out["test_acc"].append(test_acc)
+        out["test_acc_top5"].append(test_acc5)
         out["novel_vals"].append(ta)          # AverageMeter contents, :379-380 (un-rounded)
         out["base_vals"].append(acc_b)
         out["novel_acc"].append(round(ta, 2))

@@ -476,7 +476,8 @@ struct ValidateSets {
 };
 __global__ __launch_bounds__(256) void validate_sets_kernel(const float* __restrict__ feat, const long long* __restrict__ labels,
                                                              const float* __restrict__ W, int N, int D, subreg_loop_state* st,
-                                                             int* __restrict__ correct, int n_sets_max, const ValidateSets vs) {
+                                                             int* __restrict__ correct, int* __restrict__ correct5, int n_sets_max,
+                                                             const ValidateSets vs) {
     __shared__ float s_logit[MAX_CLS];
     int slot = 0;
     if (st) {
@@ -500,6 +501,17 @@ __global__ __launch_bounds__(256) void validate_sets_kernel(const float* __restr
             if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
         }
         if (lane == 0 && arg == (int)labels[b]) atomicAdd(&correct[(size_t)slot * n_sets_max + set], 1);
+        if (correct5) {
+            // top-5 (eval/util.py:26-40 `accuracy(..., topk=(1, 5))`): the label is among the five largest logits <=> fewer than
+            // five classes rank above it (strictly greater, ties towards the lower index like torch.topk)
+            const int y = (int)labels[b];
+            const float ty = s_logit[y];
+            int above = 0;
+            for (int n = lane; n < N; n += 64) above += (s_logit[n] > ty || (s_logit[n] == ty && n < y)) ? 1 : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) above += __shfl_xor(above, o);
+            if (lane == 0 && above < 5) atomicAdd(&correct5[(size_t)slot * n_sets_max + set], 1);
+        }
     }
 }
 
@@ -665,8 +677,8 @@ extern "C" int subreg_frob(const float* a, const float* b, long long n, float lm
 }
 
 extern "C" int subreg_validate_sets(const float* feat, const long long* labels, const float* weight, const int* set_rows, int n_sets,
-                                    int N, int D, subreg_loop_state* state, int* correct, int n_sets_max, int mark_done,
-                                    void* stream) {
+                                    int N, int D, subreg_loop_state* state, int* correct, int* correct_top5, int n_sets_max,
+                                    int mark_done, void* stream) {
     SUBREG_CHECK_ARG(feat && labels && weight && correct && set_rows && N > 0 && N <= MAX_CLS && D > 0);
     SUBREG_CHECK_ARG(n_sets >= 1 && n_sets <= SUBREG_MAX_QUERY_SETS && n_sets <= n_sets_max);
     ValidateSets vs;
@@ -678,7 +690,7 @@ extern "C" int subreg_validate_sets(const float* feat, const long long* labels, 
         vs.end[j] = total;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(validate_sets_kernel, total, 256, 0, s, feat, labels, weight, N, D, state, correct, n_sets_max, vs);
+    hipLaunchKernelGGL(validate_sets_kernel, total, 256, 0, s, feat, labels, weight, N, D, state, correct, correct_top5, n_sets_max, vs);
     if (mark_done && state) hipLaunchKernelGGL(validate_mark_kernel, 1, 64, 0, s, state);
     return launch_status();
 }

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SUBREG_LIB") or os.path.join(_HERE, "libsubreg_hip.so
 F32, BF16 = 0, 1
 CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
 FWD_TRAIN = 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_QUERY_SETS = 32                          # SUBREG_MAX_QUERY_SETS
 
 c_void_p, c_int, c_float, c_longlong = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -90,7 +90,7 @@ SIGNATURES = {
     "subreg_pack_conv_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "subreg_conv_wgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "subreg_conv_wgrad_splits": (_I, [_I, _I, _I, _I, _I, _I, _I]),
-    "subreg_validate_sets": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _P]),
+    "subreg_validate_sets": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P]),
     "subreg_softmax_ce": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "subreg_semantic_target": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P]),
     "subreg_semantic_target_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P]),

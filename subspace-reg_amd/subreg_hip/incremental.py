@@ -57,6 +57,7 @@ class _SessionBuffers:
         self.losses = torch.zeros(max_epochs, dtype=f32, device=dev)
         self.train_acc = torch.zeros(max_epochs, dtype=f32, device=dev)
         self.correct = torch.zeros((max_epochs + 1) * n_sets, dtype=i32, device=dev)
+        self.correct5 = torch.zeros((max_epochs + 1) * n_sets, dtype=i32, device=dev)   # top-5 hits (validate :40, never used by the loop)
         self.mom = torch.zeros(n_cls * dim, dtype=f32, device=dev)
 
 
@@ -177,7 +178,7 @@ class IncrementalRunner:
         self.query_x, self.query_id = [], []
         self.mem_x = self.mem_y = None
         self.reserve = None
-        self.run = dict(loss=[], test_acc=[], epochs=[], train_acc=[], memory_inds=[], graph_replays=[])
+        self.run = dict(loss=[], test_acc=[], test_acc_top5=[], epochs=[], train_acc=[], memory_inds=[], graph_replays=[])
         self.vocab_base = self.vocab_novel = None
         return self
 
@@ -274,8 +275,8 @@ class IncrementalRunner:
             _lib.check(lib.subreg_finetune_step(C.byref(d), s()), "finetune_step")
             if n_sets <= _lib.MAX_QUERY_SETS:          # all query sets in one launch (rows and labels are consecutive)
                 _lib.check(lib.subreg_validate_sets(_lib.ptr(feats[q_off[0]:]), _lib.ptr(query_labels), _lib.ptr(W), set_rows,
-                                                    n_sets, N, D, _lib.ptr(ses.state), _lib.ptr(ses.correct), n_sets, 1, s()),
-                           "validate_sets")
+                                                    n_sets, N, D, _lib.ptr(ses.state), _lib.ptr(ses.correct), _lib.ptr(ses.correct5),
+                                                    n_sets, 1, s()), "validate_sets")
                 return
             for j in range(n_sets):
                 _lib.check(lib.subreg_validate(_lib.ptr(feats[q_off[j]:]), _lib.ptr(query_id[j]), _lib.ptr(W),
@@ -347,6 +348,9 @@ class IncrementalRunner:
         losses = ses.losses[:epochs].cpu().numpy().astype(np.float64)
         correct = ses.correct.view(-1, n_sets)[epochs].cpu().numpy()
         test_acc = [round(_acc(int(c), query_x[j].shape[0]), 2) for j, c in enumerate(correct)]   # :372
+        top5 = None
+        if n_sets <= _lib.MAX_QUERY_SETS:           # validate's acc5 (:40); the reference computes it and uses it nowhere
+            top5 = [_acc(int(c), query_x[j].shape[0]) for j, c in enumerate(ses.correct5.view(-1, n_sets)[epochs].cpu().numpy())]
         if opt.memory_replay:                                                  # :353-359
             pick = (self.memory_picks[idx] if self.memory_picks is not None
                     else np.random.choice(opt.n_shots, opt.memory_replay))
@@ -380,6 +384,7 @@ class IncrementalRunner:
         run["test_acc"].append(test_acc)
         run["epochs"].append(epochs)
         run["graph_replays"].append(replays)
+        run["test_acc_top5"].append(top5)
         run["train_acc"].append(ses.train_acc[:epochs].cpu().numpy())
         return epochs
 

@@ -487,6 +487,45 @@ def test_linear_fwd_bwd():
     _cmp("dfeat", ft.grad.cpu().numpy(), go.astype(np.float64) @ w, 1e-5, 1e-5)
 
 
+def test_validate_sets_top1_and_top5_with_ties():
+    """validate over several query sets in one launch (language_eval.py:321-326 -> validate :18-43): top-1 and top-5 hit counts
+    per set against the oracle's stable-sort rule; features are small integers so logits are exact and ties are real.  A
+    classifier with fewer than five rows makes every row a top-5 hit."""
+    from oracle import loop_ref
+    lib = _lib.load()
+    rs = np.random.RandomState(5)
+    for N, D in ((65, 640), (351, 640), (4, 64)):
+        rows = [125, 125, 37]
+        n = sum(rows)
+        f = rs.randint(-1, 2, (n, D)).astype(np.float32)
+        w = rs.randint(-1, 2, (N, D)).astype(np.float32)
+        w[1] = w[0]                                               # duplicate rows: exact ties between classes 0 and 1
+        if N > 8:
+            w[7] = w[3]
+        y = rs.randint(0, N, n).astype(np.int64)
+        ft, wt, yt = _t(f), _t(w), torch.from_numpy(y).cuda()
+        c1 = torch.zeros(2 * 3, dtype=torch.int32, device="cuda")
+        c5 = torch.zeros(2 * 3, dtype=torch.int32, device="cuda")
+        set_rows = (C.c_int * 3)(*rows)
+        _lib.check(lib.subreg_validate_sets(_lib.ptr(ft), _lib.ptr(yt), _lib.ptr(wt), set_rows, 3, N, D, None, _lib.ptr(c1),
+                                            _lib.ptr(c5), 3, 0, None), "validate_sets")
+        _lib.check(lib.subreg_validate_sets(_lib.ptr(ft), _lib.ptr(yt), _lib.ptr(wt), set_rows, 3, N, D, None, _lib.ptr(c1),
+                                            None, 3, 0, None), "validate_sets without top-5")
+        torch.cuda.synchronize()
+        logits = f.astype(np.float64) @ w.T.astype(np.float64)
+        o = 0
+        for j, r in enumerate(rows):
+            lg, yy = logits[o:o + r], y[o:o + r]
+            want1 = int((np.argmax(lg, 1) == yy).sum())
+            want5 = int(round(loop_ref.accuracy_topk(lg, yy, 5) * r / 100.0))
+            assert int(c1[j]) == 2 * want1, (N, j, int(c1[j]), want1)           # two launches accumulated
+            assert int(c5[j]) == want5, (N, j, int(c5[j]), want5)
+            if N < 5:
+                assert want5 == r
+            o += r
+        assert int(c1[3:].sum()) == 0 and int(c5[3:].sum()) == 0
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsubreg_hip.so")
