@@ -189,6 +189,53 @@ def test_conv_folded_scale_and_fused_shortcut(case, dtype):
     _cmp("fused conv3", got, rr._nchw(want), a, r)
 
 
+# ---------------------------------------------------------------- layer-1 kernel (conv64_resident.hip) off its home shape
+# subreg_conv_fwd sends Cin = Cout = 64, 3x3, folded-scale, bf16 calls with 64 <= W <= 95 to the persistent kernel; the
+# backbone only ever calls it at 84x84.  Other widths / heights exercise what 84 does not: tiles of 2 or 3 image rows with a
+# ragged last tile (H % R != 0), DMA pieces without pixels (W < 80), the last pad column shared with the next block
+# (W = 95), odd H / W under the pooling floor, a single image, the un-activated epilogue.
+R64_CASES = [
+    # B, H, W, pool, shortcut (Cin2 = 32), act
+    (3, 66, 80, False, False, True),
+    (2, 85, 94, False, False, True),       # R = 2 rows per tile, ragged last tile
+    (1, 64, 95, False, False, False),      # widest admitted; no activation
+    (5, 7, 65, False, False, True),        # 3 rows per tile, DMA pieces without pixels, tiny image (W = 64 would need 4 rows: general kernel)
+    (2, 85, 94, True, True, True),         # pooled: odd height (floor), windows per tile searched by the host
+    (3, 66, 70, True, False, True),
+    (1, 65, 95, True, True, True),
+    (4, 84, 84, True, False, False),
+]
+
+
+@pytest.mark.parametrize("case", R64_CASES, ids=lambda c: "B%d_%dx%d_p%d_sc%d_a%d" % tuple(int(v) for v in c))
+def test_conv64_resident_other_shapes(case):
+    B, H, W, pool, sc, act = case
+    lib = _lib.load()
+    rs = np.random.RandomState(hash(case) % (2 ** 31))
+    x = _round_bf16(rs.standard_normal((B, 64, H, W)).astype(np.float32))
+    wf = _round_bf16((rs.standard_normal((64, 64, 3, 3)) * (1.4 / 24)).astype(np.float32))
+    shift = (rs.standard_normal(64) * 0.3).astype(np.float32)
+    want = rr.conv_nhwc(rr._nhwc(x).astype(np.float64), wf.astype(np.float64)) + shift
+    x2d = w2d = None
+    if sc:
+        x2 = _round_bf16(rs.standard_normal((B, 32, H, W)).astype(np.float32))
+        w2 = _round_bf16((rs.standard_normal((64, 32, 1, 1)) / np.sqrt(32)).astype(np.float32))
+        want = want + rr.conv_nhwc(rr._nhwc(x2).astype(np.float64), w2.astype(np.float64))
+        x2d, w2d = _nhwc_dev(x2, "bf16"), _pack_w(w2, "bf16")
+    if act:
+        want = rr.leaky_relu(want)
+    want = rr.maxpool_nhwc(want, 2 if pool else 1)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.full((B * Ho * Wo * 64,), float("nan"), dtype=torch.bfloat16, device=_dev())
+    xd, wd, shd = _nhwc_dev(x, "bf16"), _pack_w(wf, "bf16"), _t(shift)
+    flags = (_lib.CONV_LRELU if act else 0) | (_lib.CONV_POOL2 if pool else 0)
+    _lib.check(lib.subreg_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), None, _lib.ptr(shd), None, None, _lib.ptr(x2d),
+                                   _lib.ptr(w2d), 32 if sc else 0, B, H, W, 64, 64, 3, flags, _lib.BF16, _lib.stream_ptr()), "conv_fwd")
+    got = _nchw_host(y, B, 64, Ho, Wo, "bf16")
+    a, r = _tol("bf16", np.abs(want).max())
+    _cmp("conv64", got, rr._nchw(want), a, r)
+
+
 # ---------------------------------------------------------------- production tile shapes (bench-scale batches)
 # Every tiling subreg_conv_fwd selects at the batch sizes the benchmark / the pretraining step run (conv_fwd.hip:
 # 256-row / 128-row one-tap / 128-row three-tap two-wave tiles for Cout % 160 == 0, the three Cout = 64 tilings) needs
