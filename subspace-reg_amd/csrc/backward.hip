@@ -689,14 +689,23 @@ extern "C" int subreg_bn_bwd(const void* dy, const void* act, const void* raw, c
                              int dtype, void* stream) {
     SUBREG_CHECK_ARG(dy && raw && mean && invstd && gamma && partial && dgamma && dbeta && dx && npix > 0 && C > 0);
     hipStream_t s = (hipStream_t)stream;
-    const int slices = bn_bwd_reduce_slices(npix);
+    // slices of >= 256 pixels, at most ~512 of them (two per CU): the finalize pass walks every slice of a channel, and at
+    // 1764 slices (64 x 84 x 84 pixels) it cost 11 us of dependent fp64 loads per BatchNorm.  A thread still sums at most
+    // 64 pixels in fp32 before the fp64 stages (pixel lanes = 256 / (C / vec) >= 32 for C <= 64 ... 3 for C = 640: the slice
+    // grows only where there are many lanes).
+    const int vec_ = dtype == SUBREG_BF16 ? 8 : 4;
+    const int lanes_ = C / vec_ > 0 && C / vec_ <= 256 ? 256 / (C / vec_) : 1;
+    long long pps = (npix + 511) / 512;
+    if (pps > 64LL * lanes_) pps = 64LL * lanes_;
+    if (pps < 256) pps = 256;
+    const int slices = (int)((npix + pps - 1) / pps);                                     // <= bn_bwd_reduce_slices(npix)
     float* const coef = reinterpret_cast<float*>(partial + (size_t)slices * C * 2);     // 3*C floats in the extra slice (4*C)
     const int vec = dtype == SUBREG_BF16 ? 8 : 4;
     SUBREG_CHECK_ARG(C % vec == 0 && C / vec <= 256);
     const size_t lds = (size_t)(256 / (C / vec)) * C * 2 * sizeof(float);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, slices, 256, lds, s, (const float*)dy, (const float*)act, (const float*)raw, mean, invstd, partial, npix, C, 256),
-               hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, slices, 256, lds, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, partial, npix, C, 256));
+               hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, slices, 256, lds, s, (const float*)dy, (const float*)act, (const float*)raw, mean, invstd, partial, npix, C, (int)pps),
+               hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, slices, 256, lds, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, partial, npix, C, (int)pps));
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, (C + 15) / 16, 256, 0, s, partial, slices, C, mean, invstd, gamma, 1.0 / (double)npix,
                        dgamma, dbeta, coef);
     const size_t n = (size_t)npix * C;

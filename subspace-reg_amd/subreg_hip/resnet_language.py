@@ -208,14 +208,12 @@ class ResNet(nn.Module):
             from .train import BackboneTrainFn
             names, params = zip(*[(n, p) for n, p in self.named_parameters() if not n.startswith("classifier")])
             feat = BackboneTrainFn.apply(x, hb, self.mask_source, names, *params)
-            for m in self._bns:
-                m.num_batches_tracked += 1
+            torch._foreach_add_([m.num_batches_tracked for m in self._bns], 1)      # one launch, not one per BatchNorm
             return feat
         hb = self.hip_backbone()
         out = hb.forward(x.float(), train=self.training, masks=self.mask_source, return_stages=return_stages)
         if self.training:
-            for m in self._bns:
-                m.num_batches_tracked += 1
+            torch._foreach_add_([m.num_batches_tracked for m in self._bns], 1)
         return out
 
     def forward(self, x, is_feat=False, get_alphas=False):
