@@ -172,3 +172,18 @@ def test_bench_self_launch_and_sweep_plan_gloo():
     p2 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--selftest-host"], stdout=subprocess.PIPE,
                         stderr=subprocess.PIPE, text=True, env=env2, timeout=120)
     assert p2.returncode != 0 and "WORLD_SIZE" in p2.stderr
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_collectives_on_device():
+    """Backend "nccl" (RCCL) with one rank on cuda:0, in a fresh process: every collective the build issues (barrier, fp64 MAX,
+    state_dict broadcast incl. int64 counters, feature all-gather, sub-group, staged async gradient all-reduce behind the HIP
+    backward) runs on the device and reproduces the identity exactly (tools/rccl_smoke.py).  Two-rank semantics: the gloo tests
+    above and tools/dp_check.py / dp_pretrain_check.py."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(repo, "tools", "rccl_smoke.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "-> OK" in p.stdout and "backend nccl" in p.stdout
