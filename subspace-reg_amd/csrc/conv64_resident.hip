@@ -393,6 +393,345 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
 #endif
 }
 
+// all but the n youngest vector-memory operations (LDS-DMAs and stores, in issue order) of this wave are done; n wave-uniform
+__device__ __forceinline__ void vm_wait(int n) {
+#define R64_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        R64_VMW(0) R64_VMW(1) R64_VMW(2) R64_VMW(3) R64_VMW(4) R64_VMW(5) R64_VMW(6) R64_VMW(7) R64_VMW(8) R64_VMW(9) R64_VMW(10) R64_VMW(11)
+        R64_VMW(12) R64_VMW(13) R64_VMW(14) R64_VMW(15) R64_VMW(16)
+        default: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    }
+#undef R64_VMW
+}
+
+// 2 KB of zeros: DMA source of patch blocks outside the image for the kernel below (a whole piece of 16 pixels x 128 bytes,
+// so the lane offsets of a real piece work on it unchanged)
+__device__ __attribute__((aligned(128))) unsigned r64_zero_piece[512];
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same convolution with ONE wave per SIMD (4 waves per workgroup, one workgroup per CU, 512 registers per lane).
+// Why: the 8-wave kernel above is bound by the instructions AROUND its MFMAs - ~600 per wave and tile for 72 MFMAs, twice per
+// SIMD (profiles/r02_ab_conv64_phase_shift.txt) - and its 256-register waves have no room left.  Here wave w owns rows
+// [64 w, +64) x ALL 64 output channels:
+//   * one A fragment (LDS read) feeds two MFMAs (both column halves): half the LDS reads and waits per MFMA;
+//   * 288 registers of weights + 64 of accumulators live mostly in the accumulation registers (hipcc feeds MFMA operands
+//     from a[...]), leaving room for an 8-deep fragment ring: LDS latency is covered without a partner wave;
+//   * the tile is computed as two half-phases - row tile 0 (72 MFMAs over all of K), then row tile 1 - and everything else
+//     is a FILLER between their MFMAs: the epilogue of the row tile finished one phase earlier (one accumulator register
+//     per fragment) and the DMA pieces of the next tile's two planes (one per four fragments, in three small steps).  No
+//     extra accumulators are needed: while row tile 0 of tile t+1 accumulates, row tile 1 of tile t is still in registers;
+//   * the epilogue never touches LDS (an LDS write per fragment costs the MFMA stream ~5 cycles per MFMA,
+//     tools/probes/mfma_fillers.hip): the MFMA operands are SWAPPED (A = weights, B = pixels), so a lane holds 4 consecutive
+//     channels of ONE pixel per 4 registers; pairs are packed to bf16, v_permlane32_swap exchanges halves between the two
+//     lanes of a pixel, and each lane stores 16 bytes = 8 consecutive channels (a store instruction = 32 pixel rows x 32
+//     contiguous bytes).  The BN shift enters as one more k-step (A = shift split into bf16 hi + lo, B = ones): the first
+//     MFMA of a phase, with C = 0;
+//   * both planes of a tile stay live for the whole tile, so the ring has four planes (this tile's pair, the next tile's
+//     pair, staged a whole tile ahead) and ONE barrier per tile.
+// LINEAR only (layer1.0 conv2); same LDS image layout, tile schedule and data layouts as above.
+template <int BLOCKS, bool ACT>
+__global__ __launch_bounds__(256, 1) void conv64_wide_kernel(const Conv64Args a) {
+    constexpr int P = R64_P, PROWS = BLOCKS * P, PLANE = PROWS * R64_ROWB, PIECES = PROWS / 16, PPB = P / 16, NW = 4;
+    constexpr int NPK = (PIECES + NW - 1) / NW;                       // DMA pieces per wave and plane (8)
+    constexpr int LDS_PLANES = 4 * PLANE;
+    constexpr int RD = 8, NF = 36;                                    // fragment reads in flight (+1); fragments per half-phase
+    static_assert(PLANE + 2 * P * R64_ROWB < 65536, "chunk + tap offsets are 16-bit immediates");
+    static_assert(4 * (NPK - 1) + 2 <= 30 && NPK <= 8, "filler schedule");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#if R64_DIAG
+    const unsigned long long d_entry = __builtin_amdgcn_s_memtime(), d_entry_r = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = (nwg + 7 - xcd) >> 3;
+    const int per = (a.ntiles + 7) >> 3;
+    const int t_begin = xcd * per + slot, t_end = min((xcd + 1) * per, a.ntiles);
+    if (t_begin >= t_end) return;
+
+    // ---- resident weights: B fragments of all 64 output columns (two halves), all taps / chunks / k-steps: 288 registers.
+    //      The first NWA fragments are moved into accumulation registers by hand ("=a": MFMA reads its B operand from
+    //      a[...] directly); left to itself hipcc keeps what fits in v[...] and SPILLS the rest to a[...], copying four
+    //      registers back in front of every MFMA that uses them (136 v_accvgpr_read per tile).
+    constexpr int NWA = 48;
+    u32x4 bw[72];
+    static_for<0, 3>([&](auto bc) {                                   // three batches of 24 loads in flight, then their moves
+        constexpr int b0 = decltype(bc)::value * 24;
+        static_for<b0, b0 + 24>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value, h = idx & 1, s = (idx >> 1) & 1, t = (idx >> 2) % 9, c = idx / 36;
+            bw[idx] = *reinterpret_cast<const u32x4*>(a.w + (size_t)(32 * h + lr) * R64_ROWB + lh * 16 + (size_t)((t * 2 + c) * 64) * R64_ROWB + s * 32);
+        });
+        static_for<b0, b0 + 24>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value;
+            if constexpr (idx < NWA) {                                // from here on the fragment lives in a[...] (the compiler makes the move, after its own wait)
+                u32x4 v = bw[idx];
+                asm volatile("" : "+a"(v));
+                bw[idx] = v;
+            }
+        });
+    });
+    // the BN shift as a k-step of its own: A rows = output channels, k = 0 / 1 hold the shift's bf16 hi / lo parts; B = ones
+    u32x4 bias_a[2], ones_b;
+    {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float sh = a.shift[32 * h + lr];
+            const __bf16 hi = (__bf16)sh, lo = (__bf16)(sh - (float)hi);
+            const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+            bias_a[h] = u32x4{lh == 0 ? pk : 0u, 0u, 0u, 0u};
+        }
+        ones_b = u32x4{lh == 0 ? 0x3f803f80u : 0u, 0u, 0u, 0u};
+    }
+    for (int o = tid * 16; o < LDS_PLANES; o += NW * 64 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    // ---- DMA pieces of this wave (q = wid + 4 k): everything but the plane's base pointer is computed once
+    const int prl = lane >> 2, psl = lane & 3;
+    const unsigned glane = (unsigned)prl * 128u + ((unsigned)(psl ^ swz<4>(prl)) << 4);
+    unsigned poff[NPK];
+    unsigned long long emask[NPK];
+    int prb[NPK];
+#pragma unroll
+    for (int k = 0; k < NPK; ++k) {
+        const int q = wid + NW * k, rb = q / PPB, c0 = (q - rb * PPB) * 16, col = c0 + prl;
+        poff[k] = (unsigned)__builtin_amdgcn_readfirstlane((rb * a.W + c0) * 128);
+        emask[k] = __builtin_amdgcn_ballot_w64(col >= 1 && col <= a.W);
+        prb[k] = __builtin_amdgcn_readfirstlane(rb);
+    }
+    int vm_issued = 0;                                               // vector-memory instructions of this wave so far (in-order completion)
+    struct Src { const char* base; unsigned dst; int h_first; };    // base: one pixel BEFORE (block 0, column 1)
+    auto make_src = [&](unsigned dst, int c, int b, int h_first) {
+        Src r;
+        r.base = a.x + (((long long)b * a.H + h_first) * a.W - 1) * 128 + c * 64;
+        r.dst = dst + wid * 1024;
+        r.h_first = h_first;
+        return r;
+    };
+    const char* const zeros = reinterpret_cast<const char*>(r64_zero_piece);
+    // a DMA piece in three filler steps (a: in the image?  b: source address  c: issue), values pinned where they are computed
+    int dm_in[NPK];
+    unsigned long long dm_src[NPK];
+    auto dma_a = [&](const Src& src, auto kc) {
+        constexpr int k = decltype(kc)::value;
+        int in = __builtin_amdgcn_readfirstlane((unsigned)(src.h_first + prb[k]) < (unsigned)a.H ? 1 : 0);
+        asm volatile("" : "+s"(in));
+        dm_in[k] = in;
+    };
+    auto dma_b = [&](const Src& src, auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const unsigned long long b64 = (unsigned long long)(size_t)(dm_in[k] ? src.base + poff[k] : zeros);
+        unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
+        asm volatile("" : "+s"(lo), "+s"(hi));
+        dm_src[k] = ((unsigned long long)hi << 32) | lo;
+    };
+    auto dma_c = [&](const Src& src, auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (k < PIECES / NW || wid + NW * k < PIECES) {
+            const unsigned lds_u = src.dst + k * (NW * 1024);
+            unsigned keep_m0;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b64 exec, %1\n\t"
+                "s_mov_b32 m0, %2\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %3, %4\n\t"
+                "s_mov_b32 m0, %0\n\t"
+                "s_mov_b64 exec, -1"
+                : "=&s"(keep_m0)
+                : "s"(emask[k]), "s"(lds_u), "v"(glane), "s"(dm_src[k])
+                : "memory");
+            ++vm_issued;
+        }
+    };
+    auto stage_all = [&](const Src& src) {
+        static_for<0, NPK>([&](auto kc) { dma_a(src, kc); dma_b(src, kc); dma_c(src, kc); });
+    };
+
+    // ---- per-lane A addresses (absolute, plane pair a_set, chunk 0) of the dy = -1 row: [row tile][dx + 1][k-step];
+    //      chunk 1 and the tap row are immediates (c PLANE + (dy + 1) P 64)
+    unsigned areg[2][3][2];
+    int a_set = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = wid * 64 + i * 32 + lr, jv = j < a.R * a.W ? j : 0;
+        const int ir = (int)fdiv((unsigned)jv, a.d_w), w = jv - ir * a.W;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int row = ir * P + w + dx;
+            const unsigned ad = lds_base + (unsigned)row * R64_ROWB + 16u * (lh ^ swz<4>(row));
+            areg[i][dx][0] = ad;
+            areg[i][dx][1] = ad ^ 32u;
+        }
+    }
+    struct Geom { int b, k_img, h_first; };
+    auto tile_geom = [&](int t, Geom& g) {
+        const int bb = (int)fdiv((unsigned)t, a.d_tpi), k = t - bb * a.tpi;
+        g.b = __builtin_amdgcn_readfirstlane(bb);
+        g.k_img = __builtin_amdgcn_readfirstlane(k);
+        g.h_first = g.k_img * a.R - 1;
+    };
+
+    f32x16 acc[2][2];                                                 // [row tile][column half]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[1][h][r] = 0.f;
+    struct Pend { char* y; int nv; };                                 // where the pending row tile goes: its first output row, valid rows
+    // ---- the epilogue of row tile O, one accumulator register per step v = 16 h + r.  C layout with swapped operands: lane =
+    //      (pixel lr, half lh); register r of column half h = channel 32 h + (r & 3) + 8 (r >> 2) + 4 lh.  Registers 8 g2 .. + 7
+    //      are packed to four bf16 pairs P0..P3 (channels +0,1 | +2,3 | +8,9 | +10,11 of 16 g2 + 4 lh); two half-swaps give the
+    //      lower lane channels 16 g2 + 0..7 and the upper lane 16 g2 + 8..15 of the pixel: one 16-byte store each
+    auto lrelu1 = [&](float x) {
+        if (!ACT) return x;
+        float y;
+        asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(x * 0.1f));      // (fmaxf would add a canonicalising v_max per value)
+        return y;
+    };
+    float ex[8];
+    unsigned epk[4];
+    const unsigned st_lane = (unsigned)lr * 128u + (unsigned)lh * 16u;    // byte offset of this lane's vector in a row tile's output
+    auto epi_step = [&](auto oc, auto vc, const Pend& pe) {
+        constexpr int O = decltype(oc)::value, v = decltype(vc)::value, h = v >> 4, r = v & 15, e = r & 7;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        ex[e] = lrelu1(acc[O][h][r]);
+        if constexpr (e & 1) epk[e >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ex[e - 1], ex[e]}, bf16x2));
+        if constexpr (e == 7) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(epk[0], epk[2], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(epk[1], epk[3], false, false);
+            const u32x4 vec = {s0[0], s1[0], s0[1], s1[1]};
+            if (pe.nv > 0) {                                          // wave-uniform: the instruction exists
+                if (lr < pe.nv) *reinterpret_cast<u32x4*>(pe.y + (h * 64 + (r >> 3) * 32) + st_lane) = vec;
+                ++vm_issued;
+            }
+        }
+    };
+
+    // one half-phase: row tile I over all of K (36 fragments x 2 MFMAs) from the plane pair at areg; fillers: the pending
+    // epilogue of row tile 1 - I, the DMA pieces of plane `src`
+    int vm_mark = 0;                                                  // vm_issued after the last DMA piece of a phase
+    auto phase = [&](auto ic, const Src& src, const Pend& pe) {
+        constexpr int I = decltype(ic)::value, O = 1 - I;
+        u32x4 ring[RD];
+        auto rd = [&](auto jc) {
+            constexpr int j = decltype(jc)::value, c = j / 18, tt = (j % 18) >> 1, s = j & 1, dy = tt / 3, dx = tt % 3;
+            ring[j % RD] = lds_read16<c * PLANE + dy * P * R64_ROWB>(areg[I][dx][s]);
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        static_for<0, RD - 1>(rd);
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[I][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bias_a[0]), __builtin_bit_cast(bf16x8, ones_b), zero16, 0, 0, 0);
+        acc[I][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bias_a[1]), __builtin_bit_cast(bf16x8, ones_b), zero16, 0, 0, 0);
+        static_for<0, NF>([&](auto fc) {
+            constexpr int f = decltype(fc)::value, c = f / 18, tt = (f % 18) >> 1, s = f & 1;
+            if constexpr (f + RD - 1 < NF) rd(std::integral_constant<int, f + RD - 1>{});
+            // ---- fillers
+            if constexpr (f < 32) epi_step(std::integral_constant<int, O>{}, fc, pe);
+            if constexpr (f % 4 == 0 && f / 4 < NPK) dma_a(src, std::integral_constant<int, f / 4>{});
+            if constexpr (f % 4 == 1 && f / 4 < NPK) dma_b(src, std::integral_constant<int, f / 4>{});
+            if constexpr (f % 4 == 2 && f / 4 < NPK) dma_c(src, std::integral_constant<int, f / 4>{});
+            if constexpr (f == 4 * (NPK - 1) + 2) vm_mark = vm_issued;
+            // ---- fragment f
+            constexpr int younger = NF - 1 - f < RD - 1 ? NF - 1 - f : RD - 1;
+            u32x4 fr = ring[f % RD];
+            fr = lds_wait<younger>(fr);
+            acc[I][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw[((c * 9 + tt) * 2 + s) * 2 + 0]), __builtin_bit_cast(bf16x8, fr), acc[I][0], 0, 0, 0);
+            acc[I][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw[((c * 9 + tt) * 2 + s) * 2 + 1]), __builtin_bit_cast(bf16x8, fr), acc[I][1], 0, 0, 0);
+        });
+    };
+
+    Geom cur, nxt = {0, 0, 0};
+    int t = t_begin;
+    tile_geom(t, cur);
+    stage_all(make_src(lds_base + 0 * PLANE, 0, cur.b, cur.h_first));
+    stage_all(make_src(lds_base + 1 * PLANE, 1, cur.b, cur.h_first));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+#if R64_DIAG
+    unsigned long long dq = __builtin_amdgcn_s_memtime(), dt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long d_c0 = dq, d_r0 = __builtin_amdgcn_s_memrealtime();
+#define R64W_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dt[k] += n_ - dq; dq = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define R64W_STAMP(k) do { } while (0)
+#endif
+    Pend pend = {a.y, 0};                                             // nothing pending before the first tile (no valid rows)
+    for (int it = 0; t < t_end; ++it, t += nslot) {
+        const int set = it & 1;                                       // this tile's plane pair: planes 2 set, 2 set + 1
+        if (set != a_set) {
+            const unsigned delta = (unsigned)((set - a_set) * 2 * PLANE);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) areg[i][dx][s] += delta;
+            a_set = set;
+        }
+        // the next tile's planes are staged during this one; after the last tile: this tile's patch once more (never read)
+        if (t + nslot < t_end) tile_geom(t + nslot, nxt); else nxt = cur;
+        const Src src0 = make_src(lds_base + (2 * (set ^ 1)) * PLANE, 0, nxt.b, nxt.h_first);
+        const Src src1 = make_src(lds_base + (2 * (set ^ 1) + 1) * PLANE, 1, nxt.b, nxt.h_first);
+        const int rows_left = a.H - cur.k_img * a.R, nvalid = (rows_left < a.R ? rows_left : a.R) * a.W;
+        char* const ytile = a.y + (((long long)cur.b * a.H + (long long)cur.k_img * a.R) * a.W + wid * 64) * 128;   // wave-uniform
+#if R64_DIAG
+        dt[0] += 1;
+#endif
+        R64W_STAMP(1);
+        phase(std::integral_constant<int, 0>{}, src0, pend);           // row tile 0 | epilogue of the previous tile's row tile 1
+        R64W_STAMP(2);
+        pend.y = ytile;
+        pend.nv = nvalid - wid * 64;
+        phase(std::integral_constant<int, 1>{}, src1, pend);           // row tile 1 | epilogue of this tile's row tile 0
+        R64W_STAMP(4);
+        pend.y = ytile + 32 * 128;
+        pend.nv = nvalid - wid * 64 - 32;
+        // the next tile's planes have landed (this wave's pieces); the stores behind them may stay in flight
+        vm_wait(vm_issued - vm_mark);
+        R64W_STAMP(5);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        R64W_STAMP(6);
+        cur = nxt;
+    }
+    // ---- the last tile's row tile 1
+    static_for<0, 32>([&](auto vc) { epi_step(std::integral_constant<int, 1>{}, vc, pend); });
+#if R64_DIAG
+    if (lane == 0 && blockIdx.x * 8 + wid < 4096) {                  // (same table as the 8-wave kernel: rows wid 4..7 stay empty)
+        float* d = r64_diag + (size_t)(blockIdx.x * 8 + wid) * 12;
+        d[10] = (float)(__builtin_amdgcn_s_memrealtime() - d_entry_r);
+        d[11] = 0.f;
+        d[8] = (float)(d_c0 - d_entry);
+        d[9] = (float)(d_entry_r % 100000000ull);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) d[q] = (float)dt[q];
+        d[7] = (float)(__builtin_amdgcn_s_memtime() - d_c0) / (float)(__builtin_amdgcn_s_memrealtime() - d_r0) * 0.1f;
+    }
+#endif
+}
+
+template <int BLOCKS, bool ACT>
+static int launch_r64_wide(const Conv64Args& a, hipStream_t stream) {
+    constexpr int PLANE = BLOCKS * R64_P * R64_ROWB;
+    constexpr size_t lds = 4 * (size_t)PLANE;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = conv64_wide_kernel<BLOCKS, ACT>;
+    static std::atomic<unsigned long long> lds_set{0};
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set)) return rc;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    int grid = cus < a.ntiles ? cus : a.ntiles;
+    grid = (grid + 7) / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    return launch_status();
+}
+
 template <bool POOL, bool SC, int BLOCKS>
 static int launch_r64(const Conv64Args& a, hipStream_t stream) {
     constexpr int PLANE = BLOCKS * R64_P * R64_ROWB;
@@ -432,6 +771,9 @@ int conv64_resident(const void* x, const void* w, void* y, const float* shift, c
         a.tpi = (H + a.R - 1) / a.R;
         a.ntiles = B * a.tpi;
         a.d_tpi = make_fastdiv(a.tpi);
+        // one wave per SIMD (conv64_wide_kernel) where its DMA accounting holds: every 16-column piece of a block has pixels
+        static const bool wide_on = [] { const char* e = getenv("SUBREG_NO_WIDE64"); return !(e && e[0] == '1'); }();
+        if (wide_on && W >= R64_P - 16) return act ? launch_r64_wide<5, true>(a, stream) : launch_r64_wide<5, false>(a, stream);
         return launch_r64<false, false, 5>(a, stream);
     }
     // windows per tile: the largest WT <= 64 for which no tile touches more than two row pairs (6 blocks = 2 pairs + halo)
