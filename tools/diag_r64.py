@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """In-kernel phase breakdown of conv64_resident (a -DR64_DIAG=1 build of the library: SUBREG_LIB=...).
-Median cycles per tile and wave in: address arithmetic, chunk 0, mid barrier, chunk 1, epilogue, DMA wait, end barrier."""
+Median cycles per tile and wave in: address arithmetic, chunk 0, mid barrier, chunk 1, epilogue, DMA wait, end barrier
+(8-wave kernel; SUBREG_NO_WIDE64=1 sends the un-pooled case there too) or the two half-phases of conv64_wide_kernel."""
 import ctypes as C
 import os
 import sys
@@ -44,6 +45,8 @@ def main():
         print("  wave resident time (s_memrealtime): median %.1f us, max %.1f us" % (np.median(d[:, 10]) / 100.0, d[:, 10].max() / 100.0))
         per = d[:, 1:7] / d[:, :1]
         names = ["setup+dma issue", "chunk0", "bar1", "chunk1", "epilogue", "dma wait+bar2"]
+        if not pool and os.environ.get("SUBREG_NO_WIDE64") != "1":     # conv64_wide_kernel (4 waves per workgroup) stamps its own phases
+            names = ["set-up", "phase A (row tile 0 + fillers)", "-", "phase B (row tile 1 + fillers)", "DMA wait", "barrier"]
         med = np.median(per, axis=0)
         print("pool=%d sc=%d B=%d: waves %d, tiles/wave %.1f, shader clock %.2f GHz, cycles per tile %.0f = " %
               (pool, sc, B, len(d), np.median(d[:, 0]), np.median(d[:, 7]), med.sum()) + ", ".join("%s %.0f" % (n, v) for n, v in zip(names, med)) +
