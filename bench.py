@@ -80,13 +80,15 @@ def make_run_inputs(seed, dev, n_base):
     return meta, base
 
 
-def make_net(args, seed, dev):
-    """Seeded random-init backbone (kaiming-normal convs) with BN running stats warmed by train-mode passes."""
+def make_net(args, seed, dev, sd=None):
+    """Seeded random-init backbone (kaiming-normal convs) with BN running stats warmed by train-mode passes.  `sd`: the seed's
+    state_dict if the caller already prepared it (the sweep builds the next seed's on a host thread while this seed runs)."""
     from subreg_hip import synthetic as syn
     from subreg_hip.resnet_language import create_model
     opt = make_opt(args, seed)
     net = create_model("resnet18", 60, opt)
-    sd = syn.make_state_dict(seed, randomize_bn=False)
+    if sd is None:
+        sd = syn.make_state_dict(seed, randomize_bn=False)
     net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     net = net.to(dev)
     for p in net.parameters():
@@ -201,8 +203,22 @@ def run_sweep(args, rank, world, dev, host_only):
     sweep.barrier()
     t0 = time.perf_counter()
     done = []
+    mine = [(sd, rk) for rnd in plan for sd, rk in rnd if rank in rk]
+    # a real sweep reads the next seed's checkpoint while this one runs; here: its random initialisation, on a host thread
+    prefetch, pool = {}, None
+    if not host_only:
+        from concurrent.futures import ThreadPoolExecutor
+        from subreg_hip import synthetic as syn
+        pool = ThreadPoolExecutor(max_workers=1)
+
+        def want(i):
+            if i < len(mine) and mine[i][0] not in prefetch:
+                prefetch[mine[i][0]] = pool.submit(syn.make_state_dict, mine[i][0], randomize_bn=False)
+        want(0)
+    pos = -1
     for rnd in plan:
         for seed, ranks in [(sd, rk) for sd, rk in rnd if rank in rk]:
+            pos += 1
             group = groups[tuple(ranks)]
             if host_only:                                   # control-path self-test: the plan, groups and collectives, no GPU work
                 t = torch.tensor([float(seed)])
@@ -210,7 +226,9 @@ def run_sweep(args, rank, world, dev, host_only):
                     dist.broadcast(t, ranks[0], group=group)
                 time.sleep(0.01)
             else:
-                net, opt = make_net(args, seed, dev)         # same seed -> same synthetic backbone on every rank of the group ...
+                sd_host = prefetch.pop(seed).result()
+                want(pos + 1)
+                net, opt = make_net(args, seed, dev, sd_host)   # same seed -> same synthetic backbone on every rank of the group ...
                 if group is not None:
                     sweep.broadcast_module(net, ranks[0], group)   # ... a real sweep loads it on the leader only
                 meta, base = make_run_inputs(seed, dev, args.base_batch)
@@ -224,6 +242,7 @@ def run_sweep(args, rank, world, dev, host_only):
                 done.append(seed)
     if not host_only:
         torch.cuda.synchronize()
+        pool.shutdown(wait=False)
     sweep.barrier()
     dt = sweep.max_over_ranks(time.perf_counter() - t0, None if host_only else dev)
     seen = sorted(x for r in sweep.gather_results(done) for x in r)
