@@ -12,7 +12,7 @@ template <int N> __device__ __forceinline__ u32x4 lds_wait(u32x4 f) { asm volati
 // KIND 0: none; 1: v_mul_f32 (dependent chain of its own); 3: ds_write_b16; 4: v_accvgpr_read of a finished accumulator;
 // 5: v_cvt_pk_bf16_f32; 6: s_mov exec pair (exec write + restore); 7: global_store_dwordx4 (1 KB contiguous) once per 8 fragments;
 // 8: LDS-DMA (global_load_lds_dwordx4, 1 KB, M0 saved / set / restored, exec set / restored) once per 4 fragments, N = 1: every
-//    DMA a new 1 KB of a large buffer (HBM stream), N = 2: always the same 1 KB (L2 hit), N = 3 / 4: strided pieces (16 rows x 64 bytes at a pitch of 128 / 320 bytes);
+//    DMA a new 1 KB of a large buffer (HBM stream), N = 2: always the same 1 KB (L2 hit), N = 3 / 4: strided pieces (16 rows x 64 bytes at a pitch of 128 / 320 bytes), N = 5: strided, always the same 2 KB;
 template <int KIND, int N>
 __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* ticks, int reps) {
     __shared__ __attribute__((aligned(16))) char smem[40960];
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* tick
                 if (KIND == 6) asm volatile("s_mov_b64 exec, -1\n\ts_mov_b64 exec, -1" ::: "memory");
             }
             if ((KIND == 8 || KIND == 9) && (j & 3) == 2) {
-                const char* src = reinterpret_cast<const char*>(out) + (N == 2 ? 0 : ((size_t)(((blockIdx.x * 4 + (threadIdx.x >> 6)) * reps + it) * 9 + (j >> 2)) * (N == 4 ? 5120 : N == 3 ? 2048 : 1024)) % (512u << 20));
+                const char* src = reinterpret_cast<const char*>(out) + ((N == 2 || N == 5) ? 0 : ((size_t)(((blockIdx.x * 4 + (threadIdx.x >> 6)) * reps + it) * 9 + (j >> 2)) * (N == 4 ? 5120 : N == 3 ? 2048 : 1024)) % (512u << 20));
                 const unsigned long long bu = (unsigned long long)(size_t)src;
                 const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bu), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bu >> 32));
                 const unsigned long long bs = ((unsigned long long)hi << 32) | lo;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* tick
                 if (KIND == 8) {
                     unsigned keep;
                     // N = 3 / 4: the piece is 16 rows of 64 bytes at a row pitch of 128 / 320 bytes (a 32-channel chunk of 64- / 160-channel pixels)
-                    const unsigned voff = N == 3 ? (unsigned)(lane >> 2) * 128u + (unsigned)(lane & 3) * 16u
+                    const unsigned voff = (N == 3 || N == 5) ? (unsigned)(lane >> 2) * 128u + (unsigned)(lane & 3) * 16u
                                         : N == 4 ? (unsigned)(lane >> 2) * 320u + (unsigned)(lane & 3) * 16u : (unsigned)lane * 16u;
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 exec, -1\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0\n\ts_mov_b64 exec, -1"
                                  : "=&s"(keep) : "s"(ldsd), "v"(voff), "s"(bs) : "memory");
@@ -99,6 +99,6 @@ int main() {
     run<5, 2>("v_cvt_pk_bf16_f32"); run<5, 4>("v_cvt_pk_bf16_f32");
     run<6, 1>("exec write pair"); run<6, 2>("exec write pair");
     run<7, 1>("1 KB global store per 8 fragments");
-    run<8, 1>("LDS-DMA 1 KB / 4 fragments, stream"); run<8, 2>("LDS-DMA 1 KB / 4 fragments, same KB"); run<8, 3>("LDS-DMA 16 rows x 64 B, pitch 128 B"); run<8, 4>("LDS-DMA 16 rows x 64 B, pitch 320 B");
+    run<8, 1>("LDS-DMA 1 KB / 4 fragments, stream"); run<8, 2>("LDS-DMA 1 KB / 4 fragments, same KB"); run<8, 3>("LDS-DMA 16 rows x 64 B, pitch 128 B"); run<8, 4>("LDS-DMA 16 rows x 64 B, pitch 320 B"); run<8, 5>("... pitch 128 B, same 2 KB (cache hit)");
     return 0;
 }
