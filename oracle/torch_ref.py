@@ -77,3 +77,82 @@ def finetune_epoch(net, W, mom, base_weight, prev_rows, support_x, support_y, qu
             pred = (net.features(qx) @ W.t()).argmax(1)
             accs.append(float((pred == qy).float().sum() * (100.0 / len(qy))))
     return float(loss.detach()), accs, mom
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Pretraining step (train_supervised.py:229-244: output = model(input); loss = criterion(output, target); loss.backward())
+# with the STORAGE ROUNDING of the bf16 HIP path emulated: every tensor that path keeps in HBM as bf16 - the packed input, the
+# raw convolution outputs, the activations, the block outputs, and in the backward the gradients with respect to exactly those
+# tensors plus the pre-activation sum of a block - is rounded to bf16 here too (round-to-nearest-even, like the kernels);
+# convolutions / BatchNorm / reductions accumulate in fp32 on both sides.  With the same rounding points a LeakyReLU / MaxPool
+# decision flips only where the two accumulation ORDERS differ by an ulp, so the HIP gradients can be gated much tighter against
+# this than against the reference's fp32 autograd (tests/test_hip_train.py).
+def _round_bf16_t(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _StoreBf16(torch.autograd.Function):
+    """A tensor stored as bf16 whose gradient is stored as bf16 too."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _round_bf16_t(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _round_bf16_t(g)
+
+
+class _GradBf16(torch.autograd.Function):
+    """A value that lives in registers in the forward (not rounded) but whose gradient is stored as bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _round_bf16_t(g)
+
+
+def train_step_grads(sd, x, labels, masks, bf16=True, n_blocks=(1, 1, 2, 2), no_dropblock=True):
+    """One train-mode forward + backward of the backbone + linear classifier on CPU.  sd: state_dict (numpy), x [B,3,H,W],
+    labels [B], masks: a MaskSource (consumed in the reference's order).  Returns (loss, {parameter name: gradient})."""
+    from .resnet_ref import DROP_RATE, dropblock_gamma
+    assert no_dropblock, "block_size 1 only (every script of the reference passes --no_dropblock)"
+    store = _StoreBf16.apply if bf16 else (lambda t: t)
+    gstore = _GradBf16.apply if bf16 else (lambda t: t)
+    P = {k: torch.from_numpy(np.ascontiguousarray(v)).clone().requires_grad_(True) for k, v in sd.items()
+         if np.asarray(v).dtype != np.int64 and "running_" not in k}
+
+    def wq(name):                                   # the packed bf16 copy the kernels multiply with; gradient goes to the fp32 master
+        w = P[name]
+        return w + (_round_bf16_t(w) - w).detach() if bf16 else w
+
+    def bn(t, p):
+        return F.batch_norm(t, None, None, P[p + ".weight"], P[p + ".bias"], True, 0.1, BN_EPS)
+
+    a = store(torch.as_tensor(x, dtype=torch.float32))
+    for s in block_specs(n_blocks):
+        n = s["name"]
+        out = store(F.leaky_relu(bn(store(F.conv2d(a, wq(n + ".conv1.weight"), padding=1)), n + ".bn1"), LEAK))
+        out = store(F.leaky_relu(bn(store(F.conv2d(out, wq(n + ".conv2.weight"), padding=1)), n + ".bn2"), LEAK))
+        out = bn(store(F.conv2d(out, wq(n + ".conv3.weight"), padding=1)), n + ".bn3")
+        res = bn(store(F.conv2d(a, wq(n + ".downsample.0.weight"))), n + ".downsample.1") if s["downsample"] else a
+        out = F.leaky_relu(gstore(out + res), LEAK)
+        if s["stride"] > 1:
+            out = F.max_pool2d(out, s["stride"])
+        B, C, H, W = out.shape
+        if s["drop_block"]:                         # DropBlock with block_size 1 (:311-325): drop with probability gamma
+            gamma = dropblock_gamma(1, H, 1)
+            keep = 1.0 - masks.bernoulli((B, C, H, W), gamma)
+            scale = keep.size / keep.sum()
+        else:
+            keep = masks.dropout_keep((B, C, H, W), DROP_RATE)
+            scale = np.float32(1.0) / np.float32(1.0 - DROP_RATE)
+        a = store(out * torch.from_numpy(keep.astype(np.float32)) * float(scale))
+    feat = a.mean(dim=(2, 3))
+    logits = feat @ P["classifier.weight"].t()
+    loss = F.cross_entropy(logits, torch.as_tensor(labels, dtype=torch.long))
+    loss.backward()
+    return float(loss.detach()), {k: v.grad.numpy() for k, v in P.items() if v.grad is not None}

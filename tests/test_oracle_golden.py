@@ -301,3 +301,34 @@ def test_torch_cpu_ref_epoch_matches_numpy_oracle_step():
     _close(Wt.numpy(), want, 1e-6, 1e-5, "W after SGD")
     acc_ref, _ = loop_ref.accuracy_top1(feat[:30] @ want.T, qy)
     assert abs(accs[0] - acc_ref) < 1e-4
+
+
+def test_torch_train_step_oracle_fp32_mode_matches_reference_autograd():
+    """oracle/torch_ref.py::train_step_grads with its bf16 storage emulation switched OFF is the reference's own computation
+    (train_supervised.py:229-244 through models/resnet_language.py:268-301): loss and every parameter gradient of the
+    reference-generated golden (tests/golden/train_step.npz, hw 32) are reproduced.  The bf16 mode (same code with rounding
+    at the HIP path's storage points) is what the GPU test gates the bf16 kernels against."""
+    from oracle import torch_ref
+    from oracle.resnet_ref import MaskSource
+    from subreg_hip import synthetic as syn
+    g = np.load(os.path.join(GOLDEN, "train_step.npz"))
+    key = "hw32"
+    loss, grads = torch_ref.train_step_grads(syn.make_state_dict(71), syn.make_images(72, int(g[key + ".B"]), 32), g[key + ".labels"],
+                                             MaskSource(74), bf16=False)
+    assert abs(loss - float(g[key + ".loss"])) < 1e-5
+    n = 0
+    for k in g.files:
+        if k.startswith(key + ".grad."):
+            name = k[len(key) + 6:]
+            want = g[k].astype(np.float64)
+            got = grads[name][:want.shape[0]].astype(np.float64)
+            assert np.linalg.norm(got - want) <= 1e-3 * max(np.linalg.norm(want), 1e-20), name
+            n += 1
+    assert n > 40
+    # the bf16 mode moves the loss by bf16-rounding noise only and keeps every gradient's direction
+    loss_b, grads_b = torch_ref.train_step_grads(syn.make_state_dict(71), syn.make_images(72, int(g[key + ".B"]), 32), g[key + ".labels"],
+                                                 MaskSource(74), bf16=True)
+    assert abs(loss_b - loss) < 2e-2
+    for name in ("classifier.weight", "layer4.1.conv3.weight", "layer1.0.conv1.weight"):
+        a, b = grads_b[name].astype(np.float64).ravel(), grads[name].astype(np.float64).ravel()
+        assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) > 0.85, name
