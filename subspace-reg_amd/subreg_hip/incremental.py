@@ -287,8 +287,7 @@ class IncrementalRunner:
         self._forward(sx, train=True, out=feats[:Bs])
         if Bm:
             self._forward(mem_x, train=True, out=feats[Bs:Bs + Bm])
-        for m in net._bns:
-            m.num_batches_tracked += 1 + (1 if Bm else 0)
+        torch._foreach_add_([m.num_batches_tracked for m in net._bns], 1 + (1 if Bm else 0))     # one launch, not one per BatchNorm
         net.eval()                                                             # validate() flips the mode for good, :19
         hb.refresh()                                                           # BN running statistics moved: fold once
         self._forward_eval(all_x[Bs + Bm:], out=feats[Bs + Bm:])
