@@ -14,9 +14,9 @@ without a launcher starts its own N ranks (a parent process that never touches t
 `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child and relays rank 0's line); under
 torchrun (RANK / WORLD_SIZE in the environment) it is a rank.
 
-After the timed region the same process group runs the 10-seed x 8-session sweep of
-scripts/continual/slurm_subspace_reg.sh:8,19-31 (BASELINE.json configs[3]; `--sweep-seeds`, 0 = skip) with
-subreg_hip.sweep.plan_sweep: one seed per rank while >= N seeds remain, then the remaining seeds shared by groups of
+After the timed region (the headline is echoed to stderr first) the 10-seed x 8-session sweep of
+scripts/continual/slurm_subspace_reg.sh:8,19-31 (BASELINE.json configs[3]; `--sweep-seeds`, 0 = skip) runs - in a child
+process at one rank, on the same process group at N ranks - with subreg_hip.sweep.plan_sweep: one seed per rank while >= N seeds remain, then the remaining seeds shared by groups of
 ranks (RCCL broadcast of the seed's backbone to its group, row-sliced forwards, one feature all-gather per forward).
 Its episodes/s is reported under "sweep" in the same line (strong scaling: the work is fixed), so that
 sweep.value at N GPUs / sweep.value at 1 GPU is the speed-up the north star's >= 6x target is about.
@@ -175,6 +175,8 @@ def self_launch(args, argv):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    # dmabuf IPC (the image exports this already): the pool's host driver has no legacy IPC handles, and without it RCCL /
+    # cross-process device-tensor sharing fails with `hipIpcGetMemHandle: invalid argument`
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
@@ -202,7 +204,7 @@ def run_sweep(args, rank, world, dev, host_only):
         torch.cuda.synchronize()
     sweep.barrier()
     t0 = time.perf_counter()
-    done = []
+    done, busy = [], 0.0        # busy: this rank's seconds inside seed runs (set-up of the synthetic backbone / inputs excluded)
     mine = [(sd, rk) for rnd in plan for sd, rk in rnd if rank in rk]
     # a real sweep reads the next seed's checkpoint while this one runs; here: its random initialisation, on a host thread
     prefetch, pool = {}, None
@@ -233,11 +235,16 @@ def run_sweep(args, rank, world, dev, host_only):
                     sweep.broadcast_module(net, ranks[0], group)   # ... a real sweep loads it on the leader only
                 meta, base = make_run_inputs(seed, dev, args.base_batch)
                 shard = sweep.RowShard(group) if group is not None else None
+                torch.cuda.synchronize()
+                t_run = time.perf_counter()
                 r = IncrementalRunner(net, meta, base, opt, None, None, None, args.epochs_per_sync or args.epochs, False,
                                       verbose=False, row_shard=shard).start()
                 for idx in range(r.iter_num):
                     r.run_session(idx)
                 r.finish()
+                torch.cuda.synchronize()
+                busy += time.perf_counter() - t_run
+                del r, net, meta, base
             if rank == ranks[0]:
                 done.append(seed)
     if not host_only:
@@ -245,12 +252,36 @@ def run_sweep(args, rank, world, dev, host_only):
         pool.shutdown(wait=False)
     sweep.barrier()
     dt = sweep.max_over_ranks(time.perf_counter() - t0, None if host_only else dev)
+    # makespan of the seed runs themselves: every rank's runs are serial and a shared seed's ranks wait for each other inside its
+    # collectives, so the slowest rank's busy time is the sweep's run time.  `value` is on that (the same quantity as the
+    # headline's timed region: runner start -> finish); the wall time incl. building each seed's synthetic backbone (kaiming
+    # init on the host, 10 BN warm-up batches) and inputs is kept as `seconds_with_setup`.
+    dt_run = dt if host_only else sweep.max_over_ranks(busy, dev)
     seen = sorted(x for r in sweep.gather_results(done) for x in r)
-    return {"workload": "%d seeds x 8 sessions (BASELINE.json configs[3])" % args.sweep_seeds, "value": args.sweep_seeds * 8 / dt,
-            "unit": "episodes/s", "seconds": dt, "scaling": "strong", "seeds_done": seen,
+    return {"workload": "%d seeds x 8 sessions (BASELINE.json configs[3])" % args.sweep_seeds, "value": args.sweep_seeds * 8 / dt_run,
+            "unit": "episodes/s", "seconds": dt_run, "seconds_with_setup": dt, "scaling": "strong", "seeds_done": seen,
             "plan": [[[sd, len(rk)] for sd, rk in rnd] for rnd in plan],
             "n_ranks_seen": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
             "model_speedup_over_1_gpu": sweep.sweep_speedup(args.sweep_seeds, world)}
+
+
+def sweep_in_child(args):
+    """One-rank sweep leg in a child process (started, never exec'ed, from this GPU-holding process), killed by PID at the deadline."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--sweep-only", "--sweep-seeds", str(args.sweep_seeds), "--epochs", str(args.epochs),
+           "--dtype", args.dtype, "--base-batch", str(args.base_batch), "--epochs-per-sync", str(args.epochs_per_sync)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    try:
+        so, se = proc.communicate(timeout=args.sweep_deadline)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        return {"error": "sweep leg did not finish within %d s" % args.sweep_deadline}
+    for ln in so.splitlines():
+        if ln.startswith("{") and '"sweep"' in ln:
+            return json.loads(ln)["sweep"]
+    return {"error": "sweep child exited with code %s: %s" % (proc.returncode, se[-400:])}
 
 
 def main():
@@ -267,6 +298,7 @@ def main():
     ap.add_argument("--sweep-seeds", type=int, default=10,
                     help="also run the S-seed x 8-session sweep (configs[3]) after the timed region; 0 = skip")
     ap.add_argument("--sweep-deadline", type=int, default=900, help="seconds after which the sweep leg is abandoned")
+    ap.add_argument("--sweep-only", action="store_true", help="(internal) run only the one-rank sweep leg and print {\"sweep\": ...}")
     ap.add_argument("--reuse-features", action="store_true",
                     help="NOT the headline: opt-in frozen-feature reuse (reported in DESIGN.md only)")
     ap.add_argument("--selftest-one-gpu", action="store_true",
@@ -308,6 +340,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)   # RCCL; the timed region uses it only for the barrier and the max-over-ranks time
 
+    if args.sweep_only:
+        assert world == 1
+        print(json.dumps({"sweep": run_sweep(args, 0, 1, dev, False)}), flush=True)
+        return
     from subreg_hip.incremental import IncrementalRunner
     seed = rank + 1                                           # one seed per GPU, like the SLURM array
     net, opt = make_net(args, seed, dev)
@@ -366,9 +402,20 @@ def main():
         "images_per_s": imgs * world / dt,
     }
     del runners, r
-    # ---- after the timed region: the 10-seed sweep on the same process group (strong scaling).  A failure or a hang of
-    #      this extra leg must not cost the headline line: rank 0 prints the line without it after a deadline.
-    if args.sweep_seeds > 0:
+    if rank == 0:                                              # the headline is on record before any extra leg starts
+        print("[bench.py headline, extra legs follow] " + json.dumps(out), file=sys.stderr, flush=True)
+    # ---- after the timed region: the 10-seed sweep (strong scaling).  This extra leg can not cost the headline line:
+    #      one rank  -> it runs in a CHILD process (its own HIP context) that is killed at the deadline; a crash or hang there
+    #                   is reported under "sweep", the parent prints the line regardless;
+    #      N ranks   -> it needs this process group, so it runs here under a deadline thread that prints the line without it.
+    if args.sweep_seeds > 0 and world == 1:
+        del net, meta, base
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        out["sweep"] = sweep_in_child(args)
+    elif args.sweep_seeds > 0:
         import threading
 
         def give_up():
@@ -386,7 +433,10 @@ def main():
         timer.cancel()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, args.base_batch)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, args.base_batch)
+            except Exception as exc:                               # noqa: BLE001 - reported in the line
+                out["cpu_baseline"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

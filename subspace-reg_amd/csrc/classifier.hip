@@ -505,8 +505,9 @@ __global__ __launch_bounds__(256) void validate_sets_kernel(const float* __restr
             // top-5 (eval/util.py:26-40 `accuracy(..., topk=(1, 5))`): the label is among the five largest logits <=> fewer than
             // five classes rank above it (strictly greater, ties towards the lower index like torch.topk)
             const int y = (int)labels[b];
-            const float ty = s_logit[y];
-            int above = 0;
+            const bool yv = y >= 0 && y < N;                 // a label that is not (yet) a classifier row is a miss, like top-1
+            const float ty = s_logit[yv ? y : 0];
+            int above = yv ? 0 : 5;
             for (int n = lane; n < N; n += 64) above += (s_logit[n] > ty || (s_logit[n] == ty && n < y)) ? 1 : 0;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) above += __shfl_xor(above, o);

@@ -190,6 +190,18 @@ class HipBackbone:
             ln["ok"].add((B, H, W))
         return ln
 
+    def release(self):
+        """Drop the workspaces, lane streams and train stash (tests / long-lived processes that are done with this backbone).
+        The next forward re-allocates what it needs."""
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self._lanes, self._ws_ok, self._cap, self._keep = [], set(), (0, 0, 0), []
+        self._ws = self._col = self._stats = None
+        self._train_stash = None
+        for i in range(4):
+            self._desc.ws[i] = None
+        self._desc.col = self._desc.stats = None
+
     # ------------------------------------------------------------------ train-mode masks
     def _prepare_masks(self, B, H, W, masks):
         """Keep masks of every block output (dropout :299 / DropBlock :311-325), uploaded as NHWC u8."""
@@ -254,6 +266,7 @@ class HipBackbone:
             chunk = -(-B // n_chunks)
         lanes = 1 if (train or return_stages) else max(1, min(int(self.EVAL_LANES), chunk // 64))
         if lanes > 1:
+            assert not train, "train-mode forwards write BN statistics: lanes carry no stats buffer (desc.stats = None)"
             # eval mode, several lanes: sub-batch i of every chunk goes to lane i (its own stream + workspaces)
             sub = -(-chunk // lanes)
             self._ensure_workspace(sub, H, W)

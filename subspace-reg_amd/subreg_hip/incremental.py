@@ -344,6 +344,12 @@ class IncrementalRunner:
             for i in range(len(hb.nbt)):            # count forwards like the reference (queued-but-stopped ones do not exist there)
                 hb.nbt[i] += ran * fwd_per_epoch - executed
         epochs = done
+        if graph is not None:
+            # the captured forward points at this session's buffers and at the lanes' side streams: destroy it explicitly, on an
+            # idle device, BEFORE those buffers can be released (not whenever the garbage collector gets to it)
+            torch.cuda.synchronize()
+            graph.reset()
+            del graph
         losses = ses.losses[:epochs].cpu().numpy().astype(np.float64)
         correct = ses.correct.view(-1, n_sets)[epochs].cpu().numpy()
         test_acc = [round(_acc(int(c), query_x[j].shape[0]), 2) for j, c in enumerate(correct)]   # :372

@@ -108,14 +108,13 @@ class GradientSync:
             for t in ([base] if key not in partly else [v.contiguous() if not v.is_contiguous() else v for v in views]):
                 self.pending.append(self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
                 self.calls += 1
-        for w in self.pending:
-            w.wait()
-        self.pending, self.covered = [], []
+        try:
+            for w in self.pending:
+                w.wait()
+        finally:                                                # never carry handles / ranges of a failed step into the next
+            self.pending, self.covered = [], []
 
     __call__ = finish
-
-
-GradientAverager = GradientSync      # (round-1 name)
 
 
 def shard_sizes(n, world):
@@ -229,6 +228,19 @@ def fit(model, opt, train_loader, val_loader=None, lang_puller=None, rank=0, wor
         sync = GradientSync(group)
         model.hip_backbone().grad_stage_hook = sync.stage_ready   # overlap the all-reduce with the backward, stage by stage
     history = []
+    try:
+        _fit_epochs(model, opt, train_loader, val_loader, lang_puller, rank, world, log, optimizer, sync, history)
+    finally:
+        if sync is not None:                                    # a backward outside fit() must not start collectives nobody waits on
+            model.hip_backbone().grad_stage_hook = None
+            sync.pending, sync.covered = [], []
+    if rank == 0:                                                                                 # :193-202
+        ck.save_checkpoint(os.path.join(opt.model_path, "{}_last.pth".format(opt.model)), model, opt=opt,
+                           **_continual_extra(opt, train_loader))
+    return history
+
+
+def _fit_epochs(model, opt, train_loader, val_loader, lang_puller, rank, world, log, optimizer, sync, history):
     for epoch in range(1, opt.epochs + 1):
         set_epoch_lr(epoch, opt, optimizer)
         rec = {"epoch": epoch, "lr": optimizer.param_groups[0]["lr"]}
@@ -245,10 +257,6 @@ def fit(model, opt, train_loader, val_loader=None, lang_puller=None, rank=0, wor
             extra = _continual_extra(opt, train_loader)
             ck.save_checkpoint(os.path.join(opt.model_path, "ckpt_epoch_{epoch}.pth".format(epoch=epoch)), model, epoch=epoch,
                                **extra)
-    if rank == 0:                                                                                 # :193-202
-        ck.save_checkpoint(os.path.join(opt.model_path, "{}_last.pth".format(opt.model)), model, opt=opt,
-                           **_continual_extra(opt, train_loader))
-    return history
 
 
 def _continual_extra(opt, train_loader):

@@ -172,6 +172,20 @@ class BackboneTrainFn(torch.autograd.Function):
         B, H, W = ctx.bhw
         dfeat = dfeat.contiguous().float()
         hook = getattr(hb, "grad_stage_hook", None)
+        # Gradients that are already there (a second backward without zero_grad(), or zero_grad(set_to_none=False)) must be
+        # ACCUMULATED into, like autograd does.  The kernels below overwrite the stash's flat buffer, and the usual `.grad` is a
+        # view of exactly that buffer: take the old values out of it BEFORE the launches.
+        flat = stash.flat_grads
+        lo_ptr, hi_ptr = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        old = {}
+        for n, p in zip(ctx.names, ctx.param_objs):
+            if p.requires_grad and p.grad is not None:
+                g = p.grad
+                old[n] = g.clone() if lo_ptr <= g.data_ptr() < hi_ptr else g
+        if old and hook is not None:
+            raise RuntimeError("subreg_hip: gradient accumulation over several backward passes is not supported together with the "
+                               "data-parallel stage hook (the flat gradient buffer is being all-reduced in place): call "
+                               "zero_grad() (set_to_none=True) before every backward")
         if hook is None:
             _lib.check(hb.lib.subreg_backbone_backward(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(dfeat), B, H, W,
                                                        _lib.stream_ptr()), "backbone_backward")
@@ -189,15 +203,14 @@ class BackboneTrainFn(torch.autograd.Function):
         # overwrites it, i.e. for the optimiser step that follows).  The views are assigned to `.grad` here, directly:
         # handing them to autograd as return values makes AccumulateGrad copy each of the 66 tensors (a returned view is never
         # "stolen"), and the optimiser would then see 66 unrelated tensors instead of one buffer it can update with one launch.
-        flat = stash.flat_grads
+        # CONTRACT: the parameter gradients do not travel through autograd's return values (all None below) - they are only
+        # visible as `p.grad` after `loss.backward()`.  torch.autograd.grad(), backward(inputs=[...]), per-tensor hooks and
+        # DDP-style reducers therefore see no backbone gradients; pretrain.GradientSync is the supported data-parallel path.
         views = {name: flat[off:off + int(np.prod(shp))].view(shp) for name, off, shp in stash.grad_views}
         for n, p in zip(ctx.names, ctx.param_objs):
             if not p.requires_grad:
                 continue
-            if p.grad is None:
-                p.grad = views[n]
-            else:
-                p.grad = p.grad + views[n]   # a second backward without zero_grad(): accumulate like autograd does
+            p.grad = views[n] if n not in old else old[n] + views[n]   # accumulate like autograd does (out of place)
         return (None, None, None, None) + (None,) * len(ctx.names)
 
 
@@ -240,6 +253,9 @@ class SGD:
         mom = self._stash_mom.get(id(hb))                      # keyed by the backbone: a new stash (another batch size) keeps its momentum
         if mom is None or mom.shape != base.shape:
             mom = self._stash_mom[id(hb)] = torch.zeros_like(base)
+            if not first:                                      # earlier steps went through the per-tensor path: keep their momentum
+                for i, p, _b in items:
+                    mom[off_of[i]:off_of[i] + p.numel()].view_as(p).copy_(self.bufs[i])
         for i, p, _b in items:                                 # momentum buffers = views of one flat buffer laid out like the gradients
             self.bufs[i] = mom[off_of[i]:off_of[i] + p.numel()].view_as(p)
         hb._bind_pointers()

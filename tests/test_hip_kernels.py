@@ -573,6 +573,25 @@ def test_validate_sets_top1_and_top5_with_ties():
         assert int(c1[3:].sum()) == 0 and int(c5[3:].sum()) == 0
 
 
+def test_validate_sets_out_of_range_label_is_a_miss():
+    """A query label that is not (yet) a row of the classifier counts as wrong for top-1 AND top-5 (it used to index the logits
+    out of range in the top-5 path)."""
+    lib = _lib.load()
+    rs = np.random.RandomState(8)
+    N, D, n = 65, 640, 40
+    f, w = rs.standard_normal((n, D)).astype(np.float32), rs.standard_normal((N, D)).astype(np.float32)
+    y = np.argmax(f @ w.T, 1).astype(np.int64)                       # every row a top-1 (and top-5) hit ...
+    y[::4] = N + 3                                                   # ... except these: labels beyond the classifier
+    y[1] = -1
+    c1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+    c5 = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.subreg_validate_sets(_lib.ptr(_t(f)), _lib.ptr(torch.from_numpy(y).cuda()), _lib.ptr(_t(w)), (C.c_int * 1)(n), 1, N, D,
+                                        None, _lib.ptr(c1), _lib.ptr(c5), 1, 0, None), "validate_sets")
+    torch.cuda.synchronize()
+    ok = int(((y >= 0) & (y < N)).sum())
+    assert int(c1[0]) == ok and int(c5[0]) == ok, (int(c1[0]), int(c5[0]), ok)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsubreg_hip.so")

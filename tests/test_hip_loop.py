@@ -243,6 +243,9 @@ def test_semantic_regularizer_module_against_reference_golden(tmp_path):
     _cmp("mapping pullers", puller(wb).cpu().numpy(), g["map.pullers0"], 1e-5, 1e-4)
 
 
+_ORACLE_351 = {}
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_fused_loop_351_base_classes_against_oracle(dtype):
     """BASELINE.json configs[4]: tieredImageNet-sized base set (351 classes, train_supervised.py:94), +M, 2 sessions x 3 epochs at
@@ -264,8 +267,10 @@ def test_fused_loop_351_base_classes_against_oracle(dtype):
         sx, sy = syn.make_base_support(seed, hw, n_base=NB, class_signal=signal)
         inits = syn.make_novel_inits(seed, ns)
         picks = [np.array([1]), np.array([3])]
-        want = loop_ref.run_incremental(ResNetRef(copy_state_dict(sd)), sessions, (bx, by), opt, inits, base_support=(sx, sy),
-                                        masks=MaskSource(77), memory_picks=picks, n_base=NB)
+        if follow not in _ORACLE_351:      # the oracle run does not depend on the HIP dtype: once per weighting, not per parameter
+            _ORACLE_351[follow] = loop_ref.run_incremental(ResNetRef(copy_state_dict(sd)), sessions, (bx, by), opt, inits,
+                                                           base_support=(sx, sy), masks=MaskSource(77), memory_picks=picks, n_base=NB)
+        want = _ORACLE_351[follow]
         net = create_model("resnet18", NB, opt, dataset="tieredImageNet")
         net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
         net = net.cuda()

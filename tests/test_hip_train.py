@@ -30,8 +30,10 @@ def _td(dtype):
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 21, 21, 64, 96, 3), (3, 10, 10, 160, 64, 1), (2, 9, 7, 32, 32, 3), (4, 5, 5, 320, 320, 3),
                                    (2, 42, 42, 160, 160, 3), (3, 84, 84, 32, 64, 1), (2, 84, 84, 64, 64, 3), (3, 10, 10, 640, 320, 1),
-                                   (1, 3, 3, 32, 32, 3), (5, 21, 10, 96, 32, 3), (64, 5, 5, 64, 64, 3)])
+                                   (1, 3, 3, 32, 32, 3), (5, 21, 10, 96, 32, 3), (64, 5, 5, 64, 64, 3), (12, 84, 84, 64, 64, 3)])
 def test_conv_wgrad_and_dgrad(shape, dtype):
+    # (the two 84x84 64 -> 64 cases send the bf16 dX convolution - dgrad-packed weights, no activation - through the persistent
+    # conv64_resident kernels: 2 images = a few tiles, 12 images = every workgroup walks several tiles)
     B, H, W, Cin, Cout, k = shape
     lib = _lib.load()
     rs = np.random.RandomState(11)
@@ -367,3 +369,70 @@ def test_fused_sgd_and_repack_equals_separate_update_and_repack():
         a, b = ba.cpu().numpy(), bb.cpu().numpy()
         _cmp("momentum buffer", a, b, 1e-5 * max(float(np.abs(b).max()), 1e-6), 1e-5)
     _cmp("features after the step", feats[0], feats[1], 2e-3 * np.abs(feats[1]).max(), 2e-3)
+
+
+def _grads_of(net, x, y, zero=True):
+    hb = net.hip_backbone()
+    hb.nbt = [0] * len(hb.nbt)                      # same DropBlock rate and ...
+    net.mask_source = MaskSource(74)                # ... the same masks for every forward of this test
+    if zero:
+        for p in net.parameters():
+            p.grad = None
+    net.train()
+    torch.nn.CrossEntropyLoss()(net(x), y).backward()
+    torch.cuda.synchronize()
+    return {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+
+
+def test_second_backward_accumulates_like_autograd():
+    """loss.backward() twice without zero_grad() must ADD the second gradient (torch autograd semantics, which
+    train_supervised.py:242-244 relies on only through zero_grad); `.grad` is a view of the stash's flat buffer, which the
+    second backward overwrites - the old values have to be taken out first.  Also zero_grad(set_to_none=False)."""
+    net = _train_net("f32")
+    rs = np.random.RandomState(3)
+    x1, x2 = (torch.from_numpy(syn.make_images(80 + i, 6, 32)).cuda() for i in range(2))
+    y1, y2 = (torch.from_numpy(rs.randint(0, 60, 6)).cuda() for _ in range(2))
+    g1 = _grads_of(net, x1, y1)
+    g2 = _grads_of(net, x2, y2)
+    _grads_of(net, x1, y1)
+    both = _grads_of(net, x2, y2, zero=False)                        # accumulate on top of g1
+    for n in g1:
+        want = (g1[n] + g2[n]).cpu().numpy()
+        _cmp("accumulated " + n, both[n].cpu().numpy(), want, 1e-5 * max(float(np.abs(want).max()), 1e-6), 1e-5)
+        assert float((g1[n] - g2[n]).abs().max()) > 0                # the two gradients really differ
+    for p in net.parameters():                                        # torch's zero_grad(set_to_none=False): zeroed IN PLACE
+        p.grad.zero_()
+    again = _grads_of(net, x2, y2, zero=False)
+    for n in g2:
+        want = g2[n].cpu().numpy()
+        _cmp("after in-place zero " + n, again[n].cpu().numpy(), want, 1e-5 * max(float(np.abs(want).max()), 1e-6), 1e-5)
+    # with the data-parallel stage hook the flat buffer is all-reduced in place: accumulation is refused loudly
+    net.hip_backbone().grad_stage_hook = lambda t: None
+    try:
+        with pytest.raises(RuntimeError, match="accumulation"):
+            _grads_of(net, x1, y1, zero=False)
+    finally:
+        net.hip_backbone().grad_stage_hook = None
+
+
+def test_fused_sgd_keeps_momentum_of_earlier_unfused_steps():
+    """A step through the per-tensor kernels (gradients not views of the stash) followed by a step through the fused
+    subreg_sgd_pack_train launch: the flat momentum buffer the fused path creates must start from the existing momentum."""
+    from subreg_hip.train import SGD
+    x = torch.from_numpy(syn.make_images(5, 6, 32)).cuda()
+    y = torch.from_numpy(np.random.RandomState(6).randint(0, 60, 6)).cuda()
+    after = []
+    for second_fused in (True, False):
+        net = _train_net("bf16")
+        opt = SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+        for step in range(2):
+            _grads_of(net, x, y)
+            if step == 0 or not second_fused:
+                for p in net.parameters():
+                    p.grad = p.grad.clone()
+            opt.step()
+        assert bool(opt._stash_mom) == second_fused
+        torch.cuda.synchronize()
+        after.append({n: p.detach().cpu().numpy() for n, p in net.named_parameters()})
+    for n in after[0]:
+        _cmp("momentum carried " + n, after[0][n], after[1][n], 1e-5 * max(float(np.abs(after[1][n]).max()), 1e-3), 1e-5)

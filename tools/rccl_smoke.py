@@ -23,6 +23,8 @@ def main():
     port = s.getsockname()[1]
     s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    # dmabuf IPC: this pool's host driver supports no legacy IPC handles - without this RCCL's buffer registration fails with
+    # `hipIpcGetMemHandle: invalid argument` (the image exports it already; kept for environments built by hand)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
