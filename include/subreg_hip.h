@@ -72,6 +72,18 @@ int subreg_conv_fwd(const void* x, const void* w, void* y, const float* scale, c
                     float* stats_partial, const void* x2, const void* w2, int Cin2, int B, int H, int W, int Cin, int Cout,
                     int ksize, int flags, int dtype, void* stream);
 int subreg_conv_stats_rows(int dtype, int B, int H, int W, int Cout);
+/* First layer without an im2col buffer (bf16, Cout = 64, eval mode): y = [lrelu](conv3x3(x_nchw, w) + shift) straight from the
+ * fp32 NCHW image of the reference's loaders (models/resnet_language.py:249-251 with the BN scale folded into w);
+ * w_packed = the mode-1 layout of subreg_pack_conv_weight.  SUBREG_EUNSUPPORTED for other dtypes / widths. */
+int subreg_conv_first_fwd(const float* x_nchw, const void* w_packed, void* y, const float* shift, int B, int H, int W, int Cout,
+                          int flags, int dtype, void* stream);
+/* conv3 of layer1.0 with its 1x1 shortcut (models/resnet_language.py:146-147,254-256,286-290) fed from the fp32 NCHW image:
+ * y = pool2(lrelu(conv3x3(x, w) + conv1x1(img, w2_first) + shift)); x [B*H*W][64] bf16, w2_first = the mode-1 packed 1x1 weights.
+ * bf16, Cin = Cout = 64, SUBREG_CONV_POOL2 required; SUBREG_EUNSUPPORTED where subreg_layer1_direct_supported says 0. */
+int subreg_conv_fwd_image_shortcut(const void* x, const void* w, void* y, const float* shift, const float* img_nchw,
+                                   const void* w2_first, int B, int H, int W, int Cin, int Cout, int flags, int dtype, void* stream);
+/* 1 if an eval-mode forward of (B, H, W) images runs layer 1 without the im2col buffer (backbone desc `col` may then be NULL) */
+int subreg_layer1_direct_supported(int B, int H, int W, int dtype);
 
 /* ---- BatchNorm2d (:148,250,253,255) -------------------------------------------------------------------- */
 /* eval: scale = weight/sqrt(running_var+eps), shift = bias - running_mean*scale */

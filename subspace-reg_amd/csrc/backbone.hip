@@ -113,14 +113,19 @@ extern "C" int subreg_backbone_pack_raw(const subreg_backbone_desc* d, void* str
 extern "C" int subreg_backbone_forward(const subreg_backbone_desc* d, const float* x_nchw, int B, int H, int W, float* feat,
                                        float* const* stage_out, int flags, void* stream) {
     SUBREG_CHECK_ARG(d && d->blocks && d->n_blocks > 0 && x_nchw && feat && B > 0 && H > 0 && W > 0);
-    SUBREG_CHECK_ARG(d->col && d->ws[0] && d->ws[1] && d->ws[2] && d->ws[3]);
+    SUBREG_CHECK_ARG(d->ws[0] && d->ws[1] && d->ws[2] && d->ws[3]);
     SUBREG_CHECK_ARG(packed_first(d));
     const bool train = flags & SUBREG_FWD_TRAIN;
     SUBREG_CHECK_ARG(!train || d->stats);
     const int dt = d->dtype;
+    // eval mode, bf16, 84x84-class images: layer 1 reads the fp32 image itself (conv_first.hip; conv3's shortcut inside
+    // conv64_resident.hip) - no im2col buffer is written or read.  Otherwise conv1 and the shortcut are K = 32 GEMMs over it.
+    const bool direct = !train && d->blocks[0].stride == 2 && d->blocks[0].down.w && d->blocks[0].conv1.cout == 64 &&
+                        subreg_layer1_direct_supported(B, H, W, dt);
+    SUBREG_CHECK_ARG(direct || d->col);
 
-    TRY(subreg_pack_input(x_nchw, d->col, B, H, W, dt, stream));
-    const void* cur = d->col;
+    if (!direct) TRY(subreg_pack_input(x_nchw, d->col, B, H, W, dt, stream));
+    const void* cur = direct ? nullptr : d->col;
     int cur_slot = -1;                 // workspace slot holding `cur` (-1: the im2col buffer)
     int h = H, w = W;
     for (int i = 0; i < d->n_blocks; ++i) {
@@ -139,15 +144,19 @@ extern "C" int subreg_backbone_forward(const subreg_backbone_desc* d, const floa
         if (!train) {
             // BN scale is folded into the packed weights; conv3 accumulates the shortcut branch (1x1 conv+BN, or the
             // identity) as a second GEMM over the block input, so no separate shortcut tensor is written or re-read
-            TRY(subreg_conv_fwd(cur, b.conv1.w_folded, A, nullptr, b.conv1.shift, nullptr, nullptr, nullptr, nullptr, 0, B, h, w,
-                                b.conv1.cin, b.conv1.cout, b.conv1.ksize, SUBREG_CONV_LRELU, dt, stream));
+            const bool img_in = direct && i == 0;
+            if (img_in) TRY(subreg_conv_first_fwd(x_nchw, b.conv1.w_folded, A, b.conv1.shift, B, h, w, b.conv1.cout, SUBREG_CONV_LRELU, dt, stream));
+            else TRY(subreg_conv_fwd(cur, b.conv1.w_folded, A, nullptr, b.conv1.shift, nullptr, nullptr, nullptr, nullptr, 0, B, h, w,
+                                     b.conv1.cin, b.conv1.cout, b.conv1.ksize, SUBREG_CONV_LRELU, dt, stream));
             TRY(subreg_conv_fwd(A, b.conv2.w_folded, Bf, nullptr, b.conv2.shift, nullptr, nullptr, nullptr, nullptr, 0, B, h, w,
                                 b.conv2.cin, b.conv2.cout, b.conv2.ksize, SUBREG_CONV_LRELU, dt, stream));
             const void* w2 = b.down.w ? b.down.w_folded : b.w_identity;
             const int cin2 = b.down.w ? b.down.cin : b.conv3.cout;
             SUBREG_CHECK_ARG(w2 != nullptr);
-            TRY(subreg_conv_fwd(Bf, b.conv3.w_folded, A, nullptr, b.shift3, nullptr, nullptr, cur, w2, cin2, B, h, w,
-                                b.conv3.cin, b.conv3.cout, b.conv3.ksize, SUBREG_CONV_LRELU | pflag, dt, stream));
+            if (img_in) TRY(subreg_conv_fwd_image_shortcut(Bf, b.conv3.w_folded, A, b.shift3, x_nchw, w2, B, h, w, b.conv3.cin,
+                                                           b.conv3.cout, SUBREG_CONV_LRELU | pflag, dt, stream));
+            else TRY(subreg_conv_fwd(Bf, b.conv3.w_folded, A, nullptr, b.shift3, nullptr, nullptr, cur, w2, cin2, B, h, w,
+                                     b.conv3.cin, b.conv3.cout, b.conv3.ksize, SUBREG_CONV_LRELU | pflag, dt, stream));
             (void)C;
             out_slot = fs[0];
         } else {

@@ -57,7 +57,8 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return 
 struct Conv64Args {
     const char* x;       // [npix][64] bf16
     const char* w;       // [9][2][64][32] bf16, BN scale folded in
-    const char* x2;      // fused shortcut GEMM: [npix][32] bf16 or null
+    const char* x2;      // fused shortcut GEMM: [npix][32] bf16 (im2col rows, k = 3 tap + c) or null
+    const float* img;    // ... or the fp32 NCHW image itself [B][3][H][W] (IMG kernels: the 1x1 shortcut reads its 3 channels)
     const char* w2;      // [64][32] bf16
     char* y;             // LINEAR [npix][64] ; POOL [B*Hp*Wp][64]
     const float* shift;  // [64]
@@ -90,8 +91,12 @@ __device__ __forceinline__ u32x4 lds_wait(u32x4 frag) {      // all but the N yo
 }
 
 // BLOCKS: image-row blocks per plane (LINEAR R + 2 = 5, POOL 2 row pairs + halo = 6)
-template <bool POOL, bool SC, int BLOCKS>
+// IMG (with SC): the shortcut's input is the fp32 NCHW image (layer1.0's downsample conv, models/resnet_language.py:146-147,286):
+// each tile's own pixels are loaded from the three channel planes, converted to bf16 and written into logical slot 0 of
+// their LDS rows ([c0 c1 c2 0 0 0 0 0]; the other slots stay zero), and the shortcut GEMM is ONE k-step - no im2col buffer.
+template <bool POOL, bool SC, int BLOCKS, bool IMG = false>
 __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const Conv64Args a) {
+    static_assert(!IMG || (SC && BLOCKS == 6), "the image-fed shortcut exists for the pooled conv3 of layer 1");
     constexpr int P = R64_P, PROWS = BLOCKS * P, PLANE = PROWS * R64_ROWB, PIECES = PROWS / 16, PPB = P / 16;
     constexpr int NPK = (PIECES + R64_NW - 1) / R64_NW;              // DMA pieces per wave and plane
     constexpr int SLAB_ROWS = POOL ? 8 : 32, SLAB_RS = 32 * 2 + 16;   // one wave's slab: rows x (32 bf16 + pad)
@@ -129,10 +134,18 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
                     bw[c][t][s] = *reinterpret_cast<const uint4*>(wl + (size_t)((t * 2 + c) * 64) * R64_ROWB + s * 32);
     }
     uint4 bw2[2];
-    if (SC) {
+    if (SC && !IMG) {
         const char* wl = a.w2 + (size_t)(32 * wh + lr) * R64_ROWB + lh * 16;
         bw2[0] = *reinterpret_cast<const uint4*>(wl);
         bw2[1] = *reinterpret_cast<const uint4*>(wl + 32);
+    }
+    if (IMG) {
+        // packed 1x1 weights of the first layer sit at k = 3 * (centre tap 4) + c = 12..14 of their row; the LDS rows carry
+        // the channels at k = 0..2, so the B fragment of the one k-step is [w12 w13 w14 0 ...] in the lanes holding k 0..7
+        const unsigned short* wr = reinterpret_cast<const unsigned short*>(a.w2 + (size_t)(32 * wh + lr) * R64_ROWB);
+        const unsigned w12 = wr[12], w13 = wr[13], w14 = wr[14];
+        bw2[0] = lh == 0 ? make_uint4(w12 | (w13 << 16), w14, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+        bw2[1] = make_uint4(0u, 0u, 0u, 0u);
     }
     // ---- LDS starts as zeros: the pad rows of every block are never written again (the DMAs mask those lanes off)
     for (int o = tid * 16; o < SLAB_BASE; o += R64_NW * 64 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
@@ -170,6 +183,28 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
                     else dma16(a.x + origin * 128 + c * 64, goff[k], dst + q * 1024);
                 }
             }
+        }
+    };
+    // IMG: thread (block ib = tid / 128 of the 4 non-halo blocks, column x = tid % 128) loads its pixel's three channels ...
+    const int ib = tid >> 7, ix = tid & 127;
+    float iv[3] = {0.f, 0.f, 0.f};
+    auto img_load = [&](int b, int h_first) {
+        const int h = h_first + 1 + ib;
+        const bool ok = ix < a.W && h >= 0 && h < a.H;
+        const size_t plane = (size_t)a.H * a.W;
+        const float* p = a.img + (size_t)b * 3 * plane + (size_t)(ok ? h : 0) * a.W + (ok ? ix : 0);
+        const float v0 = p[0], v1 = p[plane], v2 = p[2 * plane];
+        iv[0] = ok ? v0 : 0.f; iv[1] = ok ? v1 : 0.f; iv[2] = ok ? v2 : 0.f;
+    };
+    // ... and writes them (bf16, logical slot 0 of LDS row (1 + ib) P + 1 + x) once every wave is done with the shortcut plane
+    auto img_store = [&]() {
+        if (ix < a.W) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            const int row = (1 + ib) * P + 1 + ix;
+            const uint4 v = make_uint4(__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{iv[0], iv[1]}, bf16x2)),
+                                       __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{iv[2], 0.f}, bf16x2)), 0u, 0u);
+            *reinterpret_cast<uint4*>(smem + X_BASE + row * R64_ROWB + 16 * (0 ^ swz<4>(row))) = v;
         }
     };
 
@@ -215,7 +250,8 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
     tile_geom(t, b, k_img, h_first, s0);
     stage(lds_base + 0 * PLANE, 0, b, h_first);
     stage(lds_base + 1 * PLANE, 1, b, h_first);
-    if (SC) stage(lds_base + X_BASE, 2, b, h_first);
+    if (SC && !IMG) stage(lds_base + X_BASE, 2, b, h_first);
+    if (IMG) { img_load(b, h_first); img_store(); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -290,7 +326,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
         };
         if (SC) {                                                   // shortcut GEMM first: its plane is re-staged at the mid barrier
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < (IMG ? 1 : 2); ++s) {
                 const uint4 a0 = *reinterpret_cast<const uint4*>(smem + X_BASE + P * R64_ROWB + areg[0][1][s]);
                 const uint4 a1 = *reinterpret_cast<const uint4*>(smem + X_BASE + P * R64_ROWB + areg[1][1][s]);
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bw2[s]), acc[0], 0, 0, 0);
@@ -305,8 +341,10 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
         __builtin_amdgcn_sched_barrier(0);
         R64_STAMP(3);
         if (more) {
+            if (IMG) img_load(nb, nh);                              // (ordinary loads first: the compiler's wait for them must not
+                                                                    // cover the DMAs below, which are issued AFTER them)
             stage(lds_base + p0 * PLANE, 1, nb, nh);                // next tile's chunk 1 -> the plane chunk 0 just left
-            if (SC) stage(lds_base + X_BASE, 2, nb, nh);
+            if (SC && !IMG) stage(lds_base + X_BASE, 2, nb, nh);
         }
         chunk(p1, std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -370,6 +408,9 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
         else if (POOL) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         R64_STAMP(6);
+        // IMG: the next tile's shortcut pixels (loaded at the mid barrier, older than the DMAs just waited for) go to LDS now -
+        // every wave left the shortcut GEMM before the mid barrier, the next one starts behind the barrier below
+        if (IMG && more) img_store();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         R64_STAMP(7);
@@ -732,13 +773,13 @@ static int launch_r64_wide(const Conv64Args& a, hipStream_t stream) {
     return launch_status();
 }
 
-template <bool POOL, bool SC, int BLOCKS>
+template <bool POOL, bool SC, int BLOCKS, bool IMG = false>
 static int launch_r64(const Conv64Args& a, hipStream_t stream) {
     constexpr int PLANE = BLOCKS * R64_P * R64_ROWB;
     constexpr int SLAB = (POOL ? 8 : 32) * (32 * 2 + 16);
     constexpr size_t lds = 3 * (size_t)PLANE + (SC ? PLANE : 0) + R64_NW * SLAB + 256;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = conv64_resident_kernel<POOL, SC, BLOCKS>;
+    auto kern = conv64_resident_kernel<POOL, SC, BLOCKS, IMG>;
     static std::atomic<unsigned long long> lds_set{0};
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set)) return rc;
     int dev = 0, cus = 256;
@@ -753,13 +794,16 @@ static int launch_r64(const Conv64Args& a, hipStream_t stream) {
 }
 
 // Returns SUBREG_EUNSUPPORTED when the shape is not this kernel's (the caller then uses the general kernel).
+// img != null: the shortcut's input is the fp32 NCHW image (x2 must be null, w2 the packed first-layer 1x1 weights).
 int conv64_resident(const void* x, const void* w, void* y, const float* shift, const void* x2, const void* w2, int Cin2, int B,
-                    int H, int W, bool pool, int act, hipStream_t stream) {
-    if ((x2 != nullptr) != (w2 != nullptr) || (x2 && Cin2 != 32)) return SUBREG_EUNSUPPORTED;
+                    int H, int W, bool pool, int act, hipStream_t stream, const float* img) {
+    if (img && (x2 || !w2 || !pool || W > 127)) return SUBREG_EUNSUPPORTED;
+    if (!img && ((x2 != nullptr) != (w2 != nullptr) || (x2 && Cin2 != 32))) return SUBREG_EUNSUPPORTED;
     // padded row pitch 96 (and not wastefully narrow images); FastDiv ranges; 32-bit byte offsets inside a patch
     if (W + 1 > R64_P || W < 64 || H < 2 || (long long)B * H * W >= (1LL << 26)) return SUBREG_EUNSUPPORTED;
     Conv64Args a;
     a.x = (const char*)x; a.w = (const char*)w; a.x2 = (const char*)x2; a.w2 = (const char*)w2; a.y = (char*)y; a.shift = shift;
+    a.img = img;
     a.H = H; a.W = W; a.act = act;
     a.R = 0; a.Hp = H / 2; a.Wp = W / 2; a.WT = 0; a.nwin = a.Hp * a.Wp;
     a.d_w = make_fastdiv(W);
@@ -791,7 +835,24 @@ int conv64_resident(const void* x, const void* w, void* y, const float* shift, c
     a.tpi = (a.nwin + wt - 1) / wt;
     a.ntiles = B * a.tpi;
     a.d_tpi = make_fastdiv(a.tpi);
+    if (img) return launch_r64<true, true, 6, true>(a, stream);
     return x2 ? launch_r64<true, true, 6>(a, stream) : launch_r64<true, false, 6>(a, stream);
+}
+
+// the shapes for which the pooled conv3 of layer 1 can take its shortcut from the image (what the function above checks, without
+// launching): the caller decides BEFORE the forward whether it needs the im2col buffer at all
+bool conv64_image_shortcut_supported(int B, int H, int W) {
+    if (W + 1 > R64_P || W < 64 || H < 2 || (long long)B * H * W >= (1LL << 26)) return false;
+    const int Hp = H / 2, Wp = W / 2, nwin = Hp * Wp;
+    for (int cand = 64; cand >= 48; --cand) {
+        bool ok = true;
+        for (int k = 0; k * cand < nwin && ok; ++k) {
+            const int first = k * cand, last = (first + cand < nwin ? first + cand : nwin) - 1;
+            if (last / Wp - first / Wp > 1) ok = false;
+        }
+        if (ok) return true;
+    }
+    return false;
 }
 
 #if R64_DIAG

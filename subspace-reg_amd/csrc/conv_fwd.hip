@@ -701,7 +701,7 @@ static int stats_rows_for(int dtype, int M, int Cout, int W) {
 }
 
 int conv64_resident(const void* x, const void* w, void* y, const float* shift, const void* x2, const void* w2, int Cin2, int B,
-                    int H, int W, bool pool, int act, hipStream_t stream);      // conv64_resident.hip
+                    int H, int W, bool pool, int act, hipStream_t stream, const float* img = nullptr);      // conv64_resident.hip
 
 // measurement switch: SUBREG_NO_RESIDENT64=1 in the environment sends layer 1 through the general kernel (A/B runs)
 static bool resident64_enabled() {
@@ -715,6 +715,27 @@ using namespace subreg;
 
 extern "C" int subreg_conv_stats_rows(int dtype, int B, int H, int W, int Cout) {
     return stats_rows_for(dtype, B * H * W, Cout, W);
+}
+
+namespace subreg {
+bool conv64_image_shortcut_supported(int B, int H, int W);         // conv64_resident.hip
+bool conv_first_supported(int B, int H, int W);                    // conv_first.hip
+}
+
+extern "C" int subreg_layer1_direct_supported(int B, int H, int W, int dtype) {
+    static const bool on = [] { const char* e = getenv("SUBREG_IM2COL_FIRST"); return !(e && e[0] == '1'); }();   // A/B switch
+    return on && dtype == SUBREG_BF16 && resident64_enabled() && conv_first_supported(B, H, W) &&
+           conv64_image_shortcut_supported(B, H, W) ? 1 : 0;
+}
+
+extern "C" int subreg_conv_fwd_image_shortcut(const void* x, const void* w, void* y, const float* shift, const float* img_nchw,
+                                              const void* w2_first, int B, int H, int W, int Cin, int Cout, int flags, int dtype,
+                                              void* stream) {
+    SUBREG_CHECK_ARG(x && w && y && shift && img_nchw && w2_first && B > 0 && H > 0 && W > 0);
+    if (dtype != SUBREG_BF16 || Cin != 64 || Cout != 64 || !(flags & SUBREG_CONV_POOL2) || (flags & SUBREG_CONV_RAW_STATS))
+        return SUBREG_EUNSUPPORTED;
+    return conv64_resident(x, w, y, shift, nullptr, w2_first, 32, B, H, W, true, (flags & SUBREG_CONV_LRELU) ? 1 : 0,
+                           (hipStream_t)stream, img_nchw);
 }
 
 extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* shift,

@@ -142,29 +142,39 @@ class HipBackbone:
         _lib.check(self.lib.subreg_backbone_pack_raw(C.byref(self._desc), _lib.stream_ptr()), "backbone_pack_raw")
         self._fold_versions = None
 
-    def _ensure_workspace(self, B, H, W):
+    def _col_elems(self, B, H, W, need_col):
+        """Elements of the first layer's im2col buffer this forward needs: none when layer 1 reads the fp32 image itself
+        (eval mode, bf16, 84x84-class images: csrc/conv_first.hip + the image-fed shortcut of csrc/conv64_resident.hip)."""
+        if not need_col and self.lib.subreg_layer1_direct_supported(B, H, W, self.dtype):
+            return 0
+        return B * H * W * 32
+
+    def _ensure_workspace(self, B, H, W, need_col=True):
         """Workspaces for a forward of B images.  Neither size is monotone in B (the BN-partial row count follows the
         tile height the conv picks for the batch: a smaller batch can need MORE partial rows), so capacity is tracked in
-        bytes / floats as the library reports them for exactly this (B, H, W), never inferred from a larger batch."""
-        if (B, H, W) in self._ws_ok:
+        bytes / floats as the library reports them for exactly this (B, H, W), never inferred from a larger batch.
+        need_col=False: an eval-mode forward (the im2col buffer is allocated only where the direct first layer does not apply)."""
+        if (B, H, W, need_col) in self._ws_ok:
             return
         dev = self.device
         nbytes = self.lib.subreg_backbone_ws_bytes(C.byref(self._desc), B, H, W)
         nstats = self.lib.subreg_backbone_stats_floats(C.byref(self._desc), B, H, W)
-        ncol = B * H * W * 32
+        ncol = self._col_elems(B, H, W, need_col)
         assert nbytes > 0 and nstats > 0
         cap_b, cap_s, cap_c = self._cap
-        if nbytes > cap_b or nstats > cap_s or ncol > cap_c:
-            cap_b, cap_s, cap_c = max(cap_b, nbytes), max(cap_s, nstats), max(cap_c, ncol)
+        if nbytes > cap_b or nstats > cap_s:
+            cap_b, cap_s = max(cap_b, nbytes), max(cap_s, nstats)
             self._ws = [torch.empty(cap_b, dtype=torch.uint8, device=dev) for _ in range(4)]
-            self._col = torch.empty(cap_c, dtype=self.tdtype, device=dev)
             self._stats = torch.empty(cap_s, dtype=torch.float32, device=dev)
             for i in range(4):
                 self._desc.ws[i] = self._ws[i].data_ptr()
-            self._desc.col = self._col.data_ptr()
             self._desc.stats = self._stats.data_ptr()
-            self._cap = (cap_b, cap_s, cap_c)
-        self._ws_ok.add((B, H, W))
+        if ncol > cap_c:
+            cap_c = ncol
+            self._col = torch.empty(cap_c, dtype=self.tdtype, device=dev)
+            self._desc.col = self._col.data_ptr()
+        self._cap = (cap_b, cap_s, cap_c)
+        self._ws_ok.add((B, H, W, need_col))
 
     def _lane(self, i, B, H, W):
         """Descriptor of eval lane i >= 1 (lane 0 is self._desc): same packed weights, own workspaces and stream."""
@@ -176,17 +186,19 @@ class HipBackbone:
         ln["desc"].blocks, ln["desc"].n_blocks = self._desc.blocks, self._desc.n_blocks
         if (B, H, W) not in ln["ok"]:
             nbytes = self.lib.subreg_backbone_ws_bytes(C.byref(self._desc), B, H, W)
-            ncol = B * H * W * 32
+            ncol = self._col_elems(B, H, W, False)                   # lanes run eval-mode forwards only
             cb, cc = ln["cap"]
-            if nbytes > cb or ncol > cc:
-                cb, cc = max(cb, nbytes), max(cc, ncol)
+            if nbytes > cb:
+                cb = nbytes
                 ln["ws"] = [torch.empty(cb, dtype=torch.uint8, device=self.device) for _ in range(4)]
-                ln["col"] = torch.empty(cc, dtype=self.tdtype, device=self.device)
                 for k in range(4):
                     ln["desc"].ws[k] = ln["ws"][k].data_ptr()
+            if ncol > cc:
+                cc = ncol
+                ln["col"] = torch.empty(cc, dtype=self.tdtype, device=self.device)
                 ln["desc"].col = ln["col"].data_ptr()
-                ln["desc"].stats = None
-                ln["cap"] = (cb, cc)
+            ln["desc"].stats = None
+            ln["cap"] = (cb, cc)
             ln["ok"].add((B, H, W))
         return ln
 
@@ -269,7 +281,7 @@ class HipBackbone:
             assert not train, "train-mode forwards write BN statistics: lanes carry no stats buffer (desc.stats = None)"
             # eval mode, several lanes: sub-batch i of every chunk goes to lane i (its own stream + workspaces)
             sub = -(-chunk // lanes)
-            self._ensure_workspace(sub, H, W)
+            self._ensure_workspace(sub, H, W, need_col=False)
             cur = torch.cuda.current_stream()
             extra = [self._lane(i, sub, H, W) for i in range(1, lanes)]
             for ln in extra:
@@ -288,7 +300,7 @@ class HipBackbone:
             for ln in extra:
                 cur.wait_stream(ln["stream"])                       # join
             return feat
-        self._ensure_workspace(chunk, H, W)
+        self._ensure_workspace(chunk, H, W, need_col=train)
         s = _lib.stream_ptr()
         if train:
             self._prepare_masks(B, H, W, masks)

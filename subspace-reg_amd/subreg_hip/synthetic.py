@@ -80,11 +80,25 @@ def session_labels(s, n_ways=5, n_shots=5, n_aug=5, n_queries=25, first_novel=60
     return support_ys.astype(np.int64), query_ys.astype(np.int64)
 
 
-def make_sessions(seed, n_sessions, hw=84, class_signal=0.0, first_novel=60):
+def class_prototype(c, hw, grid=0):
+    """Seeded mean image of class c.  grid = 0: white noise (every pixel independent); grid = g > 0: a g x g checker of
+    constant cells per channel - low-frequency content that survives a randomly initialised backbone's pooling stages, so
+    that classes are separable in FEATURE space (white-noise prototypes mostly average out)."""
+    rs = np.random.RandomState(777000 + int(c))
+    if not grid:
+        return rs.standard_normal((3, hw, hw)).astype(np.float32)
+    cell = -(-hw // grid)
+    return np.kron(rs.standard_normal((3, grid, grid)).astype(np.float32), np.ones((cell, cell), np.float32))[:, :hw, :hw]
+
+
+def make_sessions(seed, n_sessions, hw=84, class_signal=0.0, first_novel=60, proto_grid=0, hard_queries=0):
     """Episodes for `n_sessions` incremental sessions.
 
     class_signal > 0 adds a seeded per-class mean image so that accuracies are not
     all at chance (useful for the loop goldens; pure noise gives ~0 % novel accuracy).
+    hard_queries = h > 0: the LAST h query images of every class carry the prototype of the session's next class
+    (cyclically) under their own label - examples a correct classifier gets wrong by a wide margin, which caps the query
+    accuracy at (25 - h) / 25 without putting any image near a decision boundary.
     """
     sessions = []
     for s in range(n_sessions):
@@ -92,33 +106,36 @@ def make_sessions(seed, n_sessions, hw=84, class_signal=0.0, first_novel=60):
         sx = make_images(seed * 1000 + 2 * s, len(sy), hw)
         qx = make_images(seed * 1000 + 2 * s + 1, len(qy), hw)
         if class_signal:
-            for c in np.unique(sy):
-                proto = np.random.RandomState(777000 + int(c)).standard_normal((3, hw, hw)).astype(np.float32)
+            cls = np.unique(sy)
+            for i, c in enumerate(cls):
+                proto = class_prototype(c, hw, proto_grid)
                 sx[sy == c] += class_signal * proto
-                qx[qy == c] += class_signal * proto
+                rows = np.nonzero(qy == c)[0]
+                own = rows[:len(rows) - hard_queries] if hard_queries else rows
+                qx[own] += class_signal * proto
+                if hard_queries:
+                    qx[rows[len(rows) - hard_queries:]] += class_signal * class_prototype(cls[(i + 1) % len(cls)], hw, proto_grid)
         sessions.append(dict(support_xs=sx, support_ys=sy, query_xs=qx, query_ys=qy))
     return sessions
 
 
-def make_base_batch(seed, n, hw=84, n_base=60, class_signal=0.0):
+def make_base_batch(seed, n, hw=84, n_base=60, class_signal=0.0, proto_grid=0):
     rs = np.random.RandomState(seed + 500000)
     y = rs.randint(0, n_base, n).astype(np.int64)
     x = make_images(seed + 600000, n, hw)
     if class_signal:
         for c in np.unique(y):
-            proto = np.random.RandomState(777000 + int(c)).standard_normal((3, hw, hw)).astype(np.float32)
-            x[y == c] += class_signal * proto
+            x[y == c] += class_signal * class_prototype(c, hw, proto_grid)
     return x, y
 
 
-def make_base_support(seed, hw=84, n_base=60, class_signal=0.0):
+def make_base_support(seed, hw=84, n_base=60, class_signal=0.0, proto_grid=0):
     """One exemplar per base class (--n_base_support_samples 1)."""
     y = np.arange(n_base, dtype=np.int64)
     x = make_images(seed + 700000, n_base, hw)
     if class_signal:
         for c in y:
-            proto = np.random.RandomState(777000 + int(c)).standard_normal((3, hw, hw)).astype(np.float32)
-            x[c] += class_signal * proto
+            x[c] += class_signal * class_prototype(c, hw, proto_grid)
     return x, y
 
 

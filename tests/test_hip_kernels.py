@@ -132,6 +132,87 @@ def test_conv_fwd_epilogue(case, dtype):
     _cmp("conv", got, rr._nchw(want), a, r)
 
 
+def _pack_w_first(w_oihw, fold=None):
+    """mode-1 layout of subreg_pack_conv_weight: [Cout][32] bf16, k = 3 tap + c (3x3) or k = 12 + c (the 1x1 shortcut)."""
+    lib = _lib.load()
+    O, I, k, _ = w_oihw.shape
+    out = torch.empty(O * 32, dtype=torch.bfloat16, device=_dev())
+    fd = _t(fold) if fold is not None else None
+    _lib.check(lib.subreg_pack_conv_weight(_lib.ptr(_t(w_oihw)), _lib.ptr(fd), _lib.ptr(out), O, I, k, 1, _lib.BF16, _lib.stream_ptr()))
+    return out
+
+
+@pytest.mark.parametrize("shape", [(3, 84, 84), (70, 84, 84), (2, 32, 32), (5, 21, 10), (1, 9, 77), (2, 13, 200), (1, 1, 8)])
+def test_conv_first_direct_from_the_fp32_image(shape):
+    """conv1 of layer1.0 (models/resnet_language.py:249-251: conv3x3(3 -> 64) + eval BN + LeakyReLU) straight from the NCHW fp32
+    image, no im2col buffer (csrc/conv_first.hip), against the oracle on the same bf16-rounded operands: whole images rows per
+    tile with a short last tile (13 rows), one-row images, W below and above one 128-pixel wave stride, grid-stride tiles (70)."""
+    B, H, W = shape
+    lib = _lib.load()
+    rs = np.random.RandomState(B * 1000 + H + W)
+    x = rs.standard_normal((B, 3, H, W)).astype(np.float32)
+    w = (rs.standard_normal((64, 3, 3, 3)) * (1.4 / np.sqrt(27))).astype(np.float32)
+    scale = rs.uniform(0.5, 1.5, 64).astype(np.float32) * rs.choice([-1, 1], 64).astype(np.float32)
+    shift = (rs.standard_normal(64) * 0.3).astype(np.float32)
+    wd = _pack_w_first(w, scale)
+    wq = _round_bf16(w * scale[:, None, None, None])                    # what the kernel multiplies with
+    want = rr.leaky_relu(rr.conv_nhwc(rr._nhwc(_round_bf16(x)).astype(np.float64), wq.astype(np.float64)) + shift)
+    y = torch.full((B * H * W * 64,), float("nan"), dtype=torch.bfloat16, device=_dev())
+    xd, shd = _t(x), _t(shift)
+    _lib.check(lib.subreg_conv_first_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), _lib.ptr(shd), B, H, W, 64, _lib.CONV_LRELU,
+                                         _lib.BF16, _lib.stream_ptr()), "conv_first_fwd")
+    got = _nchw_host(y, B, 64, H, W, "bf16")
+    a, r = _tol("bf16", np.abs(want).max())
+    _cmp("conv_first", got, rr._nchw(want), a, r)
+    # without the activation flag
+    _lib.check(lib.subreg_conv_first_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), _lib.ptr(shd), B, H, W, 64, 0, _lib.BF16,
+                                         _lib.stream_ptr()), "conv_first_fwd")
+    want0 = rr.conv_nhwc(rr._nhwc(_round_bf16(x)).astype(np.float64), wq.astype(np.float64)) + shift
+    _cmp("conv_first (no act)", _nchw_host(y, B, 64, H, W, "bf16"), rr._nchw(want0), a, r)
+    # the entry refuses what it does not implement instead of computing something else
+    assert lib.subreg_conv_first_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), _lib.ptr(shd), B, H, W, 64, 0, _lib.F32, _lib.stream_ptr()) != 0
+    assert lib.subreg_conv_first_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), _lib.ptr(shd), B, H, W, 160, 0, _lib.BF16, _lib.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("shape", [(2, 84, 84), (37, 84, 84), (3, 85, 84), (2, 20, 94)])
+def test_layer1_conv3_with_the_shortcut_fed_from_the_image(shape):
+    """conv3 of layer1.0 with its 1x1 shortcut conv (models/resnet_language.py:146-147,254-256,286-290) reading the fp32 image
+    directly (conv64_resident.hip IMG kernels) against the oracle, and against the im2col route of subreg_conv_fwd it replaces:
+    odd sizes (floor pooling drops the last row / column), several tiles per workgroup (37 images)."""
+    B, H, W = shape
+    lib = _lib.load()
+    assert lib.subreg_layer1_direct_supported(B, H, W, _lib.BF16) == 1 and lib.subreg_layer1_direct_supported(B, H, W, _lib.F32) == 0
+    assert lib.subreg_layer1_direct_supported(B, 32, 32, _lib.BF16) == 0          # 32x32 goldens keep the general kernels
+    assert lib.subreg_layer1_direct_supported(B, 64, 70, _lib.BF16) == 0          # no 48..64-window tiling of 35-window rows
+    rs = np.random.RandomState(B + H + W)
+    img = rs.standard_normal((B, 3, H, W)).astype(np.float32)
+    x = _round_bf16(rs.standard_normal((B, 64, H, W)).astype(np.float32))
+    w = _round_bf16((rs.standard_normal((64, 64, 3, 3)) * (1.4 / np.sqrt(576))).astype(np.float32))
+    w2 = (rs.standard_normal((64, 3, 1, 1)) * 0.6).astype(np.float32)
+    shift = (rs.standard_normal(64) * 0.3).astype(np.float32)
+    want = rr.conv_nhwc(rr._nhwc(x).astype(np.float64), w.astype(np.float64)) + \
+        rr.conv_nhwc(rr._nhwc(_round_bf16(img)).astype(np.float64), _round_bf16(w2).astype(np.float64)) + shift
+    want = rr.maxpool_nhwc(rr.leaky_relu(want), 2)
+    Ho, Wo = H // 2, W // 2
+    xd, wd, w2d, shd, imgd = _nhwc_dev(x, "bf16"), _pack_w(w, "bf16"), _pack_w_first(w2), _t(shift), _t(img)
+    y = torch.full((B * Ho * Wo * 64,), float("nan"), dtype=torch.bfloat16, device=_dev())
+    flags = _lib.CONV_LRELU | _lib.CONV_POOL2
+    _lib.check(lib.subreg_conv_fwd_image_shortcut(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), _lib.ptr(shd), _lib.ptr(imgd), _lib.ptr(w2d),
+                                                  B, H, W, 64, 64, flags, _lib.BF16, _lib.stream_ptr()), "conv_fwd_image_shortcut")
+    got = _nchw_host(y, B, 64, Ho, Wo, "bf16")
+    a, r = _tol("bf16", np.abs(want).max())
+    _cmp("conv3 + image shortcut", got, rr._nchw(want), a, r)
+    # the route it replaces: im2col rows + the K = 32 shortcut GEMM
+    col = torch.empty(B * H * W * 32, dtype=torch.bfloat16, device=_dev())
+    _lib.check(lib.subreg_pack_input(_lib.ptr(imgd), _lib.ptr(col), B, H, W, _lib.BF16, _lib.stream_ptr()))
+    y2 = torch.full_like(y, float("nan"))
+    _lib.check(lib.subreg_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y2), None, _lib.ptr(shd), None, None, _lib.ptr(col), _lib.ptr(w2d),
+                                   32, B, H, W, 64, 64, 3, flags, _lib.BF16, _lib.stream_ptr()), "conv_fwd")
+    torch.cuda.synchronize()
+    d = (y.float() - y2.float()).abs().max().item()
+    assert d <= 2.0 ** -7 * float(np.abs(want).max()), d            # same products, another accumulation order: <= 1 bf16 ulp
+
+
 FUSED_CASES = [
     # B, H, W, Cin, Cout, Cin2 (0 = identity shortcut), pool      conv3 of every block type with its fused shortcut GEMM
     (2, 84, 84, 64, 64, 32, True),       # layer1.0: shortcut = 1x1 conv over the K=32 im2col rows
@@ -585,7 +666,8 @@ def test_validate_sets_out_of_range_label_is_a_miss():
     y[1] = -1
     c1 = torch.zeros(1, dtype=torch.int32, device="cuda")
     c5 = torch.zeros(1, dtype=torch.int32, device="cuda")
-    _lib.check(lib.subreg_validate_sets(_lib.ptr(_t(f)), _lib.ptr(torch.from_numpy(y).cuda()), _lib.ptr(_t(w)), (C.c_int * 1)(n), 1, N, D,
+    ft, yt, wt = _t(f), torch.from_numpy(y).cuda(), _t(w)            # (keep the device buffers alive across the launch)
+    _lib.check(lib.subreg_validate_sets(_lib.ptr(ft), _lib.ptr(yt), _lib.ptr(wt), (C.c_int * 1)(n), 1, N, D,
                                         None, _lib.ptr(c1), _lib.ptr(c5), 1, 0, None), "validate_sets")
     torch.cuda.synchronize()
     ok = int(((y >= 0) & (y < N)).sum())

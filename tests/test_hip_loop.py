@@ -71,13 +71,17 @@ def build_case(g, dtype, embed_dir=None):
     for k in g.files:
         if k.startswith("bn0."):
             sd[k[4:]] = g[k].copy()
+        if k.startswith("param."):                   # backbone parameters the generator calibrated (tools/make_golden.py::centre_features)
+            sd[k[6:]] = g[k].copy()
     sd["classifier.weight"] = g["base_classifier"].copy()
     net = create_model("resnet18", 60, opt)
     net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     net = net.cuda()
     net.mask_source = MaskSource(int(g["mask_seed"]))
-    sessions = syn.make_sessions(seed, ns, hw, class_signal=signal)
-    bx, by = syn.make_base_batch(seed, int(g["n_base_batch"]), hw, class_signal=signal)
+    pg = int(g["proto_grid"]) if "proto_grid" in g.files else 0
+    hq = int(g["hard_queries"]) if "hard_queries" in g.files else 0
+    sessions = syn.make_sessions(seed, ns, hw, class_signal=signal, proto_grid=pg, hard_queries=hq)
+    bx, by = syn.make_base_batch(seed, int(g["n_base_batch"]), hw, class_signal=signal, proto_grid=pg)
     names_base = ["b%d" % i for i in range(60)] + [""] * 40
     names_novel = ["n%d" % i for i in range(100)]
     if "names_base" in g.files:
@@ -88,7 +92,7 @@ def build_case(g, dtype, embed_dir=None):
                    names_novel)
     bsl = None
     if memory:
-        sx, sy = syn.make_base_support(seed, hw, class_signal=signal)
+        sx, sy = syn.make_base_support(seed, hw, class_signal=signal, proto_grid=pg)
         bsl = _Loader([(torch.from_numpy(sx)[None], torch.from_numpy(sy)[None], torch.zeros(1, 1, 3, hw, hw),
                         torch.zeros(1, 1, dtype=torch.long))], names_base)
     inits = syn.make_novel_inits(seed, ns)
@@ -97,11 +101,16 @@ def build_case(g, dtype, embed_dir=None):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw84_M", "hw32_sem", "hw32_map", "hw84_noM_s8"])
+@pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw84_M", "hw32_sem", "hw32_map", "hw84_noM_s8", "hw84_noM_disc",
+                                 "hw84_stop"])
 def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
     """hw84_noM_s8 is the bench-scale case (BASELINE.json configs[1]: 8 sessions, -M, 84x84, 1000-image base batch) with 6
     epochs per session, so the per-epoch hipGraph is captured and replayed and up to 1125 images go through one launch
-    sequence - the code path bench.py times."""
+    sequence - the code path bench.py times.
+    hw84_noM_disc / hw84_stop are the DISCRIMINATING 84x84 goldens (tools/make_golden.py loop84d): 30 epochs x 2 sessions and a
+    run that ends on the stable-epochs rule (language_eval.py:298-318) at epoch 48 of 80; their session accuracies sit at
+    58-80 % and the base accuracy falls 95 -> 40 -> 20 %, with the wrong answers wrong by construction (hard_queries), so the
+    bf16 gate on them is ONE query image."""
     from subreg_hip.incremental import few_shot_finetune_incremental_test
     g = np.load(os.path.join(GOLDEN, "loop_%s.npz" % tag))
     net, opt, meta, base_loader, bsl, inits, picks = build_case(g, dtype, str(tmp_path / "word_embeds"))
@@ -115,7 +124,8 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
     run = net.last_run
     ns = int(g["n_sessions"])
     f32 = dtype == "f32"
-    data_dependent_stop = tag == "hw32_stop"          # every other golden runs a fixed number of epochs (max_novel_epochs)
+    data_dependent_stop = tag in ("hw32_stop", "hw84_stop")   # every other golden runs a fixed number of epochs (max_novel_epochs)
+    discriminating = "hard_queries" in g.files        # accuracies far from chance, no image near a decision boundary
     one_image = 100.0 / 125 + 1e-6                    # one query image of a 125-image set, in accuracy points
     for s in range(ns):
         want_e = int(g["s%d.epochs" % s])
@@ -137,12 +147,19 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
         # accuracy: within 2 query images per 125-image set.  These short goldens sit near chance level, where many
         # argmaxes are near-ties between freshly initialised novel rows; bf16 activations (8-bit mantissa, ~3e-3 relative
         # on the features) flip up to two of them (measured: 28.0 vs 26.4 on hw32_sem), which no kernel change can avoid
-        _cmp("val acc s%d" % s, run["test_acc"][s], want_acc, (2 if same else 3) * one_image, 0)
+        _cmp("val acc s%d" % s, run["test_acc"][s], want_acc, (1 if discriminating else (2 if same else 3)) * one_image, 0)
     if f32 or not data_dependent_stop:
         _cmp("final classifier", run["classifier_weight"], g["final_classifier"], 1e-4 if f32 else 5e-3, 1e-4 if f32 else 5e-3)
     if int(g["hw"]) == 84 and int(g["opt.max_novel_epochs"]) > 5:
         # the per-epoch forward was replayed as a hipGraph from epoch 3 on, in every session
-        assert all(r == int(g["opt.max_novel_epochs"]) - 2 for r in run["graph_replays"]), run["graph_replays"]
+        assert all(r >= e - 2 for r, e in zip(run["graph_replays"], run["epochs"])), (run["graph_replays"], run["epochs"])
+        if not data_dependent_stop:
+            assert all(r == int(g["opt.max_novel_epochs"]) - 2 for r in run["graph_replays"]), run["graph_replays"]
+    if "acc_base_sessions" in g.files:
+        # eval_base after every session (language_eval.py:363-367): fp32 exact, bf16 within two of the base batch's images
+        want_b = np.round(g["acc_base_sessions"][1:], 2)
+        assert (want_b > 0).all() or not discriminating
+        _cmp("base acc per session", run["acc_base"], want_b, 1e-6 if f32 else 200.0 / int(g["n_base_batch"]) + 1e-6, 0)
     if f32:
         _cmp("novel avg", novel_avg, g["novel_avg"], 1e-5, 1e-6)
         _cmp("base avg", base_avg, g["base_avg"], 1e-5, 1e-6)

@@ -187,3 +187,23 @@ def test_rccl_single_rank_collectives_on_device():
     p = subprocess.run([sys.executable, os.path.join(repo, "tools", "rccl_smoke.py")], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "-> OK" in p.stdout and "backend nccl" in p.stdout
+
+
+@pytest.mark.gpu
+def test_row_sharded_sweep_path_two_ranks_on_device():
+    """Level 2 of the 10-seed sweep (BASELINE.json configs[3]; scripts/continual/slurm_subspace_reg.sh:8,19-31 shards whole seeds,
+    the build also shares the last seeds among idle GPUs): IncrementalRunner(row_shard=RowShard()) with TWO processes on the
+    device - rank 1 starts from a perturbed backbone that the group broadcast must repair, every eval-mode forward is cut into
+    two row slices (hipGraph-replayed), the [rows, 640] features are all-gathered, the train-mode forward / classifier step /
+    validation run redundantly - and the result must equal the single-process run BIT FOR BIT (losses, accuracies, classifier
+    rows; tools/dp_check.py).  The pool's boxes have one GPU, so both ranks share cuda:0 and the collectives go over gloo
+    (host-staged); with one GPU per rank the same code gathers device to device over RCCL."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(repo, "tools", "dp_check.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "single-process run: True" in p.stdout
+    done, total = [int(x) for x in p.stdout.split("rank 0:")[1].split(")")[0].replace("of", " ").split()]
+    assert 0 < done < total                                    # rank 0 really forwarded only its share of the images

@@ -86,6 +86,41 @@ def main():
         tot_t += us * count
         tot_f += flops * count
         print("%-24s M=%8d K=%5d N=%4d  %8.1f us  %7.1f TFLOP/s  %5.1f%% of peak" % (name, mrows, Cin * k * k, Cout, us, tf, 100 * tf / peak))
+    # layer 1 without the im2col buffer: conv1 from the fp32 NCHW image (conv_first.hip), conv3's shortcut from the image
+    # (conv64_resident.hip IMG kernels); these replace the two "L1" lines marked im2col / ds above plus the pack_input launch
+    if a.dtype == "bf16" and (not a.only or "L1" in a.only):
+        H = 84
+        npix = B * H * H
+        img = torch.randn(B, 3, H, H, device=dev)
+        w1 = (torch.randn(64, 32, device=dev) / 27 ** 0.5).to(td)
+        shift = torch.randn(64, device=dev)
+        y1 = torch.empty(npix, 64, device=dev, dtype=td)
+        col = torch.empty(npix, 32, device=dev, dtype=td)
+        x3 = torch.randn(npix, 64, device=dev).to(td)
+        w3 = (torch.randn(64, 9, 64, device=dev) / 576 ** 0.5).to(td)
+        y3 = torch.empty(B * 42 * 42, 64, device=dev, dtype=td)
+        fl = _lib.CONV_LRELU
+
+        def t_of(fn, iters=a.iters):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / iters
+        s = _lib.stream_ptr
+        us_pack = t_of(lambda: _lib.check(lib.subreg_pack_input(_lib.ptr(img), _lib.ptr(col), B, H, H, dt, s())))
+        us_c1 = t_of(lambda: _lib.check(lib.subreg_conv_first_fwd(_lib.ptr(img), _lib.ptr(w1), _lib.ptr(y1), _lib.ptr(shift), B, H, H, 64, fl, dt, s())))
+        us_c3 = t_of(lambda: _lib.check(lib.subreg_conv_fwd_image_shortcut(_lib.ptr(x3), _lib.ptr(w3), _lib.ptr(y3), _lib.ptr(shift), _lib.ptr(img),
+                                                                           _lib.ptr(w1), B, H, H, 64, 64, fl | _lib.CONV_POOL2, dt, s())))
+        byt1 = npix * (12 + 128)
+        print("pack_input (im2col route only)            %8.1f us  %6.2f TB/s (12 B read + 64 B written per pixel)" % (us_pack, npix * 76 / us_pack * 1e-6))
+        print("L1.conv1 direct from the fp32 image       %8.1f us  %6.2f TB/s algorithmic (140 B per pixel), %5.1f TFLOP/s" %
+              (us_c1, byt1 / us_c1 * 1e-6, 2.0 * npix * 64 * 27 / us_c1 * 1e-6))
+        print("L1.conv3+ds(image)+pool                   %8.1f us  %7.1f TFLOP/s" % (us_c3, (2.0 * npix * 64 * 576 + 2.0 * npix * 64 * 3) / us_c3 * 1e-6))
     if not a.only:
         print("conv stack, B=%d: %.1f us, %.1f TFLOP/s algorithmic (%.1f%% of %s peak)" % (B, tot_t, tot_f / tot_t * 1e-6, 100 * tot_f / tot_t * 1e-6 / peak, a.dtype))
 

@@ -221,10 +221,10 @@ class _Loader(list):
         self.dataset = SimpleNamespace(label2human=label2human)
 
 
-def calibrate_bn(net, hw, signal):
+def calibrate_bn(net, hw, signal, proto_grid=0):
     """One train-mode pass (momentum 1.0, no dropping) so the running stats match the synthetic data."""
     from oracle.resnet_ref import OnesMaskSource
-    x, _ = syn.make_base_batch(99, 64, hw, class_signal=signal)
+    x, _ = syn.make_base_batch(99, 64, hw, class_signal=signal, proto_grid=proto_grid)
     bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
     for m in bns:
         m.momentum = 1.0
@@ -241,13 +241,36 @@ def calibrate_bn(net, hw, signal):
     net.eval()
 
 
-def ncm_classifier(net, hw, signal, per_class=8):
+def centre_features(net, hw, signal, proto_grid, iters=8):
+    """Make the backbone's output features zero-mean per channel on the synthetic data by calibrating layer4.1.bn3.bias
+    (Newton steps through the monotone LeakyReLU + average pool).  A randomly initialised backbone's post-activation features
+    are dominated by one common direction (|mean| ~ 7 x the class-specific part), which turns the fine-tuning dynamics into a
+    race along that direction: every old class is forgotten completely within ~15 epochs and accuracies sit at 0 / 100 %.
+    With centred features the synthetic episodes behave like the paper's: novel classes are learned, base accuracy decays
+    slowly.  The calibrated bias is part of the fixture (`param.layer4.1.bn3.bias`)."""
+    x, _ = syn.make_base_batch(98, 64, hw, class_signal=signal, proto_grid=proto_grid)
+    xt = torch.from_numpy(x)
+    bn = net.layer4[1].bn3
+    net.eval()
+    with torch.no_grad():
+        for it in range(iters):
+            f, _ = net(xt, is_feat=True)
+            m = f[-1].mean(0)
+            bn.bias -= m / 0.55                                   # slope of LeakyReLU(0.1) averaged over positions ~ 0.55
+        f, _ = net(xt, is_feat=True)
+        print("centred features: |mean| %.4f, mean |f| %.3f" % (float(f[-1].mean(0).norm()), float(f[-1].norm(dim=1).mean())))
+    for blk in net.modules():
+        if isinstance(blk, rl.BasicBlock):
+            blk.num_batches_tracked = 0
+
+
+def ncm_classifier(net, hw, signal, per_class=8, proto_grid=0, norm=0.5):
     """Base classifier rows = nearest-class-mean directions of noisy class samples, centred and made
     orthogonal to the global mean feature (there is no bias), scaled to norm 0.5."""
     ys = np.repeat(np.arange(60), per_class)
     xs = syn.make_images(4242, len(ys), hw)
     for c in range(60):
-        xs[ys == c] += signal * np.random.RandomState(777000 + c).standard_normal((3, hw, hw)).astype(np.float32)
+        xs[ys == c] += signal * syn.class_prototype(c, hw, proto_grid)
     net.eval()
     with torch.no_grad():
         f, _ = net(torch.from_numpy(xs), is_feat=True)
@@ -256,7 +279,7 @@ def ncm_classifier(net, hw, signal, per_class=8):
     w = np.stack([f[ys == c].mean(0) for c in range(60)]) - g
     gh = g / np.linalg.norm(g)
     w = w - (w @ gh)[:, None] * gh[None, :]
-    w = 0.5 * w / np.linalg.norm(w, axis=1, keepdims=True)
+    w = norm * w / np.linalg.norm(w, axis=1, keepdims=True)
     # the centred class means sum to zero (rank 59); a real base classifier has full rank and torch.qr has no
     # rank handling (its last basis vector would be rounding noise), so add a small seeded full-rank component
     w = w + 0.004 * np.random.RandomState(31337).standard_normal(w.shape)
@@ -331,18 +354,22 @@ def gen_semantic():
     print("semantic.npz", sum(v.nbytes for v in out.values()) / 1e6, "MB")
 
 
-def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False, mapping_seed=None, **optkw):
+def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False, mapping_seed=None, signal=3.0, proto_grid=0,
+             hard_queries=0, centre=False, base_norm=0.5, **optkw):
     opt = ref_opt(set_seed=seed, neval_episodes=n_sessions, memory_replay=1 if memory else 0, **optkw)
-    signal = 3.0
     sd = syn.make_state_dict(21 + seed)
     net = ref_net(sd, opt)
-    calibrate_bn(net, hw, signal)
-    wcls = ncm_classifier(net, hw, signal)
+    calibrate_bn(net, hw, signal, proto_grid)
+    params0 = {}
+    if centre:
+        centre_features(net, hw, signal, proto_grid)
+        params0["layer4.1.bn3.bias"] = t2n(net.layer4[1].bn3.bias)
+    wcls = ncm_classifier(net, hw, signal, proto_grid=proto_grid, norm=base_norm)
     bn0 = {k: t2n(v) for k, v in net.state_dict().items() if "running_" in k}
     with torch.no_grad():
         net.classifier.weight.copy_(torch.from_numpy(wcls))
-    sessions = syn.make_sessions(seed, n_sessions, hw, class_signal=signal)
-    base_x, base_y = syn.make_base_batch(seed, n_base_batch, hw, class_signal=signal)
+    sessions = syn.make_sessions(seed, n_sessions, hw, class_signal=signal, proto_grid=proto_grid, hard_queries=hard_queries)
+    base_x, base_y = syn.make_base_batch(seed, n_base_batch, hw, class_signal=signal, proto_grid=proto_grid)
     inits = syn.make_novel_inits(seed, n_sessions)
     names_base = ["b%d" % i for i in range(60)] + [""] * 40
     names_novel = ["n%d" % i for i in range(100)]
@@ -358,11 +385,11 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False
                    names_novel)
     bsl = None
     if memory:
-        bx, by = syn.make_base_support(seed, hw, class_signal=signal)
+        bx, by = syn.make_base_support(seed, hw, class_signal=signal, proto_grid=proto_grid)
         bsl = _Loader([(torch.from_numpy(bx)[None], torch.from_numpy(by)[None],
                         torch.zeros(1, 1, 3, hw, hw), torch.zeros(1, 1, dtype=torch.long))], names_base)
     # explicit init rows through the reference's own novel_weight= argument; one call == one session start
-    rec = dict(loss=[], val=[], picks=[])
+    rec = dict(loss=[], val=[], picks=[], base=[])
     counter = {"i": 0}
     orig_aug = net.augment_base_classifier_
 
@@ -374,7 +401,12 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False
         return r
     net.augment_base_classifier_ = aug
     # record per-epoch losses (at loss.backward()), per-epoch validation accuracies, memory picks
-    orig_validate, orig_choice, orig_backward = le.validate, np.random.choice, torch.Tensor.backward
+    orig_validate, orig_choice, orig_backward, orig_eval_base = le.validate, np.random.choice, torch.Tensor.backward, le.eval_base
+
+    def eval_base(*a, **k):
+        r = orig_eval_base(*a, **k)
+        rec["base"].append(float(r[0] if isinstance(r, tuple) else r))
+        return r
 
     def validate(query_xs, query_ys_id, net_, criterion, opt_, epoch):
         r = orig_validate(query_xs, query_ys_id, net_, criterion, opt_, epoch)
@@ -390,7 +422,7 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False
     def backward(self, *a, **k):
         rec["loss"][-1].append(float(self.item()))
         return orig_backward(self, *a, **k)
-    le.validate, np.random.choice, torch.Tensor.backward = validate, choice, backward
+    le.validate, np.random.choice, torch.Tensor.backward, le.eval_base = validate, choice, backward, eval_base
     crit = torch.nn.CrossEntropyLoss()
     set_masks(61 + seed)
     t0 = time.time()
@@ -398,7 +430,7 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False
         novel_avg, base_avg = le.few_shot_finetune_incremental_test(net, ckpt, crit, meta, base_loader, opt,
                                                                     vis=False, base_support_loader=bsl)
     finally:
-        le.validate, np.random.choice, torch.Tensor.backward = orig_validate, orig_choice, orig_backward
+        le.validate, np.random.choice, torch.Tensor.backward, le.eval_base = orig_validate, orig_choice, orig_backward, orig_eval_base
     print(tag, "reference loop took %.1f s" % (time.time() - t0))
     out = dict(hw=np.array(hw), n_sessions=np.array(n_sessions), memory=np.array(int(memory)), seed=np.array(seed),
                n_base_batch=np.array(n_base_batch), signal=np.array(signal), sd_seed=np.array(21 + seed),
@@ -416,6 +448,11 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False
         out["mapping_seed"] = np.array(mapping_seed)          # weights = subreg_hip.synthetic.make_linear_map(seed)
     for k, v in bn0.items():
         out["bn0." + k] = v
+    for k, v in params0.items():
+        out["param." + k] = v                                 # backbone parameters that differ from make_state_dict(sd_seed)
+    if proto_grid or hard_queries:
+        out["proto_grid"], out["hard_queries"] = np.array(proto_grid), np.array(hard_queries)
+    out["acc_base_sessions"] = np.array(rec["base"], np.float64)   # eval_base: before session 1, then after every session
     for s in range(n_sessions):
         out["s%d.loss" % s] = np.array(rec["loss"][s], np.float64)
         out["s%d.last_val" % s] = np.array(rec["val"][s][-1], np.float64)
@@ -553,6 +590,17 @@ def main():
         gen_episodes()
     if "loop84" in what:
         gen_loop("hw84_M", 84, 3, True, 40, seed=4, max_novel_epochs=4)
+    if "loop84d" in what:
+        # DISCRIMINATING bench-scale goldens (84x84, -M): low-frequency class prototypes + centred features (centre_features) put
+        # the session accuracies at 40-95 % and keep the base accuracy well above zero; 5 of every class's 25 query images are
+        # wrong by construction (hard_queries), so no accuracy saturates and no image sits near a decision boundary.
+        # The learning rate is 75 x the scripts' 0.002: centred synthetic features have |f| ~ 2 (real ones ~ 20-30), and the
+        # CE gradient scales with |f|^2.  (~10 + ~5 min of torch-CPU)
+        gen_loop("hw84_noM_disc", 84, 2, False, 200, seed=8, signal=0.3, proto_grid=3, hard_queries=5, centre=True, base_norm=2.0,
+                 max_novel_epochs=30, learning_rate=0.15)
+        # ... and one that ENDS ON THE STABLE-EPOCHS RULE (language_eval.py:298-318) at 84x84
+        gen_loop("hw84_stop", 84, 1, False, 100, seed=9, signal=0.3, proto_grid=3, hard_queries=5, centre=True, base_norm=2.0,
+                 max_novel_epochs=80, learning_rate=0.15, stable_epochs=3, convergence_epsilon=4e-2)
     if "loop84s8" in what:
         # bench-scale case (BASELINE.json configs[1]): 8 sessions, -M, 84x84, 1000-image base batch; 6 epochs per
         # session so that the build's loop captures and replays its per-epoch hipGraph (~25 min of torch-CPU here)
