@@ -10,6 +10,8 @@
 // operands fetched straight from global memory (bf16 operands are widened on the fly); a bf16-MFMA version with LDS
 // transposing reads is the next step.
 #include "conv_index.h"
+#include <stdlib.h>
+
 #include "subreg_common.h"
 
 namespace subreg {
@@ -20,32 +22,87 @@ static inline int bw_blocks(size_t n) { return (int)((n + BW_THREADS - 1) / BW_T
 __device__ __forceinline__ float lrelu_grad(float pre) { return pre > 0.f ? 1.f : 0.1f; }
 
 // ---------------------------------------------------------------- block tail
-// out = mask*scale * pool(lrelu(v)), v = raw3*sc3+sh3 + (res*rsc+rsh | res).  One thread per OUTPUT element; writes
-// dV at the argmax pixel (dv must be zero-filled by the caller when pool != 0).
-template <typename T>
-__global__ void block_tail_bwd_kernel(const T* __restrict__ gout, const unsigned char* __restrict__ keep, float mask_scale,
-                                      const T* __restrict__ raw3, const float* __restrict__ sc3, const float* __restrict__ sh3,
-                                      const T* __restrict__ res, const float* __restrict__ rsc, const float* __restrict__ rsh,
-                                      T* __restrict__ dv, int B, int H, int W, int C, int pool) {
-    const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B * Ho * Wo * C) return;
-    const int c = i % C;
-    const size_t po = i / C;
-    const int wo = po % Wo, ho = (po / Wo) % Ho, b = po / ((size_t)Wo * Ho);
-    float g = ElemTraits<T>::to_float(gout[i]);
-    if (keep) g = keep[i] ? g * mask_scale : 0.f;
-    const float a = sc3[c], s = sh3[c], ra = rsc ? rsc[c] : 1.f, rs = rsh ? rsh[c] : 0.f;
-    const int n = pool ? 2 : 1;
-    float best = 0.f;
-    size_t bestp = 0;
-    for (int dy = 0; dy < n; ++dy)
-        for (int dx = 0; dx < n; ++dx) {
-            const size_t p = ((size_t)b * H + (pool ? 2 * ho + dy : ho)) * W + (pool ? 2 * wo + dx : wo);
-            const float v = ElemTraits<T>::to_float(raw3[p * C + c]) * a + s + ElemTraits<T>::to_float(res[p * C + c]) * ra + rs;
-            if ((dy == 0 && dx == 0) || v > best) { best = v; bestp = p; }     // first maximum in scan order
+// out = mask*scale * pool(lrelu(v)), v = raw3*sc3+sh3 + (res*rsc+rsh | res).  Thread = (channel group of 16 bytes, pixel
+// lane) walking OUTPUT pixels (coefficients loaded once, 16-byte loads and stores).  A pooled output writes all four pixels
+// of its window - dV at the first maximum in scan order, zeros at the other three - and the windows at the right / bottom
+// edge also zero the column / row that floor pooling drops, so dV needs no separate zero-fill pass.
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void block_tail_bwd_kernel(const T* __restrict__ gout, const unsigned char* __restrict__ keep,
+                                                             float mask_scale, const T* __restrict__ raw3,
+                                                             const float* __restrict__ sc3, const float* __restrict__ sh3,
+                                                             const T* __restrict__ res, const float* __restrict__ rsc,
+                                                             const float* __restrict__ rsh, T* __restrict__ dv, int H, int W, int C,
+                                                             long long npo, int ppb) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int ngrp = C / VEC, lanes = 256 / ngrp;
+    const int cg = threadIdx.x % ngrp, pl = threadIdx.x / ngrp;
+    if (pl >= lanes) return;
+    const int c0 = cg * VEC;
+    float a[VEC], sft[VEC], ra[VEC], rs[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { a[k] = sc3[c0 + k]; sft[k] = sh3[c0 + k]; ra[k] = rsc ? rsc[c0 + k] : 1.f; rs[k] = rsh ? rsh[c0 + k] : 0.f; }
+    const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W, NQ = POOL ? 4 : 1;
+    const long long p0 = (long long)blockIdx.x * ppb;
+    long long p1 = p0 + ppb;
+    if (p1 > npo) p1 = npo;
+    for (long long po = p0 + pl; po < p1; po += lanes) {
+        const int wo = (int)(po % Wo), ho = (int)((po / Wo) % Ho);
+        const long long b = po / ((long long)Wo * Ho);
+        const size_t pin = POOL ? ((size_t)b * H + 2 * ho) * W + 2 * wo : (size_t)po;
+        const size_t eo = (size_t)po * C + c0;
+        const uint4 vg = *reinterpret_cast<const uint4*>(gout + eo);
+        unsigned long long kb = 0x0101010101010101ull;
+        if (keep) kb = VEC == 8 ? *reinterpret_cast<const unsigned long long*>(keep + eo) : (unsigned long long)*reinterpret_cast<const unsigned*>(keep + eo);
+        uint4 vx[NQ], vr[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const size_t e = (pin + (q >> 1) * W + (q & 1)) * C + c0;
+            vx[q] = *reinterpret_cast<const uint4*>(raw3 + e);
+            vr[q] = *reinterpret_cast<const uint4*>(res + e);
         }
-    dv[bestp * C + c] = ElemTraits<T>::from_float(g * lrelu_grad(best));
+        const T* tg = reinterpret_cast<const T*>(&vg);
+        float best[VEC];
+        int arg[VEC];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const T* tx = reinterpret_cast<const T*>(&vx[q]);
+            const T* tr = reinterpret_cast<const T*>(&vr[q]);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float v = ElemTraits<T>::to_float(tx[k]) * a[k] + sft[k] + ElemTraits<T>::to_float(tr[k]) * ra[k] + rs[k];
+                if (q == 0 || v > best[k]) { best[k] = v; arg[k] = q; }           // first maximum in scan order
+            }
+        }
+        float d[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float g = ElemTraits<T>::to_float(tg[k]);
+            if (keep) g = ((kb >> (8 * k)) & 0xff) ? g * mask_scale : 0.f;
+            d[k] = g * lrelu_grad(best[k]);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            uint4 vo;
+            T* to = reinterpret_cast<T*>(&vo);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) to[k] = ElemTraits<T>::from_float((!POOL || arg[k] == q) ? d[k] : 0.f);
+            *reinterpret_cast<uint4*>(dv + (pin + (q >> 1) * W + (q & 1)) * C + c0) = vo;
+        }
+        if (POOL) {
+            // floor pooling: an odd last column / row belongs to no window and receives no gradient
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            const bool ec = (W & 1) && wo == Wo - 1, er = (H & 1) && ho == Ho - 1;
+            if (ec) {
+                *reinterpret_cast<uint4*>(dv + (pin + 2) * C + c0) = z;
+                *reinterpret_cast<uint4*>(dv + (pin + W + 2) * C + c0) = z;
+            }
+            if (er) {
+                *reinterpret_cast<uint4*>(dv + (pin + 2 * (size_t)W) * C + c0) = z;
+                *reinterpret_cast<uint4*>(dv + (pin + 2 * (size_t)W + 1) * C + c0) = z;
+                if (ec) *reinterpret_cast<uint4*>(dv + (pin + 2 * (size_t)W + 2) * C + c0) = z;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------- BN backward
@@ -71,20 +128,33 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
     for (int k = 0; k < VEC; ++k) { a1[k] = 0.f; a2[k] = 0.f; m[k] = mean[cg * VEC + k]; is[k] = invstd[cg * VEC + k]; }
     if (pl < lanes) {
-        for (long long p = p0 + pl; p < p1; p += lanes) {
-            const size_t e = (size_t)p * C + cg * VEC;
-            const uint4 vd = *reinterpret_cast<const uint4*>(dy + e), vr = *reinterpret_cast<const uint4*>(raw + e);
-            uint4 va = make_uint4(0, 0, 0, 0);
-            if (act) va = *reinterpret_cast<const uint4*>(act + e);
-            const T* td = reinterpret_cast<const T*>(&vd);
-            const T* tr = reinterpret_cast<const T*>(&vr);
-            const T* ta = reinterpret_cast<const T*>(&va);
+        constexpr int UN = 4;                      // pixels in flight per thread (all loads of a step before its arithmetic)
+        for (long long pb = p0 + pl; pb < p1; pb += (long long)lanes * UN) {
+            uint4 vd[UN], vr[UN], va[UN];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                float g = ElemTraits<T>::to_float(td[k]);
-                if (act) g *= lrelu_grad(ElemTraits<T>::to_float(ta[k]));
-                a1[k] += g;
-                a2[k] += g * (ElemTraits<T>::to_float(tr[k]) - m[k]) * is[k];
+            for (int u = 0; u < UN; ++u) {
+                const long long p = pb + (long long)u * lanes;
+                if (p < p1) {
+                    const size_t e = (size_t)p * C + cg * VEC;
+                    vd[u] = *reinterpret_cast<const uint4*>(dy + e);
+                    vr[u] = *reinterpret_cast<const uint4*>(raw + e);
+                    if (act) va[u] = *reinterpret_cast<const uint4*>(act + e);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (pb + (long long)u * lanes < p1) {
+                    const T* td = reinterpret_cast<const T*>(&vd[u]);
+                    const T* tr = reinterpret_cast<const T*>(&vr[u]);
+                    const T* ta = reinterpret_cast<const T*>(&va[u]);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        float g = ElemTraits<T>::to_float(td[k]);
+                        if (act) g *= lrelu_grad(ElemTraits<T>::to_float(ta[k]));
+                        a1[k] += g;
+                        a2[k] += g * (ElemTraits<T>::to_float(tr[k]) - m[k]) * is[k];
+                    }
+                }
             }
         }
     }
@@ -135,19 +205,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     }
 }
 
-// dx = k1*g + k2*raw + k3 with g = dy*lrelu'(act).  One thread = 16 bytes (8 bf16 / 4 f32 channels of one pixel): the pass
-// is HBM-bound (3 tensors read, 1 written); the coefficients come in as float4 vectors.
+// dx = k1*g + k2*raw + k3 with g = dy*lrelu'(act).  Thread = (channel group of 16 bytes, pixel lane): its 8 / 4 channels'
+// coefficients are loaded once, then it walks pixels with stride `lanes`, four in flight.  HBM-bound (3 tensors read, 1 written).
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ act, const T* __restrict__ raw,
-                                    const float* __restrict__ coef, T* __restrict__ dx, long long npix, int C) {
-    constexpr int VEC = 16 / sizeof(T);
-    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t e = v * VEC;
-    if (e >= (size_t)npix * C) return;
-    const int c0 = e % C;
-    const uint4 vd = *reinterpret_cast<const uint4*>(dy + e), vr = *reinterpret_cast<const uint4*>(raw + e);
-    uint4 va = make_uint4(0, 0, 0, 0);
-    if (act) va = *reinterpret_cast<const uint4*>(act + e);
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ act,
+                                                           const T* __restrict__ raw, const float* __restrict__ coef,
+                                                           T* __restrict__ dx, long long npix, int C, int ppb) {
+    constexpr int VEC = 16 / sizeof(T), UN = 4;
+    const int ngrp = C / VEC, lanes = 256 / ngrp;
+    const int cg = threadIdx.x % ngrp, pl = threadIdx.x / ngrp;
+    if (pl >= lanes) return;
+    const int c0 = cg * VEC;
     float k1[VEC], k2[VEC], k3[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; k += 4) {
@@ -155,18 +223,40 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
         *reinterpret_cast<float4*>(k2 + k) = *reinterpret_cast<const float4*>(coef + C + c0 + k);
         *reinterpret_cast<float4*>(k3 + k) = *reinterpret_cast<const float4*>(coef + 2 * C + c0 + k);
     }
-    const T* td = reinterpret_cast<const T*>(&vd);
-    const T* tr = reinterpret_cast<const T*>(&vr);
-    const T* ta = reinterpret_cast<const T*>(&va);
-    uint4 vo;
-    T* to = reinterpret_cast<T*>(&vo);
+    const long long p0 = (long long)blockIdx.x * ppb;
+    long long p1 = p0 + ppb;
+    if (p1 > npix) p1 = npix;
+    for (long long pb = p0 + pl; pb < p1; pb += (long long)lanes * UN) {
+        uint4 vd[UN], vr[UN], va[UN];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        float g = ElemTraits<T>::to_float(td[k]);
-        if (act) g *= lrelu_grad(ElemTraits<T>::to_float(ta[k]));
-        to[k] = ElemTraits<T>::from_float(k1[k] * g + (k2[k] * ElemTraits<T>::to_float(tr[k]) + k3[k]));
+        for (int u = 0; u < UN; ++u) {
+            const long long p = pb + (long long)u * lanes;
+            if (p < p1) {
+                const size_t e = (size_t)p * C + c0;
+                vd[u] = *reinterpret_cast<const uint4*>(dy + e);
+                vr[u] = *reinterpret_cast<const uint4*>(raw + e);
+                if (act) va[u] = *reinterpret_cast<const uint4*>(act + e);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long long p = pb + (long long)u * lanes;
+            if (p < p1) {
+                const T* td = reinterpret_cast<const T*>(&vd[u]);
+                const T* tr = reinterpret_cast<const T*>(&vr[u]);
+                const T* ta = reinterpret_cast<const T*>(&va[u]);
+                uint4 vo;
+                T* to = reinterpret_cast<T*>(&vo);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float g = ElemTraits<T>::to_float(td[k]);
+                    if (act) g *= lrelu_grad(ElemTraits<T>::to_float(ta[k]));
+                    to[k] = ElemTraits<T>::from_float(k1[k] * g + (k2[k] * ElemTraits<T>::to_float(tr[k]) + k3[k]));
+                }
+                *reinterpret_cast<uint4*>(dx + (size_t)p * C + c0) = vo;
+            }
+        }
     }
-    *reinterpret_cast<uint4*>(dx + e) = vo;
 }
 
 // ---------------------------------------------------------------- AdaptiveAvgPool2d(1) backward
@@ -457,10 +547,14 @@ __global__ __launch_bounds__(64, 2) void conv_wgrad3x3_stream_kernel(const __bf1
         }
 }
 
-// K splits of the streaming kernel: one wave per workgroup, ~2048 resident waves on the chip (8 per CU)
+// K splits of the streaming kernel: one wave per workgroup, ~1536 waves on the chip (6 per CU).  Every split writes its own
+// partial dW, which unpack_wgrad re-reads: at the 2048 waves that fill all 8 wave slots per CU the extra partials cost more
+// than the occupancy buys (B = 64 train step, same box: 6.08 ms at 2048, 5.85 at 1536, 5.87 at 1024, 6.11 at 3072;
+// profiles/r03_train_step.txt).  SUBREG_WGRAD_WAVES overrides (measurements).
 static void wgrad_stream_plan(long long Q, int Cin, int Cout, int* splits, int* rows_per_block) {
     const int tiles = (Cout / 32) * (Cin / 32);
-    long long sp = (2048 + tiles - 1) / tiles;
+    static const int target = [] { const char* e = getenv("SUBREG_WGRAD_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1536; }();
+    long long sp = (target + tiles - 1) / tiles;
     long long rpb = ((Q + sp - 1) / sp + 63) / 64 * 64;
     if (rpb < 64) rpb = 64;
     *splits = (int)((Q + rpb - 1) / rpb);
@@ -669,36 +763,39 @@ extern "C" int subreg_block_tail_bwd(const void* grad_out, const unsigned char* 
                                      void* stream) {
     SUBREG_CHECK_ARG(grad_out && raw3 && scale3 && shift3 && residual && dv && B > 0 && H > 0 && W > 0 && C > 0);
     hipStream_t s = (hipStream_t)stream;
-    const size_t es = dtype == SUBREG_BF16 ? 2 : 4;
-    if (pool && hipMemsetAsync(dv, 0, (size_t)B * H * W * C * es, s) != hipSuccess) return SUBREG_EHIP;
-    const size_t n = (size_t)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * C;
-    DISPATCH_T(dtype,
-               hipLaunchKernelGGL(block_tail_bwd_kernel<float>, bw_blocks(n), BW_THREADS, 0, s, (const float*)grad_out, keep_mask, mask_scale,
-                                  (const float*)raw3, scale3, shift3, (const float*)residual, res_scale, res_shift, (float*)dv, B, H, W, C, pool),
-               hipLaunchKernelGGL(block_tail_bwd_kernel<__bf16>, bw_blocks(n), BW_THREADS, 0, s, (const __bf16*)grad_out, keep_mask, mask_scale,
-                                  (const __bf16*)raw3, scale3, shift3, (const __bf16*)residual, res_scale, res_shift, (__bf16*)dv, B, H, W, C, pool));
+    const int vec = dtype == SUBREG_BF16 ? 8 : 4;
+    SUBREG_CHECK_ARG(C % vec == 0 && C / vec <= 256 && (!pool || (H >= 2 && W >= 2)));
+    const long long npo = (long long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    const int lanes = 256 / (C / vec);
+    long long ppb = (npo + 4095) / 4096;                    // ~4096 blocks, whole rounds of the pixel lanes
+    ppb = (ppb + lanes - 1) / lanes * lanes;
+    if (ppb < lanes) ppb = lanes;
+    const int grid = (int)((npo + ppb - 1) / ppb);
+#define BTB(TT, P) hipLaunchKernelGGL((block_tail_bwd_kernel<TT, P>), grid, 256, 0, s, (const TT*)grad_out, keep_mask, mask_scale, (const TT*)raw3, \
+                                      scale3, shift3, (const TT*)residual, res_scale, res_shift, (TT*)dv, H, W, C, npo, (int)ppb)
+    DISPATCH_T(dtype, if (pool) BTB(float, true); else BTB(float, false), if (pool) BTB(__bf16, true); else BTB(__bf16, false));
+#undef BTB
     return launch_status();
 }
 
 // slices of the reduce pass + one more slice-sized region of `partial` that holds the apply pass's coefficients
-static int bn_bwd_reduce_slices(long long npix) { return (int)((npix + 255) / 256); }
-extern "C" int subreg_bn_bwd_slices(long long npix) { return bn_bwd_reduce_slices(npix) + 1; }
+// (at most 512 slices, whatever the problem: see the slice plan in subreg_bn_bwd)
+extern "C" int subreg_bn_bwd_slices(long long npix) { (void)npix; return 512 + 1; }
 
 extern "C" int subreg_bn_bwd(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
                              const float* gamma, double* partial, float* dgamma, float* dbeta, void* dx, long long npix, int C,
                              int dtype, void* stream) {
     SUBREG_CHECK_ARG(dy && raw && mean && invstd && gamma && partial && dgamma && dbeta && dx && npix > 0 && C > 0);
     hipStream_t s = (hipStream_t)stream;
-    // slices of >= 256 pixels, at most ~512 of them (two per CU): the finalize pass walks every slice of a channel, and at
-    // 1764 slices (64 x 84 x 84 pixels) it cost 11 us of dependent fp64 loads per BatchNorm.  A thread still sums at most
-    // 64 pixels in fp32 before the fp64 stages (pixel lanes = 256 / (C / vec) >= 32 for C <= 64 ... 3 for C = 640: the slice
-    // grows only where there are many lanes).
+    // at most 512 slices (two per CU): the finalize pass walks every slice of a channel, and at 1764 slices (64 x 84 x 84
+    // pixels) it cost 11 us of dependent fp64 loads per BatchNorm.  At least one unrolled step (4 pixels) per pixel lane and
+    // slice: the small maps (1600 pixels x 640 channels in layer 4.1) then still spread over ~130 workgroups instead of 7 -
+    // with 256-pixel slices those layers ran at 0.4-1.0 TB/s (profiles/r03_hbm_kernels.txt).
     const int vec_ = dtype == SUBREG_BF16 ? 8 : 4;
     const int lanes_ = C / vec_ > 0 && C / vec_ <= 256 ? 256 / (C / vec_) : 1;
     long long pps = (npix + 511) / 512;
-    if (pps > 64LL * lanes_) pps = 64LL * lanes_;
-    if (pps < 256) pps = 256;
-    const int slices = (int)((npix + pps - 1) / pps);                                     // <= bn_bwd_reduce_slices(npix)
+    if (pps < 4LL * lanes_) pps = 4LL * lanes_;
+    const int slices = (int)((npix + pps - 1) / pps);                                     // <= 512
     float* const coef = reinterpret_cast<float*>(partial + (size_t)slices * C * 2);     // 3*C floats in the extra slice (4*C)
     const int vec = dtype == SUBREG_BF16 ? 8 : 4;
     SUBREG_CHECK_ARG(C % vec == 0 && C / vec <= 256);
@@ -708,10 +805,12 @@ extern "C" int subreg_bn_bwd(const void* dy, const void* act, const void* raw, c
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, slices, 256, lds, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, partial, npix, C, (int)pps));
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, (C + 15) / 16, 256, 0, s, partial, slices, C, mean, invstd, gamma, 1.0 / (double)npix,
                        dgamma, dbeta, coef);
-    const size_t n = (size_t)npix * C;
+    long long ppb = (npix + 4095) / 4096;                   // apply pass: ~4096 blocks, whole unrolled rounds of the pixel lanes
+    ppb = (ppb + 4 * lanes_ - 1) / (4 * lanes_) * (4 * lanes_);
+    const int agrid = (int)((npix + ppb - 1) / ppb);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, bw_blocks(n / 4), BW_THREADS, 0, s, (const float*)dy, (const float*)act, (const float*)raw, coef, (float*)dx, npix, C),
-               hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, bw_blocks(n / 8), BW_THREADS, 0, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, coef, (__bf16*)dx, npix, C));
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, agrid, 256, 0, s, (const float*)dy, (const float*)act, (const float*)raw, coef, (float*)dx, npix, C, (int)ppb),
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, agrid, 256, 0, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, coef, (__bf16*)dx, npix, C, (int)ppb));
     return launch_status();
 }
 

@@ -172,53 +172,102 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------- train-mode apply pass
-// y = mask * mask_scale * pool( act( x*scale+shift + (res*rscale+rshift | res) ) ), all NHWC.
-// One thread = 16 bytes of output (8 bf16 / 4 f32 channels of one output pixel): HBM-bound pass.
-template <typename T>
-__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                const T* __restrict__ res, const float* __restrict__ rscale,
-                                const float* __restrict__ rshift, const unsigned char* __restrict__ keep,
-                                float mask_scale, T* __restrict__ y, int B, int H, int W, int C, int act, int pool) {
-    constexpr int VEC = 16 / sizeof(T);
-    const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
-    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
-    if (i >= (size_t)B * Ho * Wo * C) return;
-    const int c0 = i % C;
-    const size_t po = i / C;
-    const int wo = po % Wo, ho = (po / Wo) % Ho, b = po / ((size_t)Wo * Ho);
-    float sc[VEC], sh[VEC], rsc[VEC], rsh[VEC], best[VEC];
+// y = mask * mask_scale * pool( act( x*scale+shift + (res*rscale+rshift | res) ) ), all NHWC.  HBM-bound pass.
+// Thread = (channel group of 16 bytes, pixel lane), like the BN-backward reduce: its 8 / 4 channels' coefficients are
+// loaded ONCE and it then walks output pixels with stride `lanes`, four pixels in flight per step.  (One thread per
+// 16 output bytes with its coefficients re-loaded every time - 32 scalar loads beside two vector loads - ran at
+// 1.0-2.0 TB/s algorithmic, profiles/r03_hbm_kernels.txt.)
+template <typename T, bool POOL, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const T* __restrict__ res,
+                                                       const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                       const unsigned char* __restrict__ keep, float mask_scale,
+                                                       T* __restrict__ y, int H, int W, int C, int act, long long npo,
+                                                       int ppb) {
+    constexpr int VEC = 16 / sizeof(T), UN = POOL ? 1 : 4;
+    const int ngrp = C / VEC, lanes = 256 / ngrp;
+    const int cg = threadIdx.x % ngrp, pl = threadIdx.x / ngrp;
+    if (pl >= lanes) return;
+    const int c0 = cg * VEC;
+    float sc[VEC], sh[VEC], rsc[VEC], rsh[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
         sc[k] = scale[c0 + k]; sh[k] = shift[c0 + k];
-        rsc[k] = rscale ? rscale[c0 + k] : 1.f; rsh[k] = rshift ? rshift[c0 + k] : 0.f;
-        best[k] = -3.0e38f;
+        rsc[k] = (RES && rscale) ? rscale[c0 + k] : 1.f; rsh[k] = (RES && rshift) ? rshift[c0 + k] : 0.f;
     }
-    const int n = pool ? 2 : 1;
-    for (int dy = 0; dy < n; ++dy)
-        for (int dx = 0; dx < n; ++dx) {
-            const size_t p = ((size_t)b * H + (pool ? 2 * ho + dy : ho)) * W + (pool ? 2 * wo + dx : wo);
-            const uint4 vx = *reinterpret_cast<const uint4*>(x + p * C + c0);
-            uint4 vr = make_uint4(0, 0, 0, 0);
-            if (res) vr = *reinterpret_cast<const uint4*>(res + p * C + c0);
-            const T* tx = reinterpret_cast<const T*>(&vx);
-            const T* tr = reinterpret_cast<const T*>(&vr);
+    const long long p0 = (long long)blockIdx.x * ppb;
+    long long p1 = p0 + ppb;
+    if (p1 > npo) p1 = npo;
+    const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+    auto finish = [&](float (&v)[VEC], long long po) {
+        uint4 vo;
+        T* to = reinterpret_cast<T*>(&vo);
+        const size_t e = (size_t)po * C + c0;
+        unsigned long long kb = 0x0101010101010101ull;
+        if (keep) kb = VEC == 8 ? *reinterpret_cast<const unsigned long long*>(keep + e) : (unsigned long long)*reinterpret_cast<const unsigned*>(keep + e);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                float v = ElemTraits<T>::to_float(tx[k]) * sc[k] + sh[k];
-                if (res) v += ElemTraits<T>::to_float(tr[k]) * rsc[k] + rsh[k];
-                best[k] = fmaxf(best[k], v);
+        for (int k = 0; k < VEC; ++k) {
+            float r = v[k];
+            if (act) r = lrelu(r);
+            if (keep) r = ((kb >> (8 * k)) & 0xff) ? r * mask_scale : 0.f;
+            to[k] = ElemTraits<T>::from_float(r);
+        }
+        *reinterpret_cast<uint4*>(y + e) = vo;
+    };
+    if constexpr (!POOL) {
+        for (long long pb = p0 + pl; pb < p1; pb += (long long)lanes * UN) {
+            uint4 vx[UN], vr[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const long long p = pb + (long long)u * lanes;
+                if (p < p1) {
+                    vx[u] = *reinterpret_cast<const uint4*>(x + (size_t)p * C + c0);
+                    if (RES) vr[u] = *reinterpret_cast<const uint4*>(res + (size_t)p * C + c0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const long long p = pb + (long long)u * lanes;
+                if (p < p1) {
+                    const T* tx = reinterpret_cast<const T*>(&vx[u]);
+                    const T* tr = reinterpret_cast<const T*>(&vr[u]);
+                    float v[VEC];
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        v[k] = ElemTraits<T>::to_float(tx[k]) * sc[k] + sh[k];
+                        if (RES) v[k] += ElemTraits<T>::to_float(tr[k]) * rsc[k] + rsh[k];
+                    }
+                    finish(v, p);
+                }
             }
         }
-    uint4 vo;
-    T* to = reinterpret_cast<T*>(&vo);
+    } else {
+        for (long long po = p0 + pl; po < p1; po += lanes) {
+            const int wo = (int)(po % Wo), ho = (int)((po / Wo) % Ho);
+            const long long b = po / ((long long)Wo * Ho);
+            const size_t pin = ((size_t)b * H + 2 * ho) * W + 2 * wo;        // top-left pixel of the 2x2 window
+            uint4 vx[4], vr[4];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        float v = best[k];
-        if (act) v = lrelu(v);
-        if (keep) v = keep[i + k] ? v * mask_scale : 0.f;
-        to[k] = ElemTraits<T>::from_float(v);
+            for (int q = 0; q < 4; ++q) {
+                const size_t e = (pin + (q >> 1) * W + (q & 1)) * C + c0;
+                vx[q] = *reinterpret_cast<const uint4*>(x + e);
+                if (RES) vr[q] = *reinterpret_cast<const uint4*>(res + e);
+            }
+            float best[VEC];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const T* tx = reinterpret_cast<const T*>(&vx[q]);
+                const T* tr = reinterpret_cast<const T*>(&vr[q]);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float v = ElemTraits<T>::to_float(tx[k]) * sc[k] + sh[k];
+                    if (RES) v += ElemTraits<T>::to_float(tr[k]) * rsc[k] + rsh[k];
+                    best[k] = q == 0 ? v : fmaxf(best[k], v);
+                }
+            }
+            finish(best, po);
+        }
     }
-    *reinterpret_cast<uint4*>(y + i) = vo;
 }
 
 // ---------------------------------------------------------------- keep-mask helpers
@@ -374,13 +423,24 @@ extern "C" int subreg_bn_apply(const void* x, const float* scale, const float* s
     const int act = (flags & SUBREG_CONV_LRELU) ? 1 : 0, pool = (flags & SUBREG_CONV_POOL2) ? 1 : 0;
     SUBREG_CHECK_ARG(!pool || (H >= 2 && W >= 2));
     SUBREG_CHECK_ARG(C % (dtype == SUBREG_BF16 ? 8 : 4) == 0);      // 16-byte vectors along the channel axis
-    const size_t n = (size_t)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * C;
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn_apply_kernel<float>, ew_blocks(n / 4), EW_THREADS, 0, s, (const float*)x, scale, shift,
-                                  (const float*)residual, res_scale, res_shift, keep_mask, mask_scale, (float*)y, B, H, W, C, act, pool),
-               hipLaunchKernelGGL(bn_apply_kernel<__bf16>, ew_blocks(n / 8), EW_THREADS, 0, s, (const __bf16*)x, scale, shift,
-                                  (const __bf16*)residual, res_scale, res_shift, keep_mask, mask_scale, (__bf16*)y, B, H, W, C, act, pool));
+    const int vec = dtype == SUBREG_BF16 ? 8 : 4;
+    SUBREG_CHECK_ARG(C / vec <= 256);
+    const long long npo = (long long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    const int lanes = 256 / (C / vec);
+    // pixels per block: ~4096 blocks, at least one unrolled step of every pixel lane
+    long long ppb = (npo + 4095) / 4096;
+    const int step = lanes * (pool ? 1 : 4);
+    ppb = (ppb + step - 1) / step * step;
+    if (ppb < step) ppb = step;
+    const int grid = (int)((npo + ppb - 1) / ppb);
+#define BNA(TT, P, R) hipLaunchKernelGGL((bn_apply_kernel<TT, P, R>), grid, 256, 0, s, (const TT*)x, scale, shift, (const TT*)residual, \
+                                         res_scale, res_shift, keep_mask, mask_scale, (TT*)y, H, W, C, act, npo, (int)ppb)
+#define BNA_T(TT) do { if (pool) { if (residual) BNA(TT, true, true); else BNA(TT, true, false); } \
+                       else { if (residual) BNA(TT, false, true); else BNA(TT, false, false); } } while (0)
+    DISPATCH_T(dtype, BNA_T(float), BNA_T(__bf16));
+#undef BNA_T
+#undef BNA
     return launch_status();
 }
 

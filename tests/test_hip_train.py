@@ -133,9 +133,11 @@ def test_bn_backward(dtype, with_act):
     _cmp("dx", dx.float().cpu().numpy().reshape(B, H, W, Cc), dx_ref, tol * np.abs(dx_ref).max(), tol)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("pool", [0, 1])
-def test_block_tail_backward(pool):
-    """keep mask * scale, MaxPool2d(2) routing to the first maximum (floor mode: 9x7 -> 4x3), LeakyReLU'."""
+def test_block_tail_backward(pool, dtype):
+    """keep mask * scale, MaxPool2d(2) routing to the first maximum (floor mode: 9x7 -> 4x3), LeakyReLU'.  dV starts as NaN:
+    the kernel itself must zero the non-maximum pixels AND the row / column floor pooling drops."""
     B, H, W, Cc = 2, 9, 7, 64
     lib = _lib.load()
     rs = np.random.RandomState(8)
@@ -149,17 +151,22 @@ def test_block_tail_backward(pool):
     z = rr.leaky_relu(v)
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     gout = rs.standard_normal((B, Ho, Wo, Cc))
+    if dtype == "bf16":                               # (rounded BEFORE the oracle sees them; v is recomputed from the rounded operands)
+        raw3, res, gout = (_round_bf16(a.astype(np.float32)).astype(np.float64) for a in (raw3, res, gout))
+        v = raw3 * sc + sh + res * rsc + rsh
+        z = rr.leaky_relu(v)
     keep = (rs.random_sample((B, Ho, Wo, Cc)) > 0.2)
     want = br.lrelu_backward(br.maxpool_backward(gout * keep * 1.25, z, 2 if pool else 1), v)
     dev = _dev()
-    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev, _td(dtype))
     r3, rd, gd, kd = f(raw3), f(res), f(gout), torch.from_numpy(keep.astype(np.uint8)).to(dev)
     scd, shd, rscd, rshd = _t(sc), _t(sh), _t(rsc), _t(rsh)
-    dv = torch.full((B * H * W * Cc,), float("nan"), device=dev) if pool else torch.empty(B * H * W * Cc, device=dev)
+    dv = torch.full((B * H * W * Cc,), float("nan"), device=dev, dtype=_td(dtype))
     _lib.check(lib.subreg_block_tail_bwd(_lib.ptr(gd), _lib.ptr(kd), 1.25, _lib.ptr(r3), _lib.ptr(scd), _lib.ptr(shd), _lib.ptr(rd),
-                                         _lib.ptr(rscd), _lib.ptr(rshd), _lib.ptr(dv), B, H, W, Cc, pool, _lib.F32, _lib.stream_ptr()))
+                                         _lib.ptr(rscd), _lib.ptr(rshd), _lib.ptr(dv), B, H, W, Cc, pool, _lib.dtype_code(dtype), _lib.stream_ptr()))
     torch.cuda.synchronize()
-    _cmp("dv", dv.cpu().numpy().reshape(B, H, W, Cc), want, 1e-5, 1e-5)
+    tol = 1e-5 if dtype == "f32" else 1e-2
+    _cmp("dv", dv.float().cpu().numpy().reshape(B, H, W, Cc), want, tol, tol)
 
 
 def _train_net(dtype):
