@@ -332,3 +332,21 @@ def test_torch_train_step_oracle_fp32_mode_matches_reference_autograd():
     for name in ("classifier.weight", "layer4.1.conv3.weight", "layer1.0.conv1.weight"):
         a, b = grads_b[name].astype(np.float64).ravel(), grads[name].astype(np.float64).ravel()
         assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) > 0.85, name
+
+
+def test_backward_from_stash_equals_the_full_oracle_step():
+    """oracle/backward_ref.py::backward_from_stash (the backward started from a GIVEN forward stash: what the GPU test feeds the
+    HIP path's own bf16 stash into) reproduces train_step's gradients exactly when handed train_step's own stash - and
+    train_step is pinned by the reference's autograd golden above."""
+    from oracle import backward_ref as br
+    sd = syn.make_state_dict(71)
+    x = syn.make_images(72, 4, 32)
+    y = np.array([1, 5, 7, 30])
+    stash = {}
+    from oracle import resnet_ref as rr
+    loss, _logits, grads = br.train_step(rr.copy_state_dict(sd), x, y, masks=MaskSource(74), stash_out=stash)
+    loss2, grads2 = br.backward_from_stash(sd, stash, x, y)
+    assert abs(loss - loss2) < 1e-6
+    assert set(grads) == set(grads2)
+    for k in grads:
+        _close(grads2[k], grads[k], 1e-9 * max(float(np.abs(grads[k]).max()), 1e-12), 1e-9, k)
