@@ -103,6 +103,11 @@ int subreg_mask_nchw_to_nhwc(const float* mask_nchw, unsigned char* keep_nhwc, i
 /* counter-based Bernoulli(1-p_drop) keep mask for free-running train forwards; kept_count may be NULL */
 int subreg_random_keep_mask(unsigned char* keep, long long n, unsigned long long seed, float p_drop, unsigned int* kept_count,
                             void* stream);
+/* DropBlock._compute_block_mask (:327-357) for block_size > 1: sample [B][C][H-bs+1][W-bs+1] u8 (1 = seed, NCHW order like
+ * the reference's Bernoulli sample) -> keep mask NHWC u8 and the number of kept elements (scale = numel / kept, :320-323);
+ * restates the reference's seed / offset pairing (nz.repeat vs offsets.repeat). */
+int subreg_dropblock_mask(const unsigned char* sample, unsigned char* keep_nhwc, int B, int C, int H, int W, int block_size,
+                          unsigned int* kept_count, void* stream);
 /* AdaptiveAvgPool2d(1) + view (:125,179-181): [B][H*W][C] -> fp32 [B][C] */
 int subreg_avgpool(const void* x, float* feat, int B, int H, int W, int C, int dtype, void* stream);
 

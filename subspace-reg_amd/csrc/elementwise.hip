@@ -318,6 +318,62 @@ __global__ __launch_bounds__(256) void random_keep_kernel(unsigned char* __restr
     }
 }
 
+// ---------------------------------------------------------------- DropBlock block mask (block_size > 1)
+// DropBlock._compute_block_mask (models/resnet_language.py:327-357) on the device: sample [B][C][H-bs+1][W-bs+1] (u8, 1 =
+// seed) -> keep mask NHWC u8 (pre-filled with ones by the caller).  The reference pairs seed i % n with offset i % bs^2 for
+// i < n bs^2 (nz.repeat vs offsets.repeat, :345-346), so the seed of rank r (row-major order of Tensor.nonzero()) receives
+// the offset o iff (r - o) % gcd(n, bs^2) == 0 - plus its own padded position (the padded sample itself).  The ranks need a
+// prefix sum over the sample in row-major order: ONE workgroup, every thread counts the seeds of its contiguous chunk, an
+// LDS scan gives each chunk its first rank and the total n, then every thread walks its chunk again and clears the covered
+// mask elements (plain byte stores of 0: writers never disagree).  The reference's scripts all pass --no_dropblock (block
+// size 1, which never comes here), so this is a correctness path, not a throughput one.
+__global__ __launch_bounds__(1024) void dropblock_mask_kernel(const unsigned char* __restrict__ sample, unsigned char* __restrict__ keep,
+                                                              int B, int C, int H, int W, int bs) {
+    __shared__ unsigned cnt[1024];
+    __shared__ unsigned total;
+    const int hs = H - bs + 1, ws = W - bs + 1, lp = (bs - 1) / 2, tid = threadIdx.x;
+    const size_t n_el = (size_t)B * C * hs * ws;
+    const size_t per = (n_el + 1023) / 1024, lo = (size_t)tid * per, hi = lo + per < n_el ? lo + per : n_el;
+    unsigned c = 0;
+    for (size_t i = lo; i < hi; ++i) c += sample[i] != 0;
+    cnt[tid] = c;
+    __syncthreads();
+    if (tid == 0) {                                   // exclusive scan of 1024 chunk counts (serial: 1024 adds)
+        unsigned run = 0;
+        for (int k = 0; k < 1024; ++k) { const unsigned v = cnt[k]; cnt[k] = run; run += v; }
+        total = run;
+    }
+    __syncthreads();
+    const unsigned n = total;
+    if (n == 0) return;
+    unsigned g = n, b2 = (unsigned)(bs * bs);
+    while (b2) { const unsigned t = g % b2; g = b2; b2 = t; }       // g = gcd(n, bs^2)
+    unsigned rank = cnt[tid];
+    for (size_t i = lo; i < hi; ++i) {
+        if (sample[i] == 0) continue;
+        const int j = (int)(i % ws), ii = (int)((i / ws) % hs), cc = (int)((i / ((size_t)ws * hs)) % C);
+        const size_t b = i / ((size_t)ws * hs * C);
+        for (int o = 0; o < bs * bs; ++o) {
+            const int oy = o / bs, ox = o % bs;
+            const bool own = oy == lp && ox == lp;                   // the seed itself in the padded sample
+            if (!own && (int)((rank + (unsigned)(bs * bs) * g - (unsigned)o) % g) != 0) continue;
+            keep[((b * H + ii + oy) * W + j + ox) * C + cc] = 0;
+        }
+        ++rank;
+    }
+}
+
+__global__ __launch_bounds__(256) void count_ones_kernel(const unsigned char* __restrict__ m, size_t n, unsigned int* __restrict__ out) {
+    unsigned c = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) c += m[i] != 0;
+    __shared__ unsigned wsum[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+}
+
 // ---------------------------------------------------------------- AdaptiveAvgPool2d(1) + view
 template <typename T>
 __global__ void avgpool_kernel(const T* __restrict__ x, float* __restrict__ feat, int B, int HW, int C) {
@@ -458,6 +514,20 @@ extern "C" int subreg_random_keep_mask(unsigned char* keep, long long n, unsigne
     SUBREG_CHECK_ARG(keep && n > 0 && p_drop >= 0.f && p_drop < 1.f);
     hipLaunchKernelGGL(random_keep_kernel, dim3((unsigned)(((size_t)n + 4095) / 4096)), dim3(256), 0, (hipStream_t)stream, keep,
                        (size_t)n, seed, p_drop, kept_count);
+    return launch_status();
+}
+
+extern "C" int subreg_dropblock_mask(const unsigned char* sample, unsigned char* keep_nhwc, int B, int C, int H, int W, int block_size,
+                                     unsigned int* kept_count, void* stream) {
+    SUBREG_CHECK_ARG(sample && keep_nhwc && kept_count && B > 0 && C > 0 && block_size >= 1 && H >= block_size && W >= block_size);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * C * H * W;
+    if (hipMemsetAsync(keep_nhwc, 1, n, s) != hipSuccess || hipMemsetAsync(kept_count, 0, sizeof(unsigned int), s) != hipSuccess)
+        return SUBREG_EHIP;
+    hipLaunchKernelGGL(dropblock_mask_kernel, 1, 1024, 0, s, sample, keep_nhwc, B, C, H, W, block_size);
+    size_t blocks = (n + 256 * 64 - 1) / (256 * 64);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(count_ones_kernel, dim3((unsigned)blocks), dim3(256), 0, s, keep_nhwc, n, kept_count);
     return launch_status();
 }
 

@@ -111,6 +111,7 @@ SIGNATURES = {
     "subreg_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P]),
     "subreg_mask_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_random_keep_mask": (_I, [_P, _L, C.c_ulonglong, _F, _P, _P]),
+    "subreg_dropblock_mask": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "subreg_avgpool": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_backbone_ws_bytes": (_L, [C.POINTER(BackboneDesc), _I, _I, _I]),
     "subreg_backbone_stats_floats": (_L, [C.POINTER(BackboneDesc), _I, _I, _I]),

@@ -5,6 +5,7 @@ Drives `subreg_backbone_forward` (csrc/backbone.hip), i.e. ResNet.forward up to 
 All tensors are torch CUDA tensors used as plain device memory; torch does no math here.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -22,29 +23,15 @@ def dropblock_gamma(num_batches_tracked, feat_size, block_size, drop_rate=DROP_R
     return (1 - keep_rate) / block_size ** 2 * feat_size ** 2 / (feat_size - block_size + 1) ** 2
 
 
-def dropblock_block_mask_host(sample_nchw, block_size):
-    """DropBlock._compute_block_mask (:327-357) for block_size > 1, on the host (mask preparation only;
-    every script of the reference passes --no_dropblock => block_size 1, which never comes here).
-    Restates the reference's repeat/tile pairing: seed i % n meets offset i % bs^2."""
-    bs = block_size
-    lp, rp = int((bs - 1) / 2), int(bs / 2)
-    padded = np.pad(sample_nchw, ((0, 0), (0, 0), (lp, rp), (lp, rp))).astype(np.float32)
-    nz = np.argwhere(sample_nchw != 0)
-    n = nz.shape[0]
-    if n:
-        i = np.arange(bs * bs * n)
-        s, o = nz[i % n], i % (bs * bs)
-        padded[s[:, 0], s[:, 1], s[:, 2] + o // bs, s[:, 3] + o % bs] = 1.0
-    return 1.0 - padded
-
-
 class HipBackbone:
     """params: dict with the reference's state_dict key names -> LIVE fp32 CUDA tensors (conv weights, BN
     weight/bias/running_mean/running_var).  BN running stats are updated in place by train-mode forwards."""
 
     MAX_EVAL_CHUNK = 1536     # images per launch sequence: one launch for a whole epoch's batch (<= 1125 images at 8 sessions) - larger grids
                               # waste less on partial last rounds (+8 % episodes/s over 512); 6.3 GB of workspaces in bf16
-    EVAL_LANES = 2            # eval-mode forwards: the batch is cut into this many sub-batches (images are independent in eval mode),
+    EVAL_LANES = int(os.environ.get("SUBREG_EVAL_LANES", "2"))   # (the environment override is for profiling runs: with one lane the
+                              # per-kernel durations of a rocprofv3 trace are not inflated by the lanes' overlap)
+                              # eval-mode forwards: the batch is cut into this many sub-batches (images are independent in eval mode),
                               # each running its own 22-conv launch sequence on its own HIP stream and workspaces, forked from and
                               # joined to the caller's stream once per forward.  While one lane's kernel drains its partial last round
                               # of workgroups, the other lanes' kernels fill the idle CUs (tools/bench_forward.py, graph replay,
@@ -241,13 +228,25 @@ class HipBackbone:
                     _lib.check(self.lib.subreg_random_keep_mask(_lib.ptr(keep), n, int(torch.randint(0, 2 ** 62, (1,))),
                                                                 float(gamma), _lib.ptr(cnt), s), "random_keep_mask")
                     scale = n / max(int(cnt.item()), 1)
-                else:
-                    sample = (masks.bernoulli(shape, gamma) if masks is not None
-                              else (np.random.random_sample(shape) < gamma).astype(np.float32))
-                    bm = 1.0 - sample if bs == 1 else dropblock_block_mask_host(sample, bs)
+                elif bs == 1:                                   # injected element mask (block_size 1)
+                    bm = 1.0 - masks.bernoulli(shape, gamma)
                     scale = bm.size / bm.sum()
                     m = torch.from_numpy(np.ascontiguousarray(bm, dtype=np.float32)).to(self.device)
                     _lib.check(self.lib.subreg_mask_nchw_to_nhwc(_lib.ptr(m), _lib.ptr(keep), B, cout, h, w, 0, s), "mask")
+                else:
+                    # block_size > 1 (no --no_dropblock): the Bernoulli seeds come from the injected source or from the device
+                    # generator; DropBlock._compute_block_mask (:327-357) runs on the device
+                    ns = int(np.prod(shape))
+                    if masks is not None:
+                        sample = torch.from_numpy(np.ascontiguousarray(masks.bernoulli(shape, gamma) != 0).astype(np.uint8)).to(self.device)
+                    else:
+                        sample = torch.empty(ns, dtype=torch.uint8, device=self.device)
+                        _lib.check(self.lib.subreg_random_keep_mask(_lib.ptr(sample), ns, int(torch.randint(0, 2 ** 62, (1,))),
+                                                                    float(1.0 - gamma), None, s), "random_keep_mask")   # 1 with probability gamma
+                    cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
+                    _lib.check(self.lib.subreg_dropblock_mask(_lib.ptr(sample), _lib.ptr(keep), B, cout, h, w, bs, _lib.ptr(cnt), s),
+                               "dropblock_mask")
+                    scale = n / max(int(cnt.item()), 1)
             self._keep.append(keep)
             self._blk[bi].keep_mask = keep.data_ptr()
             self._blk[bi].mask_scale = float(scale)

@@ -654,6 +654,30 @@ def test_validate_sets_top1_and_top5_with_ties():
         assert int(c1[3:].sum()) == 0 and int(c5[3:].sum()) == 0
 
 
+@pytest.mark.parametrize("case", [(2, 8, 10, 10, 5, 7), (3, 16, 10, 10, 5, 25), (1, 8, 5, 5, 5, 5), (2, 8, 9, 7, 3, 6), (2, 8, 6, 6, 2, 9),
+                                  (1, 8, 10, 10, 5, 0), (4, 64, 10, 10, 5, 400)])
+def test_dropblock_block_mask_on_device(case):
+    """DropBlock._compute_block_mask (models/resnet_language.py:327-357) for block_size > 1 as a device kernel against the
+    oracle's restatement (pinned by blocks.npz against the reference itself), including the seed / offset PAIRING quirk: seed
+    counts n with gcd(n, bs^2) = 1 (every offset), = bs (n = 5), = bs^2 (n = 25: one offset per seed), even block sizes,
+    no seed at all, and many seeds spread over all 1024 scan chunks."""
+    B, Cc, H, W, bs, n_seeds = case
+    lib = _lib.load()
+    rs = np.random.RandomState(B * 100 + n_seeds)
+    shape = (B, Cc, H - bs + 1, W - bs + 1)
+    sample = np.zeros(int(np.prod(shape)), np.float32)
+    sample[rs.choice(sample.size, n_seeds, replace=False)] = 1.0
+    sample = sample.reshape(shape)
+    want = rr.dropblock_block_mask(sample, bs)                      # NCHW {0,1}
+    sd, keep = torch.from_numpy(sample.astype(np.uint8)).cuda(), torch.full((B * H * W * Cc,), 7, dtype=torch.uint8, device="cuda")
+    cnt = torch.full((1,), 123, dtype=torch.int32, device="cuda")
+    _lib.check(lib.subreg_dropblock_mask(_lib.ptr(sd), _lib.ptr(keep), B, Cc, H, W, bs, _lib.ptr(cnt), None), "dropblock_mask")
+    torch.cuda.synchronize()
+    got = keep.cpu().numpy().reshape(B, H, W, Cc).transpose(0, 3, 1, 2)
+    assert np.array_equal(got, want.astype(np.uint8)), (case, int((got != want).sum()))
+    assert int(cnt[0]) == int(want.sum())
+
+
 def test_validate_sets_out_of_range_label_is_a_miss():
     """A query label that is not (yet) a row of the classifier counts as wrong for top-1 AND top-5 (it used to index the logits
     out of range in the top-5 path)."""

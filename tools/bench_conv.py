@@ -17,10 +17,13 @@ import torch  # noqa: E402
 from subreg_hip import _lib  # noqa: E402
 
 # (name, H, Cin, Cout, ksize, pool, Cin2 (fused shortcut K; -1 none; 0 identity), count per forward)
+# Cin = 3 marks the production first layer: conv1 straight from the fp32 NCHW image (conv_first.hip); Cin2 = 3 marks conv3 of
+# layer 1 with its 1x1 shortcut fed from the image (conv64_resident.hip IMG kernels).  `--im2col` benches the K = 32 im2col
+# route they replaced (plus its pack_input launch) instead.
 LAYERS = [
-    ("L1.conv1 (K=32 im2col)", 84, 32, 64, 1, False, -1, 1),
+    ("L1.conv1 (fp32 image)", 84, 3, 64, 3, False, -1, 1),
     ("L1.conv2", 84, 64, 64, 3, False, -1, 1),
-    ("L1.conv3+ds+pool", 84, 64, 64, 3, True, 32, 1),
+    ("L1.conv3+ds(image)+pool", 84, 64, 64, 3, True, 3, 1),
     ("L2.conv1", 42, 64, 160, 3, False, -1, 1),
     ("L2.conv2", 42, 160, 160, 3, False, -1, 1),
     ("L2.conv3+ds+pool", 42, 160, 160, 3, True, 64, 1),
@@ -43,6 +46,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--im2col", action="store_true", help="layer 1 over the K = 32 im2col buffer (the round-2 route) + pack_input")
     a = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -51,10 +55,50 @@ def main():
     peak = 2500.0 if a.dtype == "bf16" else 157.3
     B = a.batch
     tot_t, tot_f = 0.0, 0.0
-    for name, H, Cin, Cout, k, pool, cin2, count in LAYERS:
+    layers = list(LAYERS)
+    if a.im2col or a.dtype != "bf16":
+        layers[0] = ("L1.conv1 (K=32 im2col)", 84, 32, 64, 1, False, -1, 1)
+        layers[2] = ("L1.conv3+ds+pool", 84, 64, 64, 3, True, 32, 1)
+        layers.insert(0, ("pack_input (im2col rows)", 84, 0, 32, 0, False, -1, 1))
+    for name, H, Cin, Cout, k, pool, cin2, count in layers:
         if a.only and a.only not in name:
             continue
         npix = B * H * H
+        if Cin == 0 or Cin == 3 or cin2 == 3:                       # the first layer's special kernels
+            img = torch.randn(B, 3, H, H, device=dev)
+            w1 = (torch.randn(64, 32, device=dev) / 27 ** 0.5).to(td)
+            shift = torch.randn(64, device=dev)
+            if Cin == 0:
+                out = torch.empty(npix, 32, device=dev, dtype=td)
+                run = lambda: _lib.check(lib.subreg_pack_input(_lib.ptr(img), _lib.ptr(out), B, H, H, dt, _lib.stream_ptr()))   # noqa: E731
+                flops, mrows, kk = 0.0, npix, 0
+            elif Cin == 3:
+                out = torch.empty(npix, 64, device=dev, dtype=td)
+                run = lambda: _lib.check(lib.subreg_conv_first_fwd(_lib.ptr(img), _lib.ptr(w1), _lib.ptr(out), _lib.ptr(shift), B, H, H, 64,   # noqa: E731
+                                                                   _lib.CONV_LRELU, dt, _lib.stream_ptr()))
+                flops, mrows, kk = 2.0 * npix * 64 * 27, npix, 27
+            else:
+                x3 = torch.randn(npix, 64, device=dev).to(td)
+                w3 = (torch.randn(64, 9, 64, device=dev) / 576 ** 0.5).to(td)
+                out = torch.empty(B * (H // 2) ** 2, 64, device=dev, dtype=td)
+                run = lambda: _lib.check(lib.subreg_conv_fwd_image_shortcut(_lib.ptr(x3), _lib.ptr(w3), _lib.ptr(out), _lib.ptr(shift), _lib.ptr(img),   # noqa: E731
+                                                                            _lib.ptr(w1), B, H, H, 64, 64, _lib.CONV_LRELU | _lib.CONV_POOL2, dt,
+                                                                            _lib.stream_ptr()))
+                flops, mrows, kk = 2.0 * npix * 64 * 576 + 2.0 * npix * 64 * 3, npix, 576
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / a.iters
+            tf = flops / us * 1e-6
+            tot_t += us * count
+            tot_f += flops * count
+            print("%-24s M=%8d K=%5d N=%4d  %8.1f us  %7.1f TFLOP/s  %5.1f%% of peak" % (name, mrows, kk, Cout, us, tf, 100 * tf / peak))
+            continue
         x = torch.randn(npix, Cin, device=dev).to(td)
         w = (torch.randn(Cout, k * k, Cin, device=dev) / (Cin * k * k) ** 0.5).to(td)
         shift = torch.randn(Cout, device=dev)
@@ -86,41 +130,6 @@ def main():
         tot_t += us * count
         tot_f += flops * count
         print("%-24s M=%8d K=%5d N=%4d  %8.1f us  %7.1f TFLOP/s  %5.1f%% of peak" % (name, mrows, Cin * k * k, Cout, us, tf, 100 * tf / peak))
-    # layer 1 without the im2col buffer: conv1 from the fp32 NCHW image (conv_first.hip), conv3's shortcut from the image
-    # (conv64_resident.hip IMG kernels); these replace the two "L1" lines marked im2col / ds above plus the pack_input launch
-    if a.dtype == "bf16" and (not a.only or "L1" in a.only):
-        H = 84
-        npix = B * H * H
-        img = torch.randn(B, 3, H, H, device=dev)
-        w1 = (torch.randn(64, 32, device=dev) / 27 ** 0.5).to(td)
-        shift = torch.randn(64, device=dev)
-        y1 = torch.empty(npix, 64, device=dev, dtype=td)
-        col = torch.empty(npix, 32, device=dev, dtype=td)
-        x3 = torch.randn(npix, 64, device=dev).to(td)
-        w3 = (torch.randn(64, 9, 64, device=dev) / 576 ** 0.5).to(td)
-        y3 = torch.empty(B * 42 * 42, 64, device=dev, dtype=td)
-        fl = _lib.CONV_LRELU
-
-        def t_of(fn, iters=a.iters):
-            for _ in range(3):
-                fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(iters):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) * 1e3 / iters
-        s = _lib.stream_ptr
-        us_pack = t_of(lambda: _lib.check(lib.subreg_pack_input(_lib.ptr(img), _lib.ptr(col), B, H, H, dt, s())))
-        us_c1 = t_of(lambda: _lib.check(lib.subreg_conv_first_fwd(_lib.ptr(img), _lib.ptr(w1), _lib.ptr(y1), _lib.ptr(shift), B, H, H, 64, fl, dt, s())))
-        us_c3 = t_of(lambda: _lib.check(lib.subreg_conv_fwd_image_shortcut(_lib.ptr(x3), _lib.ptr(w3), _lib.ptr(y3), _lib.ptr(shift), _lib.ptr(img),
-                                                                           _lib.ptr(w1), B, H, H, 64, 64, fl | _lib.CONV_POOL2, dt, s())))
-        byt1 = npix * (12 + 128)
-        print("pack_input (im2col route only)            %8.1f us  %6.2f TB/s (12 B read + 64 B written per pixel)" % (us_pack, npix * 76 / us_pack * 1e-6))
-        print("L1.conv1 direct from the fp32 image       %8.1f us  %6.2f TB/s algorithmic (140 B per pixel), %5.1f TFLOP/s" %
-              (us_c1, byt1 / us_c1 * 1e-6, 2.0 * npix * 64 * 27 / us_c1 * 1e-6))
-        print("L1.conv3+ds(image)+pool                   %8.1f us  %7.1f TFLOP/s" % (us_c3, (2.0 * npix * 64 * 576 + 2.0 * npix * 64 * 3) / us_c3 * 1e-6))
     if not a.only:
         print("conv stack, B=%d: %.1f us, %.1f TFLOP/s algorithmic (%.1f%% of %s peak)" % (B, tot_t, tot_f / tot_t * 1e-6, 100 * tot_f / tot_t * 1e-6 / peak, a.dtype))
 
