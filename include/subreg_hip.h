@@ -82,6 +82,12 @@ int subreg_conv_first_fwd(const float* x_nchw, const void* w_packed, void* y, co
  * bf16, Cin = Cout = 64, SUBREG_CONV_POOL2 required; SUBREG_EUNSUPPORTED where subreg_layer1_direct_supported says 0. */
 int subreg_conv_fwd_image_shortcut(const void* x, const void* w, void* y, const float* shift, const float* img_nchw,
                                    const void* w2_first, int B, int H, int W, int Cin, int Cout, int flags, int dtype, void* stream);
+/* conv1 + BN + LeakyReLU + conv2 + BN + LeakyReLU of layer1.0 in one launch (models/resnet_language.py:249-253, eval mode):
+ * y [B*H*W][64] bf16 = lrelu(conv3x3(lrelu(conv3x3(x_nchw, w1) + shift1), w2) + shift2); the 64-channel intermediate stays in
+ * LDS.  w1 = mode-1 packed first-layer weights, w2 = mode-0 packed 64 -> 64 weights (both BN-folded).  bf16, 84x84-class images
+ * only: SUBREG_EUNSUPPORTED otherwise (the caller then runs subreg_conv_first_fwd + subreg_conv_fwd). */
+int subreg_conv12_first_fused(const float* x_nchw, const void* w1_packed, const float* shift1, const void* w2_packed,
+                              const float* shift2, void* y, int B, int H, int W, int flags, int dtype, void* stream);
 /* 1 if an eval-mode forward of (B, H, W) images runs layer 1 without the im2col buffer (backbone desc `col` may then be NULL) */
 int subreg_layer1_direct_supported(int B, int H, int W, int dtype);
 

@@ -145,11 +145,19 @@ extern "C" int subreg_backbone_forward(const subreg_backbone_desc* d, const floa
             // BN scale is folded into the packed weights; conv3 accumulates the shortcut branch (1x1 conv+BN, or the
             // identity) as a second GEMM over the block input, so no separate shortcut tensor is written or re-read
             const bool img_in = direct && i == 0;
-            if (img_in) TRY(subreg_conv_first_fwd(x_nchw, b.conv1.w_folded, A, b.conv1.shift, B, h, w, b.conv1.cout, SUBREG_CONV_LRELU, dt, stream));
-            else TRY(subreg_conv_fwd(cur, b.conv1.w_folded, A, nullptr, b.conv1.shift, nullptr, nullptr, nullptr, nullptr, 0, B, h, w,
-                                     b.conv1.cin, b.conv1.cout, b.conv1.ksize, SUBREG_CONV_LRELU, dt, stream));
-            TRY(subreg_conv_fwd(A, b.conv2.w_folded, Bf, nullptr, b.conv2.shift, nullptr, nullptr, nullptr, nullptr, 0, B, h, w,
-                                b.conv2.cin, b.conv2.cout, b.conv2.ksize, SUBREG_CONV_LRELU, dt, stream));
+            // layer 1 from the image: conv1 + conv2 in one launch where the fused kernel takes the shape, else conv1 by itself
+            int fused = SUBREG_EUNSUPPORTED;
+            if (img_in && b.conv2.cin == 64 && b.conv2.cout == 64)
+                fused = subreg_conv12_first_fused(x_nchw, b.conv1.w_folded, b.conv1.shift, b.conv2.w_folded, b.conv2.shift, Bf, B, h, w,
+                                                  SUBREG_CONV_LRELU, dt, stream);
+            if (fused != SUBREG_OK) {
+                if (fused != SUBREG_EUNSUPPORTED) return fused;
+                if (img_in) TRY(subreg_conv_first_fwd(x_nchw, b.conv1.w_folded, A, b.conv1.shift, B, h, w, b.conv1.cout, SUBREG_CONV_LRELU, dt, stream));
+                else TRY(subreg_conv_fwd(cur, b.conv1.w_folded, A, nullptr, b.conv1.shift, nullptr, nullptr, nullptr, nullptr, 0, B, h, w,
+                                         b.conv1.cin, b.conv1.cout, b.conv1.ksize, SUBREG_CONV_LRELU, dt, stream));
+                TRY(subreg_conv_fwd(A, b.conv2.w_folded, Bf, nullptr, b.conv2.shift, nullptr, nullptr, nullptr, nullptr, 0, B, h, w,
+                                    b.conv2.cin, b.conv2.cout, b.conv2.ksize, SUBREG_CONV_LRELU, dt, stream));
+            }
             const void* w2 = b.down.w ? b.down.w_folded : b.w_identity;
             const int cin2 = b.down.w ? b.down.cin : b.conv3.cout;
             SUBREG_CHECK_ARG(w2 != nullptr);

@@ -90,6 +90,26 @@ __device__ __forceinline__ u32x4 lds_wait(u32x4 frag) {      // all but the N yo
     return frag;
 }
 
+typedef float r64_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 r64_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned r64_pack(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(r64_f32x2{lo, hi}, r64_bf16x2));
+}
+// one LDS-DMA piece whose 64 lanes read from arbitrary 64-bit addresses (the address lives in a VGPR pair, no scalar base)
+__device__ __forceinline__ void dma16_far(const char* p, unsigned lds_addr) {
+    const unsigned lds_u = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(p), "s"(lds_u)
+        : "memory");
+}
+
 // BLOCKS: image-row blocks per plane (LINEAR R + 2 = 5, POOL 2 row pairs + halo = 6)
 // IMG (with SC): the shortcut's input is the fp32 NCHW image (layer1.0's downsample conv, models/resnet_language.py:146-147,286):
 // each tile's own pixels are loaded from the three channel planes, converted to bf16 and written into logical slot 0 of
@@ -432,6 +452,300 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
         d[7] = ghz;
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv1 -> conv2 of layer1.0 in ONE kernel (models/resnet_language.py:249-253: conv3x3(3 -> 64) + BN + LeakyReLU, then
+// conv3x3(64 -> 64) + BN + LeakyReLU, eval mode): the 64-channel intermediate never leaves the chip.  The resident kernel above
+// stages, per tile of 3 image rows, the 5 rows x W pixels x 64 channels of conv1's OUTPUT from HBM (128 B per pixel written by
+// the conv1 kernel, 128 B read back: the two largest streams of the whole backbone).  Here the same planes are COMPUTED from the
+// fp32 NCHW image instead: per tile 7 image rows x 3 channels arrive by LDS-DMA (12 B per pixel), are converted to the bf16
+// [row][column][c0 c1 c2 1] patch of conv_first.hip, and a K = 48 MFMA pass (weights = conv1's packed matrix with its BN shift
+// riding on the constant-1 channel, fragments kept in LDS) produces the 5 x W x 64 block straight into the swizzled, zero-bordered
+// plane layout the register-resident conv2 reads.  Extra MFMA work: 48 / 576 x 5 / 3 = 14 % of conv2's; HBM traffic of the pair:
+// 12 B + 128 B per pixel instead of 12 + 128 + 128 + 128.
+// Pipeline per iteration (tile T): [DMA fp32 patch of T+2] -> [conv1 of T+1 from the bf16 patch into the other plane pair] ->
+// [conv2 chunks of T from this pair, epilogue] -> barrier -> [convert the fp32 patch of T+2 to bf16] -> barrier.  Four planes
+// (two pairs), so conv1 of the next tile has no dependency on this tile's reads.  LINEAR tiles only (conv2 is not pooled).
+struct Conv64FusedArgs {
+    const float* img;    // [B][3][H][W] fp32
+    const char* w1;      // [64][32] bf16, k = 3 tap + c, BN scale folded (subreg_pack_conv_weight mode 1)
+    const float* shift1; // [64]
+    const char* w;       // conv2: [9][2][64][32] bf16, BN scale folded
+    const float* shift;  // [64]
+    char* y;             // [npix][64] bf16
+    int H, W, act, ntiles, tpi, R;
+    FastDiv d_w, d_tpi;
+};
+
+__global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(const Conv64FusedArgs a) {
+    constexpr int P = R64_P, BLOCKS = 5, PROWS = BLOCKS * P, PLANE = PROWS * R64_ROWB;
+    constexpr int XROWS = BLOCKS + 2;                                   // image rows under a tile's 5 conv1 rows
+    constexpr int XF_BASE = 4 * PLANE, XF_BYTES = 3 * XROWS * 96 * 4;   // fp32 patch [c][row][x], DMA target
+    constexpr int X4_BASE = XF_BASE + XF_BYTES, X4_ROW = (96 + 4) * 8, X4_BYTES = XROWS * X4_ROW;   // bf16 patch [row][x + 2][4]
+    constexpr int WF_BASE = X4_BASE + X4_BYTES, WF_BYTES = 6 * 64 * 16; // conv1 A fragments [i][s][lane]
+    constexpr int SLAB_RS = 32 * 2 + 16, SLAB = 32 * SLAB_RS;
+    constexpr int SLAB_BASE = WF_BASE + WF_BYTES, SHIFT_BASE = SLAB_BASE + R64_NW * SLAB;
+    static_assert(SHIFT_BASE + 256 <= 160 * 1024, "LDS budget");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wh = wid & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int W = a.W, W4 = W >> 2;
+
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = (nwg + 7 - xcd) >> 3;
+    const int per = (a.ntiles + 7) >> 3;
+    const int t_begin = xcd * per + slot, t_end = min((xcd + 1) * per, a.ntiles);
+    if (t_begin >= t_end) return;
+
+    // ---- conv2's resident weights (as in conv64_resident_kernel)
+    uint4 bw[2][9][2];
+    {
+        const char* wl = a.w + (size_t)(32 * wh + lr) * R64_ROWB + lh * 16;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    bw[c][t][s] = *reinterpret_cast<const uint4*>(wl + (size_t)((t * 2 + c) * 64) * R64_ROWB + s * 32);
+    }
+    // ---- LDS: planes and fp32 patch zero; bf16 patch = (0, 0, 0, 1) everywhere (its border columns are never rewritten)
+    for (int o = tid * 16; o < X4_BASE; o += R64_NW * 64 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
+    for (int o = tid * 8; o < X4_BYTES; o += R64_NW * 64 * 8) *reinterpret_cast<uint2*>(smem + X4_BASE + o) = make_uint2(0u, 0x3F800000u);
+    float* const s_shift = reinterpret_cast<float*>(smem + SHIFT_BASE);
+    if (tid < 64) s_shift[tid] = a.shift[tid];
+    // conv1's A fragments through the (still idle) slab region: fragment (i, s), lane (r, h) holds k' = 16 s + 8 h + j of output
+    // channel 32 i + r, k' = 4 tap + c; c = 3: the BN shift (tap 4: bf16 hi part, tap 3: lo part) against the constant-1 channel
+    {
+        __bf16* const wl = reinterpret_cast<__bf16*>(smem + SLAB_BASE);
+        float* const sh1 = reinterpret_cast<float*>(smem + SLAB_BASE + 4096);
+        if (tid < 256) reinterpret_cast<uint4*>(wl)[tid] = reinterpret_cast<const uint4*>(a.w1)[tid];
+        if (tid < 64) sh1[tid] = a.shift1[tid];
+        __syncthreads();
+        if (wid < 6) {                                                 // wave w builds fragment (i, s) = (w / 3, w % 3)
+            const int i = wid / 3, s = wid % 3;
+            const float shv = sh1[32 * i + lr];
+            const __bf16 sh_hi = (__bf16)shv, sh_lo = (__bf16)(shv - (float)sh_hi);
+            unsigned short e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int tap = 4 * s + 2 * lh + (j >> 2), c = j & 3;
+                const bool ok = c < 3 && tap < 9;
+                const unsigned short v = __builtin_bit_cast(unsigned short, wl[(32 * i + lr) * 32 + (ok ? 3 * tap + c : 0)]);
+                e[j] = ok ? v : (unsigned short)0;
+                if (c == 3 && tap == 4) e[j] = __builtin_bit_cast(unsigned short, sh_hi);
+                if (c == 3 && tap == 3) e[j] = __builtin_bit_cast(unsigned short, sh_lo);
+            }
+            *reinterpret_cast<uint4*>(smem + WF_BASE + (wid * 64 + lane) * 16) =
+                make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16));
+        }
+    }
+    __syncthreads();
+
+    // ---- tile -> (image, first tile row)
+    auto tile_geom = [&](int t, int& b, int& k_img) {
+        const int bb = (int)fdiv((unsigned)t, a.d_tpi);
+        b = __builtin_amdgcn_readfirstlane(bb);
+        k_img = __builtin_amdgcn_readfirstlane(t - bb * a.tpi);
+    };
+    // ---- fp32 patch by LDS-DMA: XF = [c][row r][x] floats, r = 0..6 <-> image row R k - 2 + r; piece q = floats [256 q, +256)
+    const size_t plane_px = (size_t)a.H * W;
+    const int xf_floats = 3 * XROWS * W, xf_pieces = (xf_floats + 255) >> 8;
+    auto dma_patch = [&](int b, int k_img) {
+        for (int q = wid; q < xf_pieces; q += R64_NW) {
+            const int idx = q * 256 + lane * 4;
+            const int c = idx / (XROWS * W), rem = idx - c * (XROWS * W), r = rem / W, x = rem - r * W;
+            const int h = a.R * k_img - 2 + r;
+            const bool ok = idx < xf_floats && h >= 0 && h < a.H;
+            const char* src = ok ? reinterpret_cast<const char*>(a.img + ((size_t)b * 3 + c) * plane_px + (size_t)h * W + x)
+                                 : reinterpret_cast<const char*>(r64_zero_line);
+            dma16_far(src, lds_base + XF_BASE + q * 1024);
+        }
+    };
+    // ---- fp32 patch -> bf16 [row][x + 2][c0 c1 c2 1]: item = (row, float4 column)
+    auto convert_patch = [&]() {
+        const int items = XROWS * W4;
+        for (int it = tid; it < items; it += R64_NW * 64) {
+            const int r = it / W4, j = it - r * W4;
+            const float4 v0 = *reinterpret_cast<const float4*>(smem + XF_BASE + ((0 * XROWS + r) * W + 4 * j) * 4);
+            const float4 v1 = *reinterpret_cast<const float4*>(smem + XF_BASE + ((1 * XROWS + r) * W + 4 * j) * 4);
+            const float4 v2 = *reinterpret_cast<const float4*>(smem + XF_BASE + ((2 * XROWS + r) * W + 4 * j) * 4);
+            const unsigned one = 0x3F800000u;
+            uint4* dst = reinterpret_cast<uint4*>(smem + X4_BASE + r * X4_ROW + (4 * j + 2) * 8);
+            dst[0] = make_uint4(r64_pack(v0.x, v1.x), (r64_pack(v2.x, 0.f) & 0xffffu) | one, r64_pack(v0.y, v1.y), (r64_pack(v2.y, 0.f) & 0xffffu) | one);
+            dst[1] = make_uint4(r64_pack(v0.z, v1.z), (r64_pack(v2.z, 0.f) & 0xffffu) | one, r64_pack(v0.w, v1.w), (r64_pack(v2.w, 0.f) & 0xffffu) | one);
+        }
+    };
+    // ---- conv1 of the tile whose bf16 patch is in X4, into plane pair `pp`: 32-pixel groups of its 5 rows x W pixels; wave w
+    //      takes groups w, w + 8.  Rows outside the image become zero rows (conv2's zero padding, not conv1 of zeros).
+    int toff[3][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int tap = 4 * s + 2 * lh + u;
+            tap = tap < 9 ? tap : 8;
+            toff[s][u] = (tap / 3) * X4_ROW + (tap % 3) * 8;
+        }
+    auto conv1_tile = [&](int k_img, int pp) {
+        const int npx = BLOCKS * W;
+        for (int g0 = wid * 32; g0 < npx; g0 += R64_NW * 32) {
+            const int p = g0 + lr;
+            const bool valid = p < npx;
+            const int rb = valid ? (int)fdiv((unsigned)p, a.d_w) : 0, x = valid ? p - rb * W : 0;
+            const int h = a.R * k_img - 1 + rb;
+            const bool inside = h >= 0 && h < a.H;
+            const char* const base = smem + X4_BASE + rb * X4_ROW + (x + 1) * 8;
+            f32x16 acc1[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const uint2 t0 = *reinterpret_cast<const uint2*>(base + toff[s][0]);
+                const uint2 t1 = *reinterpret_cast<const uint2*>(base + toff[s][1]);
+                const uint4 xf = make_uint4(t0.x, t0.y, t1.x, t1.y);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const uint4 wfr = *reinterpret_cast<const uint4*>(smem + WF_BASE + ((i * 3 + s) * 64 + lane) * 16);
+                    acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfr), __builtin_bit_cast(bf16x8, xf), acc1[i], 0, 0, 0);
+                }
+            }
+            // lane (pixel lr, half lh) holds channels 32 i + 8 q + 4 lh + {0..3} in registers 4q..4q+3: 8 bytes of slot q of plane
+            // (pair, chunk i), row rb P + 1 + x
+            const int row = rb * P + 1 + x;
+            const unsigned rbase = (unsigned)row * R64_ROWB + 8u * lh;
+            const int sw = swz<4>(row);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = acc1[i][4 * q + e];
+                        v[e] = inside ? fmaxf(t, t * 0.1f) : 0.f;
+                    }
+                    if (valid)
+                        *reinterpret_cast<uint2*>(smem + (2 * pp + i) * PLANE + rbase + 16u * (unsigned)(q ^ sw)) =
+                            make_uint2(r64_pack(v[0], v[1]), r64_pack(v[2], v[3]));
+                }
+        }
+    };
+
+    // ---- conv2's per-lane A addresses (LINEAR: the same for every tile)
+    unsigned areg[2][3][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = wm * 64 + i * 32 + lr, jv = j < a.R * W ? j : 0;
+        const int ir = (int)fdiv((unsigned)jv, a.d_w), w = jv - ir * W;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int row = ir * P + w + dx;
+            const unsigned ad = (unsigned)row * R64_ROWB + 16u * (lh ^ swz<4>(row));
+            areg[i][dx][0] = ad;
+            areg[i][dx][1] = ad ^ 32u;
+        }
+    }
+
+    // ---- prologue: patch + conv1 of the first tile, patch of the second
+    int t = t_begin, b, k_img;
+    tile_geom(t, b, k_img);
+    dma_patch(b, k_img);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    convert_patch();
+    __syncthreads();
+    conv1_tile(k_img, 0);
+    int nb = 0, nk = 0;
+    if (t + nslot < t_end) {
+        tile_geom(t + nslot, nb, nk);
+        dma_patch(nb, nk);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                                                   // (conv1's reads of the bf16 patch are done)
+    if (t + nslot < t_end) convert_patch();
+    __syncthreads();
+
+    for (int it = 0; t < t_end; ++it, t += nslot) {
+        const int pp = it & 1;
+        const bool more = t + nslot < t_end, more2 = t + 2 * nslot < t_end;
+        int b2 = 0, k2 = 0;
+        if (more2) {
+            tile_geom(t + 2 * nslot, b2, k2);
+            dma_patch(b2, k2);                                         // lands while this tile computes
+        }
+        if (more) conv1_tile(nk, pp ^ 1);
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        auto chunk = [&](int pl, auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int NRD = 36, RD = R64_DEPTH;
+            unsigned ta[2][3][2];
+            const unsigned pb = lds_base + pl * PLANE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) ta[i][dx][s] = areg[i][dx][s] + pb;
+            u32x4 ring[RD];
+            auto rd = [&](auto jc) {
+                constexpr int j = decltype(jc)::value, tt = j >> 2, s = (j >> 1) & 1, i = j & 1, dy = tt / 3, dx = tt % 3;
+                ring[j % RD] = lds_read16<dy * P * R64_ROWB>(ta[i][dx][s]);
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            static_for<0, RD - 1>(rd);
+            static_for<0, NRD>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (j + RD - 1 < NRD) rd(std::integral_constant<int, j + RD - 1>{});
+                constexpr int left = NRD - 1 - j;
+                u32x4 f = ring[j % RD];
+                f = lds_wait<(left >= RD - 1 ? RD - 1 : left)>(f);
+                acc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f),
+                                                                      __builtin_bit_cast(bf16x8, bw[c][j >> 2][(j >> 1) & 1]), acc[j & 1], 0, 0, 0);
+            });
+        };
+        chunk(2 * pp, std::integral_constant<int, 0>{});
+        chunk(2 * pp + 1, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- epilogue (LINEAR): + shift, LeakyReLU, bf16 through this wave's slab, 16-byte stores
+        char* const slab = smem + SLAB_BASE + wid * SLAB;
+        const float sh = s_shift[32 * wh + lr];
+        const int rows_left = a.H - k_img * a.R, nvalid = (rows_left < a.R ? rows_left : a.R) * W;
+        const long long pix0 = ((long long)b * a.H + (long long)k_img * a.R) * W;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int jrow0 = wm * 64 + i * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][r] + sh;
+                if (a.act) v = fmaxf(v, v * 0.1f);
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                *reinterpret_cast<__bf16*>(slab + row * SLAB_RS + lr * 2) = (__bf16)v;
+            }
+#pragma unroll
+            for (int v0 = 0; v0 < 128; v0 += 64) {
+                const int v = v0 + lane, row = v >> 2, c16 = v & 3;
+                const uint4 val = *reinterpret_cast<const uint4*>(slab + row * SLAB_RS + c16 * 16);
+                if (jrow0 + row < nvalid)
+                    *reinterpret_cast<uint4*>(a.y + (size_t)(pix0 + jrow0 + row) * 128 + wh * 64 + c16 * 16) = val;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's patch pieces of tile t + 2 landed (and its stores)
+        __syncthreads();                                               // every wave: conv1 read the bf16 patch, every patch piece landed
+        if (more2) convert_patch();
+        __syncthreads();                                               // bf16 patch of t + 2 and the planes of t + 1 are complete
+        b = nb; k_img = nk; nb = b2; nk = k2;
+    }
 }
 
 // all but the n youngest vector-memory operations (LDS-DMAs and stores, in issue order) of this wave are done; n wave-uniform
@@ -790,6 +1104,36 @@ static int launch_r64(const Conv64Args& a, hipStream_t stream) {
     int grid = cus < a.ntiles ? cus : a.ntiles;                    // one persistent workgroup per CU
     grid = (grid + 7) / 8 * 8;                                     // whole XCD groups (surplus workgroups exit at once)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(R64_NW * 64), lds, stream, a);
+    return launch_status();
+}
+
+// conv1 + conv2 of layer1.0 fused (eval mode, bf16): SUBREG_EUNSUPPORTED for shapes outside the kernel's LDS plan.
+bool conv64_fused_first_supported(int B, int H, int W) {
+    return W % 4 == 0 && W >= 80 && W + 1 <= R64_P && H >= 2 && 256 / W == 3 && (long long)B * H * W < (1LL << 26);
+}
+int conv64_fused_first(const float* img, const void* w1, const float* shift1, const void* w2, const float* shift2, void* y, int B, int H,
+                       int W, int act, hipStream_t stream) {
+    if (!conv64_fused_first_supported(B, H, W) || ((size_t)img & 15)) return SUBREG_EUNSUPPORTED;
+    Conv64FusedArgs a;
+    a.img = img; a.w1 = (const char*)w1; a.shift1 = shift1; a.w = (const char*)w2; a.shift = shift2; a.y = (char*)y;
+    a.H = H; a.W = W; a.act = act;
+    a.R = 3;
+    a.tpi = (H + a.R - 1) / a.R;
+    a.ntiles = B * a.tpi;
+    a.d_w = make_fastdiv(W);
+    a.d_tpi = make_fastdiv(a.tpi);
+    constexpr size_t lds = 4 * (size_t)(5 * R64_P * R64_ROWB) + 3 * 7 * 96 * 4 + 7 * (96 + 4) * 8 + 6 * 64 * 16 + R64_NW * 32 * (32 * 2 + 16) + 256;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static std::atomic<unsigned long long> lds_set{0};
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv64_fused_first_kernel), lds, lds_set)) return rc;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    int grid = cus < a.ntiles ? cus : a.ntiles;
+    grid = (grid + 7) / 8 * 8;
+    hipLaunchKernelGGL(conv64_fused_first_kernel, dim3(grid), dim3(R64_NW * 64), lds, stream, a);
     return launch_status();
 }
 

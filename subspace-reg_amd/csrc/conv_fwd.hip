@@ -722,6 +722,20 @@ bool conv64_image_shortcut_supported(int B, int H, int W);         // conv64_res
 bool conv_first_supported(int B, int H, int W);                    // conv_first.hip
 }
 
+namespace subreg {
+int conv64_fused_first(const float* img, const void* w1, const float* shift1, const void* w2, const float* shift2, void* y, int B, int H,
+                       int W, int act, hipStream_t stream);          // conv64_resident.hip
+}
+
+extern "C" int subreg_conv12_first_fused(const float* x_nchw, const void* w1_packed, const float* shift1, const void* w2_packed,
+                                         const float* shift2, void* y, int B, int H, int W, int flags, int dtype, void* stream) {
+    SUBREG_CHECK_ARG(x_nchw && w1_packed && shift1 && w2_packed && shift2 && y && B > 0 && H > 0 && W > 0);
+    static const bool on = [] { const char* e = getenv("SUBREG_NO_FUSED12"); return !(e && e[0] == '1'); }();   // A/B switch
+    if (!on || dtype != SUBREG_BF16 || (flags & (SUBREG_CONV_POOL2 | SUBREG_CONV_RAW_STATS))) return SUBREG_EUNSUPPORTED;
+    return conv64_fused_first(x_nchw, w1_packed, shift1, w2_packed, shift2, y, B, H, W, (flags & SUBREG_CONV_LRELU) ? 1 : 0,
+                              (hipStream_t)stream);
+}
+
 extern "C" int subreg_layer1_direct_supported(int B, int H, int W, int dtype) {
     static const bool on = [] { const char* e = getenv("SUBREG_IM2COL_FIRST"); return !(e && e[0] == '1'); }();   // A/B switch
     return on && dtype == SUBREG_BF16 && resident64_enabled() && conv_first_supported(B, H, W) &&

@@ -87,6 +87,7 @@ SIGNATURES = {
     "subreg_conv_stats_rows": (_I, [_I, _I, _I, _I, _I]),
     "subreg_conv_first_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "subreg_conv_fwd_image_shortcut": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "subreg_conv12_first_fused": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_layer1_direct_supported": (_I, [_I, _I, _I, _I]),
     "subreg_bn_fold": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _P]),
     "subreg_bn_train_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),

@@ -130,6 +130,28 @@ def main():
         tot_t += us * count
         tot_f += flops * count
         print("%-24s M=%8d K=%5d N=%4d  %8.1f us  %7.1f TFLOP/s  %5.1f%% of peak" % (name, mrows, Cin * k * k, Cout, us, tf, 100 * tf / peak))
+    if a.dtype == "bf16" and not a.im2col and (not a.only or "L1" in a.only):
+        # conv1 + conv2 of layer 1 in one launch (what the backbone runs): replaces the first two lines above
+        H, npix = 84, B * 84 * 84
+        img = torch.randn(B, 3, H, H, device=dev)
+        w1 = (torch.randn(64, 32, device=dev) / 27 ** 0.5).to(td)
+        w2 = (torch.randn(64, 9, 64, device=dev) / 576 ** 0.5).to(td)
+        sh1, sh2 = torch.randn(64, device=dev), torch.randn(64, device=dev)
+        out = torch.empty(npix, 64, device=dev, dtype=td)
+        run = lambda: _lib.check(lib.subreg_conv12_first_fused(_lib.ptr(img), _lib.ptr(w1), _lib.ptr(sh1), _lib.ptr(w2), _lib.ptr(sh2), _lib.ptr(out),   # noqa: E731
+                                                               B, H, H, _lib.CONV_LRELU, dt, _lib.stream_ptr()))
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / a.iters
+        flops = 2.0 * npix * 64 * (27 + 576)
+        print("%-24s M=%8d K=%5d N=%4d  %8.1f us  %7.1f TFLOP/s  %5.1f%% of peak   (one launch instead of the first two lines)" %
+              ("L1.conv1+conv2 fused", npix, 603, 64, us, flops / us * 1e-6, 100 * flops / us * 1e-6 / peak))
     if not a.only:
         print("conv stack, B=%d: %.1f us, %.1f TFLOP/s algorithmic (%.1f%% of %s peak)" % (B, tot_t, tot_f / tot_t * 1e-6, 100 * tot_f / tot_t * 1e-6 / peak, a.dtype))
 
