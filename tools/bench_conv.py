@@ -20,9 +20,10 @@ from subreg_hip import _lib  # noqa: E402
 # Cin = 3 marks the production first layer: conv1 straight from the fp32 NCHW image (conv_first.hip); Cin2 = 3 marks conv3 of
 # layer 1 with its 1x1 shortcut fed from the image (conv64_resident.hip IMG kernels).  `--im2col` benches the K = 32 im2col
 # route they replaced (plus its pack_input launch) instead.
+# (Cin = -3: conv1 + conv2 of layer 1 as the ONE fused launch the backbone runs, conv64_fused_first_kernel; `--unfused` benches
+# the two launches it replaced.)
 LAYERS = [
-    ("L1.conv1 (fp32 image)", 84, 3, 64, 3, False, -1, 1),
-    ("L1.conv2", 84, 64, 64, 3, False, -1, 1),
+    ("L1.conv1+conv2 (fp32 image)", 84, -3, 64, 3, False, -1, 1),
     ("L1.conv3+ds(image)+pool", 84, 64, 64, 3, True, 3, 1),
     ("L2.conv1", 42, 64, 160, 3, False, -1, 1),
     ("L2.conv2", 42, 160, 160, 3, False, -1, 1),
@@ -47,6 +48,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--im2col", action="store_true", help="layer 1 over the K = 32 im2col buffer (the round-2 route) + pack_input")
+    ap.add_argument("--unfused", action="store_true", help="conv1 (from the image) and conv2 of layer 1 as two launches")
     a = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -57,14 +59,15 @@ def main():
     tot_t, tot_f = 0.0, 0.0
     layers = list(LAYERS)
     if a.im2col or a.dtype != "bf16":
-        layers[0] = ("L1.conv1 (K=32 im2col)", 84, 32, 64, 1, False, -1, 1)
-        layers[2] = ("L1.conv3+ds+pool", 84, 64, 64, 3, True, 32, 1)
-        layers.insert(0, ("pack_input (im2col rows)", 84, 0, 32, 0, False, -1, 1))
+        layers[0:2] = [("pack_input (im2col rows)", 84, 0, 32, 0, False, -1, 1), ("L1.conv1 (K=32 im2col)", 84, 32, 64, 1, False, -1, 1),
+                       ("L1.conv2", 84, 64, 64, 3, False, -1, 1), ("L1.conv3+ds+pool", 84, 64, 64, 3, True, 32, 1)]
+    elif a.unfused:
+        layers[0:1] = [("L1.conv1 (fp32 image)", 84, 3, 64, 3, False, -1, 1), ("L1.conv2", 84, 64, 64, 3, False, -1, 1)]
     for name, H, Cin, Cout, k, pool, cin2, count in layers:
         if a.only and a.only not in name:
             continue
         npix = B * H * H
-        if Cin == 0 or Cin == 3 or cin2 == 3:                       # the first layer's special kernels
+        if Cin == 0 or Cin == 3 or Cin == -3 or cin2 == 3:          # the first layer's special kernels
             img = torch.randn(B, 3, H, H, device=dev)
             w1 = (torch.randn(64, 32, device=dev) / 27 ** 0.5).to(td)
             shift = torch.randn(64, device=dev)
@@ -72,6 +75,13 @@ def main():
                 out = torch.empty(npix, 32, device=dev, dtype=td)
                 run = lambda: _lib.check(lib.subreg_pack_input(_lib.ptr(img), _lib.ptr(out), B, H, H, dt, _lib.stream_ptr()))   # noqa: E731
                 flops, mrows, kk = 0.0, npix, 0
+            elif Cin == -3:
+                w2 = (torch.randn(64, 9, 64, device=dev) / 576 ** 0.5).to(td)
+                sh2 = torch.randn(64, device=dev)
+                out = torch.empty(npix, 64, device=dev, dtype=td)
+                run = lambda: _lib.check(lib.subreg_conv12_first_fused(_lib.ptr(img), _lib.ptr(w1), _lib.ptr(shift), _lib.ptr(w2), _lib.ptr(sh2),   # noqa: E731
+                                                                       _lib.ptr(out), B, H, H, _lib.CONV_LRELU, dt, _lib.stream_ptr()))
+                flops, mrows, kk = 2.0 * npix * 64 * (27 + 576), npix, 603
             elif Cin == 3:
                 out = torch.empty(npix, 64, device=dev, dtype=td)
                 run = lambda: _lib.check(lib.subreg_conv_first_fwd(_lib.ptr(img), _lib.ptr(w1), _lib.ptr(out), _lib.ptr(shift), B, H, H, 64,   # noqa: E731
@@ -130,28 +140,6 @@ def main():
         tot_t += us * count
         tot_f += flops * count
         print("%-24s M=%8d K=%5d N=%4d  %8.1f us  %7.1f TFLOP/s  %5.1f%% of peak" % (name, mrows, Cin * k * k, Cout, us, tf, 100 * tf / peak))
-    if a.dtype == "bf16" and not a.im2col and (not a.only or "L1" in a.only):
-        # conv1 + conv2 of layer 1 in one launch (what the backbone runs): replaces the first two lines above
-        H, npix = 84, B * 84 * 84
-        img = torch.randn(B, 3, H, H, device=dev)
-        w1 = (torch.randn(64, 32, device=dev) / 27 ** 0.5).to(td)
-        w2 = (torch.randn(64, 9, 64, device=dev) / 576 ** 0.5).to(td)
-        sh1, sh2 = torch.randn(64, device=dev), torch.randn(64, device=dev)
-        out = torch.empty(npix, 64, device=dev, dtype=td)
-        run = lambda: _lib.check(lib.subreg_conv12_first_fused(_lib.ptr(img), _lib.ptr(w1), _lib.ptr(sh1), _lib.ptr(w2), _lib.ptr(sh2), _lib.ptr(out),   # noqa: E731
-                                                               B, H, H, _lib.CONV_LRELU, dt, _lib.stream_ptr()))
-        for _ in range(3):
-            run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.iters):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / a.iters
-        flops = 2.0 * npix * 64 * (27 + 576)
-        print("%-24s M=%8d K=%5d N=%4d  %8.1f us  %7.1f TFLOP/s  %5.1f%% of peak   (one launch instead of the first two lines)" %
-              ("L1.conv1+conv2 fused", npix, 603, 64, us, flops / us * 1e-6, 100 * flops / us * 1e-6 / peak))
     if not a.only:
         print("conv stack, B=%d: %.1f us, %.1f TFLOP/s algorithmic (%.1f%% of %s peak)" % (B, tot_t, tot_f / tot_t * 1e-6, 100 * tot_f / tot_t * 1e-6 / peak, a.dtype))
 

@@ -1,33 +1,50 @@
 #!/bin/bash
 # Re-record the round's measurements on the GPU box (run through gpurun from the repo root):
-#   bash tools/record_evidence.sh           -> everything under gpurun_out/evidence/
-# Then copy what should be judged into profiles/ (see profiles/README.md).
-# Needs subspace-reg_amd/subreg_hip/libsubreg_diag.so (a -DR64_DIAG=1 build of conv64_resident.hip) for the stamp table; skipped if absent.
+#   bash tools/record_evidence.sh [tag]     -> everything under gpurun_out/evidence/
+# Then copy what should be judged into profiles/ as <tag>_* (see profiles/README.md).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/evidence
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+G="grep -v amdgpu.ids"
+# --- the headline line (default flags) and the same command under the kernel trace.  The traced run uses ONE eval lane
+#     (SUBREG_EVAL_LANES=1): with two lanes kernels of both lanes overlap and per-kernel durations are inflated; with one lane
+#     sum(kernel time of the forward kernels) / images reproduces roofline.frac of ITS OWN bench line (bench_lanes1.json)
 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_bench -o b -- python3 $R/bench.py --no-cpu-baseline --sweep-seeds 0 > $O/bench_profiled.json 2> /dev/null
+SUBREG_EVAL_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_bench -o b -- python3 $R/bench.py --no-cpu-baseline --sweep-seeds 0 > $O/bench_lanes1.json 2> /dev/null
 f=$(find /tmp/ev_bench -name "*kernel_stats.csv" | head -1); cut -c1-140 "$f" > $O/kernel_stats.csv
 f=$(find /tmp/ev_bench -name "*kernel_trace.csv" | head -1); python3 $R/tools/prof_summary.py "$f" --top 25 --conv > $O/kernel_summary.txt 2>&1
-for b in 256 700 1125; do python3 $R/tools/bench_conv.py --batch $b 2>&1 | grep -v amdgpu.ids > $O/conv_layers_b$b.txt; done
-python3 $R/tools/bench_conv.py --batch 256 --dtype f32 2>&1 | grep -v amdgpu.ids > $O/conv_layers_f32.txt
-SUBREG_NO_RESIDENT64=1 python3 $R/tools/bench_conv.py --batch 700 --only L1.conv 2>&1 | grep -v amdgpu.ids > $O/conv_l1_general_kernel_b700.txt
-python3 $R/tools/bench_forward.py --lanes 1,2,3 2>&1 | grep -v amdgpu.ids > $O/forward_lanes.txt
+# --- per-layer conv table (HIP events, random data, 20 back-to-back launches per layer)
+for b in 256 700 1125; do python3 $R/tools/bench_conv.py --batch $b 2>&1 | $G > $O/conv_layers_b$b.txt; done
+python3 $R/tools/bench_conv.py --batch 700 --unfused --only L1 2>&1 | $G > $O/conv_l1_unfused_b700.txt
+python3 $R/tools/bench_conv.py --batch 700 --im2col --only L1 2>&1 | $G > $O/conv_l1_im2col_b700.txt
+python3 $R/tools/bench_conv.py --batch 256 --dtype f32 2>&1 | $G > $O/conv_layers_f32.txt
+# --- whole forward, A/B of this round's layer-1 changes within one box
+for v in "" SUBREG_NO_FUSED12=1 SUBREG_IM2COL_FIRST=1; do
+  echo "== ${v:-production}" >> $O/forward_ab_layer1.txt
+  env $v python3 $R/tools/bench_forward.py --lanes 2 --batches 250,500,750,1125 2>&1 | $G >> $O/forward_ab_layer1.txt
+done
+python3 $R/tools/bench_forward.py --lanes 1,2,3 2>&1 | $G > $O/forward_lanes.txt
+# --- HBM traffic of the conv stack (separate --pmc passes, counters only with --kernel-trace)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/ev_fetch -o f -- python3 $R/tools/bench_conv.py --batch 256 --iters 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/ev_write -o w -- python3 $R/tools/bench_conv.py --batch 256 --iters 3 > /dev/null 2>&1
 ff=$(find /tmp/ev_fetch -name "*counter_collection.csv" | head -1); fw=$(find /tmp/ev_write -name "*counter_collection.csv" | head -1)
 (cd $R && python3 tools/traffic_summary.py "$ff" "$fw" 256 bf16 > $O/traffic_layers.txt 2>&1; cp profiles/traffic.json $O/traffic.json)
-python3 $R/tools/bench_train.py --steps 20 2>&1 | grep -v amdgpu.ids > $O/train_step.txt
-python3 $R/tools/bench_train.py --steps 20 --batch 128 2>&1 | grep -v amdgpu.ids >> $O/train_step.txt
+# --- HBM-bound kernels: streaming rates of the box, then the element-wise / BN kernels against them
+$R/tools/probes/stream_bw 1024 > $O/stream_bw.txt 2>&1
+python3 $R/tools/bench_elementwise.py 2>&1 | $G > $O/hbm_kernels.txt
+# --- pretraining step
+python3 $R/tools/bench_train.py --steps 20 2>&1 | $G > $O/train_step.txt
+python3 $R/tools/bench_train.py --steps 20 --batch 128 2>&1 | $G >> $O/train_step.txt
+python3 $R/tools/bench_train.py --steps 20 --batch 8 2>&1 | $G >> $O/train_step.txt
+python3 $R/tools/bench_train.py --steps 10 --batch 512 2>&1 | $G >> $O/train_step.txt
 rocprofv3 --kernel-trace --output-format csv -d /tmp/ev_train -o t -- python3 $R/tools/bench_train.py --steps 10 > /dev/null 2>&1
-f=$(find /tmp/ev_train -name "*kernel_trace.csv" | head -1); python3 $R/tools/prof_summary.py "$f" --top 25 > $O/train_kernel_summary.txt 2>&1
+f=$(find /tmp/ev_train -name "*kernel_trace.csv" | head -1); python3 $R/tools/prof_summary.py "$f" --top 30 > $O/train_kernel_summary.txt 2>&1
+# --- SQ / GRBM counters of four layers
+bash $R/tools/pmc_layers.sh > $O/pmc_raw.txt 2>&1
+# --- multi-rank paths on the one GPU
 python3 $R/tools/dp_pretrain_check.py 2>&1 | grep -v "amdgpu.ids\|Gloo\|socket.cpp" > $O/dp_pretrain_check.txt
 python3 $R/tools/dp_check.py 2>&1 | grep -v "amdgpu.ids\|Gloo\|socket.cpp" > $O/dp_check.txt
-if [ -f $R/subspace-reg_amd/subreg_hip/libsubreg_diag.so ]; then
-  SUBREG_LIB=$R/subspace-reg_amd/subreg_hip/libsubreg_diag.so python3 $R/tools/diag_r64.py 256 2>&1 | grep -v amdgpu.ids > $O/conv64_stamps.txt
-fi
-cd $R && python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
+python3 $R/tools/rccl_smoke.py 2>&1 | grep -v "amdgpu.ids" > $O/rccl_single_rank_smoke.txt
 echo evidence done

@@ -20,7 +20,7 @@ from bench_conv import LAYERS  # noqa: E402
 def per_dispatch(path, counter):
     d = OrderedDict()
     for r in csv.DictReader(open(path)):
-        if not any(k in r["Kernel_Name"] for k in ("conv_fwd_kernel", "conv64_resident_kernel", "conv64_wide_kernel", "conv_first_kernel")) or r["Counter_Name"] != counter:
+        if not any(k in r["Kernel_Name"] for k in ("conv_fwd_kernel", "conv64_resident_kernel", "conv64_wide_kernel", "conv_first_kernel", "conv64_fused_first_kernel")) or r["Counter_Name"] != counter:
             continue
         d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
     return [d[k] for k in sorted(d)]
