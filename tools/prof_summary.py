@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV: per kernel (short name) and, for the conv kernels, per launch geometry
-(= per layer shape).  Usage: prof_summary.py <kernel_trace.csv> [--top N] [--conv]"""
+(= per layer shape).  Usage: prof_summary.py <kernel_trace.csv> [--top N] [--conv] [--images N]"""
 import csv
 import re
 import sys
@@ -39,6 +39,14 @@ def main():
     print("total kernel time %.1f ms" % (total * 1e-3))
     for n, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:top]:
         print("%-64s calls %6d  total %9.1f us  avg %9.1f us  %5.1f%%" % (n[:64], c, t, t / c, 100 * t / total))
+    if "--images" in sys.argv:
+        # roofline.frac of bench.py from the trace alone: the forward's kernels (conv family + avgpool) over the images forwarded
+        # in the traced process (warm-up included).  Only meaningful for a ONE-lane run (SUBREG_EVAL_LANES=1): two lanes overlap.
+        n_img = float(sys.argv[sys.argv.index("--images") + 1])
+        fwd = sum(t for n, (c, t) in per.items() if n.startswith(("conv", "avgpool")))
+        tf = n_img * 8.1219e9 / (fwd * 1e-6) / 1e12
+        print("forward kernels (conv*, avgpool): %.1f ms over %.0f images -> %.1f TFLOP/s algorithmic = %.4f of the 2500 TFLOP/s bf16 peak"
+              % (fwd * 1e-3, n_img, tf, tf / 2500.0))
     if "--conv" in sys.argv:
         print("\nconv launches by geometry (grid_m x grid_n, vgpr, agpr, lds):")
         for k, (c, t) in sorted(geo.items(), key=lambda kv: -kv[1][1])[:40]:
