@@ -55,7 +55,7 @@ template <> struct KT<float> {
 // its finer tiles let the B fragments ring-pipeline (+15..30 % on the 10x10 / 5x5 layers); 32 (v_mfma_f32_32x32x16_bf16)
 // for the 64-row wave tiles (+5..10 % at batch 350-500 over the 16x16 shape).  f32: 32 (v_mfma_f32_32x32x2_f32).
 template <typename T> constexpr int mfma_tile(int NI, int NJ) {
-    return (SUBREG_BF16_MFMA16 && sizeof(T) == 2 && NI == 1 && NJ == 5) ? 16 : 32;
+    return (SUBREG_BF16_MFMA16 && sizeof(T) == 2 && (NI == 1 || SUBREG_BF16_MFMA16 >= 2) && NJ == 5) ? 16 : 32;   // (2: measurement builds)
 }
 
 struct ConvArgs {
