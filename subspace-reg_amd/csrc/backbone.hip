@@ -147,7 +147,10 @@ extern "C" int subreg_backbone_forward(const subreg_backbone_desc* d, const floa
             const bool img_in = direct && i == 0;
             // layer 1 from the image: conv1 + conv2 in one launch where the fused kernel takes the shape, else conv1 by itself
             int fused = SUBREG_EUNSUPPORTED;
-            if (img_in && b.conv2.cin == 64 && b.conv2.cout == 64)
+            // (below ~190 images per call the fused kernel - one workgroup per CU owning the CU's whole LDS - loses to the two
+            // launches, whose workgroups share CUs with the other eval lane's kernels: -3 % at 125 images per lane, +0.5 % at 250,
+            // +1.2 % at 375; profiles/r03_forward_ab_layer1.txt)
+            if (img_in && b.conv2.cin == 64 && b.conv2.cout == 64 && B >= 192)
                 fused = subreg_conv12_first_fused(x_nchw, b.conv1.w_folded, b.conv1.shift, b.conv2.w_folded, b.conv2.shift, Bf, B, h, w,
                                                   SUBREG_CONV_LRELU, dt, stream);
             if (fused != SUBREG_OK) {

@@ -283,7 +283,7 @@ struct StepArgs {
 };
 
 // phase A: grid = Bs+Bm row blocks (+2 norm blocks): logits, softmax-CE, dlogits, argmax
-__global__ __launch_bounds__(256) void step_rows_kernel(const StepArgs a) {
+__global__ __launch_bounds__(512) void step_rows_kernel(const StepArgs a) {
     __shared__ float s_logit[MAX_CLS];
     __shared__ double red[17];
     if (a.st->stop) return;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void step_rows_kernel(const StepArgs a) {
 }
 
 // phase B: grid = N class-row blocks: dW row, regulariser gradients, SGD(momentum, wd) update in place
-__global__ __launch_bounds__(256) void step_update_kernel(const StepArgs a) {
+__global__ __launch_bounds__(1024) void step_update_kernel(const StepArgs a) {
     __shared__ float s_dl[2048];
     __shared__ float s_c[MAX_BASE];
     __shared__ double red[17];
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void step_finish_kernel(const StepArgs a) {
 }
 
 // validation: one block per query row: argmax == label -> integer counter for (epoch slot, set)
-__global__ __launch_bounds__(256) void validate_kernel(const float* __restrict__ feat, const long long* __restrict__ labels,
+__global__ __launch_bounds__(512) void validate_kernel(const float* __restrict__ feat, const long long* __restrict__ labels,
                                                         const float* __restrict__ W, int N, int D,
                                                         subreg_loop_state* st, int* __restrict__ correct, int set_index,
                                                         int n_sets_max, int is_last_set) {
@@ -474,7 +474,7 @@ struct ValidateSets {
     int n_sets;
     int end[SUBREG_MAX_QUERY_SETS];      // exclusive prefix sums of the sets' row counts
 };
-__global__ __launch_bounds__(256) void validate_sets_kernel(const float* __restrict__ feat, const long long* __restrict__ labels,
+__global__ __launch_bounds__(512) void validate_sets_kernel(const float* __restrict__ feat, const long long* __restrict__ labels,
                                                              const float* __restrict__ W, int N, int D, subreg_loop_state* st,
                                                              int* __restrict__ correct, int* __restrict__ correct5, int n_sets_max,
                                                              const ValidateSets vs) {
@@ -691,7 +691,7 @@ extern "C" int subreg_validate_sets(const float* feat, const long long* labels, 
         vs.end[j] = total;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(validate_sets_kernel, total, 256, 0, s, feat, labels, weight, N, D, state, correct, correct_top5, n_sets_max, vs);
+    hipLaunchKernelGGL(validate_sets_kernel, total, 512, 0, s, feat, labels, weight, N, D, state, correct, correct_top5, n_sets_max, vs);
     if (mark_done && state) hipLaunchKernelGGL(validate_mark_kernel, 1, 64, 0, s, state);
     return launch_status();
 }
@@ -751,8 +751,13 @@ extern "C" int subreg_finetune_step(const subreg_step_desc* d, void* stream) {
     a.stable_mode = d->stable_mode; a.target_loss = d->target_loss; a.eps = d->convergence_eps;
     hipStream_t s = (hipStream_t)stream;
     const int Bt = a.Bs + a.Bm;
-    hipLaunchKernelGGL(step_rows_kernel, Bt + 2, 256, 0, s, a);
-    hipLaunchKernelGGL(step_update_kernel, a.N, 256, 0, s, a);
+    // These launches are latency-bound (one short dependent chain per wave): more waves per block shorten the chains without
+    // changing any per-element arithmetic - 8 waves share a row's classes (4 passes of 4 classes instead of 7 at 100 classes),
+    // and one thread per feature dimension in the update (640 threads: one pass over the support rows instead of 2.5).
+    hipLaunchKernelGGL(step_rows_kernel, Bt + 2, 512, 0, s, a);
+    int ut = (a.D + 63) / 64 * 64;
+    ut = ut < 256 ? 256 : (ut > 1024 ? 1024 : ut);
+    hipLaunchKernelGGL(step_update_kernel, a.N, ut, 0, s, a);
     hipLaunchKernelGGL(step_finish_kernel, 1, 256, 0, s, a);
     return launch_status();
 }
@@ -763,7 +768,7 @@ extern "C" int subreg_validate(const float* feat, const long long* labels, const
     SUBREG_CHECK_ARG(feat && labels && weight && correct && B > 0 && N > 0 && N <= MAX_CLS && D > 0);
     SUBREG_CHECK_ARG(set_index >= 0 && set_index < n_sets_max);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(validate_kernel, B, 256, 0, s, feat, labels, weight, N, D, state, correct, set_index, n_sets_max, mark_done);
+    hipLaunchKernelGGL(validate_kernel, B, 512, 0, s, feat, labels, weight, N, D, state, correct, set_index, n_sets_max, mark_done);
     if (mark_done && state) hipLaunchKernelGGL(validate_mark_kernel, 1, 64, 0, s, state);
     return launch_status();
 }

@@ -102,7 +102,7 @@ def build_case(g, dtype, embed_dir=None):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw84_M", "hw32_sem", "hw32_map", "hw84_noM_s8", "hw84_noM_disc",
-                                 "hw84_stop"])
+                                 "hw84_stop", "hw84_sem", "hw84_map"])
 def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
     """hw84_noM_s8 is the bench-scale case (BASELINE.json configs[1]: 8 sessions, -M, 84x84, 1000-image base batch) with 6
     epochs per session, so the per-epoch hipGraph is captured and replayed and up to 1125 images go through one launch
@@ -110,7 +110,9 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
     hw84_noM_disc / hw84_stop are the DISCRIMINATING 84x84 goldens (tools/make_golden.py loop84d): 30 epochs x 2 sessions and a
     run that ends on the stable-epochs rule (language_eval.py:298-318) at epoch 48 of 80; their session accuracies sit at
     58-80 % and the base accuracy falls 95 -> 40 -> 20 %, with the wrong answers wrong by construction (hard_queries), so the
-    bf16 gate on them is ONE query image."""
+    bf16 gate on them is ONE query image.  hw84_sem / hw84_map: the semantic subspace regularizer and the linear-mapping target
+    (scripts/continual/slurm_semantic_subspace_reg.sh, slurm_linear_mapping.sh) on the same kind of episodes at 84x84, 30 epochs,
+    with the reference's own word vectors."""
     from subreg_hip.incremental import few_shot_finetune_incremental_test
     g = np.load(os.path.join(GOLDEN, "loop_%s.npz" % tag))
     net, opt, meta, base_loader, bsl, inits, picks = build_case(g, dtype, str(tmp_path / "word_embeds"))
@@ -273,7 +275,8 @@ _ORACLE_351 = {}
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_fused_loop_351_base_classes_against_oracle(dtype):
+@pytest.mark.parametrize("scale", [(32, 2, 3)], ids=["hw32"])     # ((84, 1, 2) works too: ~6 minutes of NumPy oracle for accuracies at chance)
+def test_fused_loop_351_base_classes_against_oracle(dtype, scale):
     """BASELINE.json configs[4]: tieredImageNet-sized base set (351 classes, train_supervised.py:94), +M, 2 sessions x 3 epochs at
     32x32.  The reference cannot run this configuration (eval_incremental.py:82-83 raises), so parity is against the NumPy
     restatement of its loop (oracle/loop_ref.py, pinned by the 60-class goldens) with n_base = 351.  Both weightings of the
@@ -283,20 +286,23 @@ def test_fused_loop_351_base_classes_against_oracle(dtype):
     from oracle.resnet_ref import ResNetRef, copy_state_dict
     from subreg_hip.incremental import few_shot_finetune_incremental_test
     from subreg_hip.resnet_language import create_model
-    NB, hw, ns, seed, signal = 351, 32, 2, 9, 3.0
-    for follow in (False, True):
-        opt = make_opt(set_seed=seed, neval_episodes=ns, memory_replay=1, hip_dtype=dtype, max_novel_epochs=3,
+    # hw84: the same configuration at the reference's image size (one session, 476 support + exemplar images per forward, the
+    # production 84x84 kernels incl. the fused layer 1); one weighting only (the NumPy oracle needs ~2 minutes for it)
+    hw, ns, n_epochs = scale
+    NB, seed, signal = 351, 9, 3.0
+    for follow in ((False, True) if hw == 32 else (True,)):
+        opt = make_opt(set_seed=seed, neval_episodes=ns, memory_replay=1, hip_dtype=dtype, max_novel_epochs=n_epochs,
                        dataset="tieredImageNet", avg_weights_follow_n_base=follow)
         sd = syn.make_state_dict(40, n_cls=NB)
         sessions = syn.make_sessions(seed, ns, hw, class_signal=signal, first_novel=NB)
         bx, by = syn.make_base_batch(seed, 64, hw, n_base=NB, class_signal=signal)
         sx, sy = syn.make_base_support(seed, hw, n_base=NB, class_signal=signal)
         inits = syn.make_novel_inits(seed, ns)
-        picks = [np.array([1]), np.array([3])]
-        if follow not in _ORACLE_351:      # the oracle run does not depend on the HIP dtype: once per weighting, not per parameter
-            _ORACLE_351[follow] = loop_ref.run_incremental(ResNetRef(copy_state_dict(sd)), sessions, (bx, by), opt, inits,
+        picks = [np.array([1]), np.array([3])][:ns]
+        if (hw, follow) not in _ORACLE_351:      # the oracle run does not depend on the HIP dtype: once per weighting, not per parameter
+            _ORACLE_351[(hw, follow)] = loop_ref.run_incremental(ResNetRef(copy_state_dict(sd)), sessions, (bx, by), opt, inits,
                                                            base_support=(sx, sy), masks=MaskSource(77), memory_picks=picks, n_base=NB)
-        want = _ORACLE_351[follow]
+        want = _ORACLE_351[(hw, follow)]
         net = create_model("resnet18", NB, opt, dataset="tieredImageNet")
         net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
         net = net.cuda()
@@ -314,7 +320,7 @@ def test_fused_loop_351_base_classes_against_oracle(dtype):
         f32 = dtype == "f32"
         assert run["classifier_weight"].shape == (NB + 5 * ns, 640)
         for s in range(ns):
-            assert run["epochs"][s] == want["epochs"][s] == 3
+            assert run["epochs"][s] == want["epochs"][s] == n_epochs
             _cmp("loss s%d" % s, run["loss"][s], want["loss"][s], 2e-4 if f32 else 5e-2, 2e-4 if f32 else 2e-2)
             _cmp("val acc s%d" % s, run["test_acc"][s], want["test_acc"][s], 1e-6 if f32 else 200.0 / 125 + 1e-6, 0)
             # validate's top-5 (language_eval.py:40); among 351+ classes it separates from top-1

@@ -268,9 +268,11 @@ def test_softmax_ce_kernel_matches_torch_and_reference_accuracy():
         assert cnt.tolist() == [int(correct[:1].sum()), int(correct[:5].sum())], (B, N, cnt.tolist())
 
 
-def test_pretrain_driver_runs_the_reference_routine(tmp_path):
+@pytest.mark.parametrize("hw", [32, 84])
+def test_pretrain_driver_runs_the_reference_routine(tmp_path, hw):
     """train_supervised.py:150-202 over the HIP train step: LR schedule applied, loss falls on a small fixed batch set,
-    periodic + last checkpoints are written in the reference's format and reload into an identical model."""
+    periodic + last checkpoints are written in the reference's format and reload into an identical model.  84x84 is the
+    reference's image size (the streaming dW kernel, 42x42 / 21x21 maps and the 21 -> 10 floor pooling only occur there)."""
     import argparse
     from subreg_hip import checkpoint as ck, pretrain as pt
     from subreg_hip.resnet_language import create_model
@@ -284,7 +286,7 @@ def test_pretrain_driver_runs_the_reference_routine(tmp_path):
     net = net.cuda()
     rs = np.random.RandomState(2)
     ys = [torch.from_numpy(rs.randint(0, 10, size=16)) for _ in range(3)]
-    batches = [(torch.from_numpy((rs.standard_normal((16, 3, 32, 32)) + y.numpy()[:, None, None, None] * 0.5).astype(np.float32)), y,
+    batches = [(torch.from_numpy((rs.standard_normal((16, 3, hw, hw)) + y.numpy()[:, None, None, None] * 0.5).astype(np.float32)), y,
                 torch.arange(16)) for y in ys]
 
     class _DS(list):

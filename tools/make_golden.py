@@ -601,6 +601,16 @@ def main():
         # ... and one that ENDS ON THE STABLE-EPOCHS RULE (language_eval.py:298-318) at 84x84
         gen_loop("hw84_stop", 84, 1, False, 100, seed=9, signal=0.3, proto_grid=3, hard_queries=5, centre=True, base_norm=2.0,
                  max_novel_epochs=80, learning_rate=0.15, stable_epochs=3, convergence_epsilon=4e-2)
+    if "loop84sem" in what:
+        # the semantic subspace regularizer and the linear-mapping target (scripts/continual/slurm_semantic_subspace_reg.sh,
+        # slurm_linear_mapping.sh) at 84x84 on the discriminating episodes, with the reference's own word vectors (~10 + ~3 min).
+        # label_pull 0.03 (the scripts sweep it): at 1.0 the constant semantic target holds the novel rows and nothing is learned
+        # in 30 epochs on these episodes (novel accuracy 0-2 %)
+        gen_loop("hw84_sem", 84, 2, False, 100, seed=10, signal=0.3, proto_grid=3, hard_queries=5, centre=True, base_norm=2.0,
+                 max_novel_epochs=30, learning_rate=0.15, label_pull=0.03, real_names=True, attraction_override=None, temperature=3.0)
+        gen_loop("hw84_map", 84, 1, False, 100, seed=11, signal=0.3, proto_grid=3, hard_queries=5, centre=True, base_norm=2.0,
+                 max_novel_epochs=30, learning_rate=0.15, label_pull=0.03, real_names=True, mapping_seed=78,
+                 attraction_override="mapping_linear_label2image")
     if "loop84s8" in what:
         # bench-scale case (BASELINE.json configs[1]): 8 sessions, -M, 84x84, 1000-image base batch; 6 epochs per
         # session so that the build's loop captures and replays its per-epoch hipGraph (~25 min of torch-CPU here)
