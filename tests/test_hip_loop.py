@@ -306,10 +306,20 @@ def test_fused_loop_351_base_classes_against_oracle(dtype, scale):
         sx, sy = syn.make_base_support(seed, hw, n_base=NB, class_signal=signal)
         inits = syn.make_novel_inits(seed, ns)
         picks = [np.array([1]), np.array([3])][:ns]
-        if (hw, follow) not in _ORACLE_351:      # the oracle run does not depend on the HIP dtype: once per weighting, not per parameter
-            _ORACLE_351[(hw, follow)] = loop_ref.run_incremental(ResNetRef(copy_state_dict(sd)), sessions, (bx, by), opt, inits,
-                                                           base_support=(sx, sy), masks=MaskSource(77), memory_picks=picks, n_base=NB)
-        want = _ORACLE_351[(hw, follow)]
+        # ONE oracle run (~100 s of NumPy) for both HIP dtypes and both weightings: the weighting only enters the running average
+        # (language_eval.py:383-393: the rounded (w1 * base + w2 * novel) / (w1 + w2)), which is recomputed here from the oracle's
+        # un-rounded per-session values for the other weighting
+        if hw not in _ORACLE_351:
+            _ORACLE_351[hw] = loop_ref.run_incremental(ResNetRef(copy_state_dict(sd)), sessions, (bx, by), opt, inits,
+                                                       base_support=(sx, sy), masks=MaskSource(77), memory_picks=picks, n_base=NB)
+            _ORACLE_351[hw]["_follow"] = follow
+        want = dict(_ORACLE_351[hw])
+        if want.pop("_follow") != follow:
+            wa = [want["weighted_avg"][0]]                            # (the entry before session 1 is the base accuracy alone)
+            for k in range(ns):
+                w1, w2 = (NB, 5 * (k + 1)) if follow else (200, NB + 5 * (k + 1) - 60)
+                wa.append(round((w1 * want["base_vals"][k] + w2 * want["novel_vals"][k]) / (w1 + w2), 2))
+            want["weighted_avg"] = wa
         net = create_model("resnet18", NB, opt, dataset="tieredImageNet")
         net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
         net = net.cuda()
