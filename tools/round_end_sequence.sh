@@ -33,7 +33,7 @@ step() {   # name, command...
   say "step [$name]: rc=$rc wall=$(( t1 - t0 )) ms   | $(grep -v amdgpu.ids $O/res_$name.log | tail -1 | cut -c1-200)"
   probe $name
 }
-say "round-end sequence, mode=$MODE repeat=$REPEAT, $(date -u +%FT%TZ), head $(cat $R/.git_head 2>/dev/null)"
+say "round-end sequence, mode=$MODE repeat=$REPEAT, $(date -u +%FT%TZ)"
 probe start
 for it in $(seq 1 $REPEAT); do
   say "== pass $it"
