@@ -400,6 +400,7 @@ def main():
                      "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": traffic,
                      "kernel": "conv_fwd_kernel family over %d backbone forwards (%.1f ms each)" % (n_fwd, fwd_ms / max(n_fwd, 1))},
         "images_per_s": imgs * world / dt,
+        "epochs_per_s": args.steps * world * args.epochs / dt,     # fine-tune epochs (forward + step + validation) per second, SURVEY.md 8d
     }
     del runners, r
     if rank == 0:                                              # the headline is on record before any extra leg starts
