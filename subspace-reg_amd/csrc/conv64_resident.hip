@@ -27,6 +27,9 @@ namespace subreg {
 #ifndef R64_DEPTH
 #define R64_DEPTH 4     // A-fragment reads in flight ahead of the MFMA that consumes them (+1)
 #endif
+#ifndef R64_FUSED_STAGGER
+#define R64_FUSED_STAGGER 1     // conv64_fused_first_kernel: waves 4-7 run conv1 of the next tile AFTER their conv2 chunks (0: all waves first)
+#endif
 #ifndef R64_DIAG
 #define R64_DIAG 0      // 1: per-wave s_memtime stamps of the tile loop's phases into r64_diag (measurement builds only)
 #endif
@@ -679,7 +682,9 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
             tile_geom(t + 2 * nslot, b2, k2);
             dma_patch(b2, k2);                                         // lands while this tile computes
         }
-        if (more) conv1_tile(nk, pp ^ 1);
+        // conv1 of the next tile needs nothing from this tile (its own plane pair, its own patch): the two waves of a SIMD (w and
+        // w + 4) run it at opposite ends of the tile, so one wave's VALU / LDS-heavy conv1 phase meets its partner's MFMA chunks
+        if (more && (wid < 4 || !R64_FUSED_STAGGER)) conv1_tile(nk, pp ^ 1);
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -740,6 +745,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (R64_FUSED_STAGGER && more && wid >= 4) conv1_tile(nk, pp ^ 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's patch pieces of tile t + 2 landed (and its stores)
         __syncthreads();                                               // every wave: conv1 read the bf16 patch, every patch piece landed
         if (more2) convert_patch();
