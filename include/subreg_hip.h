@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUBREG_ABI_VERSION 4
+#define SUBREG_ABI_VERSION 5
 
 #define SUBREG_OK 0
 #define SUBREG_EINVAL (-1)       /* bad argument (null pointer, shape not supported by contract) */
@@ -314,6 +314,12 @@ typedef struct subreg_step_desc {
     float target_loss, convergence_eps;
     const float* pull_target; /* [n_classes - n_old][dim] CONSTANT pullers of this session's novel rows (semantic subspace
                                * regularizer / linear mapping, LangPuller.forward :75-87), or NULL: project onto `basis` */
+    /* optimiser (eval/util.py:92-102 `get_optim`): 0 = SGD(lr, momentum, weight_decay) with momentum_buf; 1 = torch.optim.Adam
+     * (lr, betas, eps, weight_decay as L2 added to the gradient; --adam): momentum_buf is exp_avg, exp_avg_sq its second moment
+     * (both zero-initialised per session), the step count is state->epoch + 1 */
+    int adam;
+    float beta1, beta2, adam_eps;
+    float* exp_avg_sq;       /* [n_classes][dim], required with adam */
 } subreg_step_desc;
 
 /* the validation of ALL query sets so far (language_eval.py:321-326: one `validate` call over the list of sets) in one

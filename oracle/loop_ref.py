@@ -166,10 +166,23 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
                     l, g = sr.loss1_and_grad(opt.label_pull, base_weight, W[n_old:])
                 loss = f32(loss + f32(l))
                 grad[n_old:] += g
-            # ---- SGD step (torch.optim.SGD: wd added to grad, momentum buffer), :293-295
-            g32 = grad.astype(f32) + f32(opt.weight_decay) * W
-            buf = g32.copy() if buf is None else f32(opt.momentum) * buf + g32
-            W = (W - f32(opt.learning_rate) * buf).astype(f32)
+            if getattr(opt, "adam", False):
+                # ---- torch.optim.Adam(lr, weight_decay=0.0005) (eval/util.py:93-96; defaults betas (0.9, 0.999), eps 1e-8):
+                #      L2 term added to the gradient, bias-corrected moments, scalar factors in double like Python
+                g32 = grad.astype(f32) + f32(0.0005) * W
+                if buf is None:
+                    buf, buf2, t_adam = np.zeros_like(W), np.zeros_like(W), 0
+                t_adam += 1
+                buf = (buf + (g32 - buf) * f32(1.0 - 0.9)).astype(f32)
+                buf2 = (buf2 * f32(0.999) + f32(1.0 - 0.999) * g32 * g32).astype(f32)
+                bc1, bc2 = 1.0 - 0.9 ** t_adam, 1.0 - 0.999 ** t_adam
+                denom = (np.sqrt(buf2) / f32(np.sqrt(bc2)) + f32(1e-8)).astype(f32)
+                W = (W - f32(opt.learning_rate / bc1) * (buf / denom)).astype(f32)
+            else:
+                # ---- SGD step (torch.optim.SGD: wd added to grad, momentum buffer), :293-295
+                g32 = grad.astype(f32) + f32(opt.weight_decay) * W
+                buf = g32.copy() if buf is None else f32(opt.momentum) * buf + g32
+                W = (W - f32(opt.learning_rate) * buf).astype(f32)
             net.sd["classifier.weight"] = W
             # ---- stop rule, :298-318
             lv = float(loss)

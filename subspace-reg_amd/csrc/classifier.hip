@@ -280,6 +280,9 @@ struct StepArgs {
     float* train_acc;       // [max_epochs]
     int max_epochs, min_epochs, stable_epochs, stable_mode;
     float target_loss, eps;
+    int adam;               // 0: SGD(momentum, wd); 1: torch.optim.Adam (mom = exp_avg, mom2 = exp_avg_sq)
+    float beta1, beta2, adam_eps;
+    float* mom2;
 };
 
 // phase A: grid = Bs+Bm row blocks (+2 norm blocks): logits, softmax-CE, dlogits, argmax
@@ -390,9 +393,24 @@ __global__ __launch_bounds__(1024) void step_update_kernel(const StepArgs a) {
             g -= 2.f * a.pull * r;
         }
         g += a.wd * w;
-        const float m = first ? g : a.momentum * a.mom[(size_t)n * D + d] + g;
-        a.mom[(size_t)n * D + d] = m;
-        wr[d] = w - a.lr * m;
+        if (!a.adam) {
+            const float m = first ? g : a.momentum * a.mom[(size_t)n * D + d] + g;
+            a.mom[(size_t)n * D + d] = m;
+            wr[d] = w - a.lr * m;
+        } else {
+            // torch.optim.Adam, single-tensor form: exp_avg.lerp_(g, 1 - b1); exp_avg_sq = b2 * v + (1 - b2) g^2;
+            // denom = sqrt(v) / sqrt(1 - b2^t) + eps; p -= (lr / (1 - b1^t)) * exp_avg / denom   (scalars in double, like Python)
+            const size_t e = (size_t)n * D + d;
+            const float m0 = first ? 0.f : a.mom[e], v0 = first ? 0.f : a.mom2[e];
+            const float m = m0 + (g - m0) * (1.f - a.beta1);
+            const float v = v0 * a.beta2 + (1.f - a.beta2) * g * g;
+            a.mom[e] = m;
+            a.mom2[e] = v;
+            const double t = (double)(a.st->epoch + 1);
+            const double bc1 = 1.0 - pow((double)a.beta1, t), bc2 = 1.0 - pow((double)a.beta2, t);
+            const float denom = sqrtf(v) / (float)sqrt(bc2) + a.adam_eps;
+            wr[d] = w - (float)((double)a.lr / bc1) * (m / denom);
+        }
     }
     l1 = block_sum(l1, red);
     if (threadIdx.x == 0) a.rowl1[n] = novel ? (float)((double)a.pull * l1) : 0.f;
@@ -749,6 +767,8 @@ extern "C" int subreg_finetune_step(const subreg_step_desc* d, void* stream) {
     a.st = d->state; a.losses = d->losses; a.train_acc = d->train_acc;
     a.max_epochs = d->max_epochs; a.min_epochs = d->min_epochs; a.stable_epochs = d->stable_epochs;
     a.stable_mode = d->stable_mode; a.target_loss = d->target_loss; a.eps = d->convergence_eps;
+    a.adam = d->adam; a.beta1 = d->beta1; a.beta2 = d->beta2; a.adam_eps = d->adam_eps; a.mom2 = d->exp_avg_sq;
+    SUBREG_CHECK_ARG(!d->adam || d->exp_avg_sq);
     hipStream_t s = (hipStream_t)stream;
     const int Bt = a.Bs + a.Bm;
     // These launches are latency-bound (one short dependent chain per wave): more waves per block shorten the chains without

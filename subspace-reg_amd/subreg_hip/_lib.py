@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SUBREG_LIB") or os.path.join(_HERE, "libsubreg_hip.so
 F32, BF16 = 0, 1
 CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
 FWD_TRAIN = 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_QUERY_SETS = 32                          # SUBREG_MAX_QUERY_SETS
 
 c_void_p, c_int, c_float, c_longlong = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -69,7 +69,8 @@ class StepDesc(C.Structure):
                 ("dlogits", c_void_p), ("rowloss", c_void_p), ("rowcorrect", c_void_p), ("norms", c_void_p),
                 ("rowl1", c_void_p), ("state", c_void_p), ("losses", c_void_p), ("train_acc", c_void_p),
                 ("max_epochs", c_int), ("min_epochs", c_int), ("stable_epochs", c_int), ("stable_mode", c_int),
-                ("target_loss", c_float), ("convergence_eps", c_float), ("pull_target", c_void_p)]
+                ("target_loss", c_float), ("convergence_eps", c_float), ("pull_target", c_void_p),
+                ("adam", c_int), ("beta1", c_float), ("beta2", c_float), ("adam_eps", c_float), ("exp_avg_sq", c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/subreg_hip.h declares

@@ -58,7 +58,8 @@ class _SessionBuffers:
         self.train_acc = torch.zeros(max_epochs, dtype=f32, device=dev)
         self.correct = torch.zeros((max_epochs + 1) * n_sets, dtype=i32, device=dev)
         self.correct5 = torch.zeros((max_epochs + 1) * n_sets, dtype=i32, device=dev)   # top-5 hits (validate :40, never used by the loop)
-        self.mom = torch.zeros(n_cls * dim, dtype=f32, device=dev)
+        self.mom = torch.zeros(n_cls * dim, dtype=f32, device=dev)      # SGD momentum buffer / Adam exp_avg
+        self.mom2 = torch.zeros(n_cls * dim, dtype=f32, device=dev)     # Adam exp_avg_sq (--adam, eval/util.py:93-96)
 
 
 class IncrementalRunner:
@@ -84,8 +85,6 @@ class IncrementalRunner:
         self.dp = row_shard if (row_shard is not None and row_shard.size > 1) else None
         if net.classifier.bias is not None:
             raise NotImplementedError("fused loop assumes --no_linear_bias backbones (slurm_run_backbone.sh:39)")
-        if getattr(opt, "adam", False):
-            raise NotImplementedError("fused step implements SGD(momentum) (eval/util.py:98-101)")
         if int(getattr(opt, "freeze_backbone_at", 1)) != 1:
             # language_eval.py:247-249 trains the backbone with SGD until epoch == freeze_backbone_at; every script passes 1
             raise NotImplementedError("freeze_backbone_at=%r: the fused loop keeps the backbone frozen from epoch 1 "
@@ -258,6 +257,11 @@ class IncrementalRunner:
         d.pull_target = self.pullers.data_ptr() if self.pull_mode == "target" else None
         d.n_base, d.n_prev, d.n_old = self.n_base, (reserve.shape[0] if use_prev else 0), n_old
         d.lr, d.momentum, d.weight_decay = opt.learning_rate, opt.momentum, opt.weight_decay
+        if getattr(opt, "adam", False):                 # get_optim (eval/util.py:92-97): Adam(lr, weight_decay=0.0005), torch defaults
+            d.adam, d.beta1, d.beta2, d.adam_eps, d.weight_decay = 1, 0.9, 0.999, 1e-8, 0.0005
+            d.exp_avg_sq = ses.mom2.data_ptr()
+        else:
+            d.adam, d.exp_avg_sq = 0, None
         d.lmbd_base = opt.lmbd_reg_transform_w or 0.0
         d.lmbd_prev = opt.lmbd_reg_novel or 0.0
         d.pull = opt.label_pull or 0.0

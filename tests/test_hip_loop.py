@@ -102,7 +102,7 @@ def build_case(g, dtype, embed_dir=None):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw84_M", "hw32_sem", "hw32_map", "hw84_noM_s8", "hw84_noM_disc",
-                                 "hw84_stop", "hw84_sem", "hw84_map"])
+                                 "hw84_stop", "hw84_sem", "hw84_map", "hw32_adam"])
 def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
     """hw84_noM_s8 is the bench-scale case (BASELINE.json configs[1]: 8 sessions, -M, 84x84, 1000-image base batch) with 6
     epochs per session, so the per-epoch hipGraph is captured and replayed and up to 1125 images go through one launch
@@ -112,7 +112,7 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
     58-80 % and the base accuracy falls 95 -> 40 -> 20 %, with the wrong answers wrong by construction (hard_queries), so the
     bf16 gate on them is ONE query image.  hw84_sem / hw84_map: the semantic subspace regularizer and the linear-mapping target
     (scripts/continual/slurm_semantic_subspace_reg.sh, slurm_linear_mapping.sh) on the same kind of episodes at 84x84, 30 epochs,
-    with the reference's own word vectors."""
+    with the reference's own word vectors.  hw32_adam: `--adam` (eval/util.py:92-97, torch.optim.Adam instead of SGD), +M, 3 sessions."""
     from subreg_hip.incremental import few_shot_finetune_incremental_test
     g = np.load(os.path.join(GOLDEN, "loop_%s.npz" % tag))
     net, opt, meta, base_loader, bsl, inits, picks = build_case(g, dtype, str(tmp_path / "word_embeds"))

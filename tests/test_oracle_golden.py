@@ -140,7 +140,7 @@ def _loop_setup(g):
     opt = SimpleNamespace(n_ways=5, n_shots=5, learning_rate=0.002, momentum=0.9, weight_decay=5e-4,
                           lmbd_reg_transform_w=0.2, lmbd_reg_novel=0.1, label_pull=1.0, max_novel_epochs=1000,
                           min_novel_epochs=20, target_train_loss=0.0, convergence_epsilon=1e-4, stable_epochs=10,
-                          memory_replay=1 if memory else 0)
+                          memory_replay=1 if memory else 0, adam=False)
     for k in g.files:
         if k.startswith("opt."):
             setattr(opt, k[4:], g[k].item())
@@ -169,7 +169,7 @@ def _embed_kwargs(g):
     return kw
 
 
-@pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw32_sem", "hw32_map"])
+@pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw32_sem", "hw32_map", "hw32_adam"])
 def test_loop_against_reference(tag):
     g = _load("loop_%s.npz" % tag)
     sd, opt, sessions, base, bsup, inits, mseed, picks = _loop_setup(g)

@@ -32,6 +32,7 @@ sys.path.insert(0, REF)
 torch.Tensor.cuda = lambda self, *a, **k: self
 torch.nn.Module.cuda = lambda self, *a, **k: self
 torch.cuda.is_available = lambda: True
+torch.cuda.is_current_stream_capturing = lambda: False    # torch.optim.Adam asks this whenever is_available() says True (--adam golden)
 os.chdir(REF)
 
 import models.resnet_language as rl          # noqa: E402  (the reference)
@@ -565,7 +566,7 @@ def gen_train_step():
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["blocks", "backbone", "reg", "train", "loop32", "semantic", "episodes", "loop84"]
+    what = sys.argv[1:] or ["blocks", "backbone", "reg", "train", "loop32", "adam", "semantic", "episodes", "loop84"]
     if "blocks" in what:
         gen_blocks()
     if "backbone" in what:
@@ -580,6 +581,9 @@ def main():
         # data-dependent stop: loose epsilon + short stable window so the stable rule fires before the cap
         gen_loop("hw32_stop", 32, 2, True, 40, seed=3, max_novel_epochs=40, stable_epochs=3,
                  convergence_epsilon=2e-2)
+    if "adam" in what:
+        # --adam (eval/util.py:92-97: torch.optim.Adam(lr, weight_decay=0.0005) instead of SGD), +M, three sessions
+        gen_loop("hw32_adam", 32, 3, True, 40, seed=13, max_novel_epochs=5, adam=True)
     if "semantic" in what:
         gen_semantic()
         gen_loop("hw32_sem", 32, 3, True, 40, seed=5, max_novel_epochs=4, real_names=True, attraction_override=None,
