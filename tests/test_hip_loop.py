@@ -159,6 +159,11 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
         # (measured: <= 2.0e-2 on hw84_noM_disc, 3.5e-2 on ONE of 41600 elements of hw84_map)
         wmax = float(np.abs(g["final_classifier"]).max())
         tol_bf16 = 5e-2 * wmax if discriminating else 5e-3
+        if "opt.adam" in g.files and bool(g["opt.adam"]):
+            # Adam divides by sqrt(v): an element whose gradient is within bf16 feature noise of zero moves by +-lr per step
+            # either way, so two correct implementations can differ by 2 * lr per epoch on it (measured: 23 of 48000 elements
+            # up to 9.2e-3 after 5 epochs at lr 0.002); fp32 stays at 1e-4
+            tol_bf16 = 2.0 * float(g["opt.learning_rate"] if "opt.learning_rate" in g.files else 0.002) * int(g["opt.max_novel_epochs"])
         _cmp("final classifier", run["classifier_weight"], g["final_classifier"], 1e-4 if f32 else tol_bf16, 1e-4 if f32 else 5e-3)
         if discriminating and not f32:
             dw = run["classifier_weight"].astype(np.float64) - g["final_classifier"].astype(np.float64)
