@@ -213,7 +213,7 @@ def test_layer1_conv3_with_the_shortcut_fed_from_the_image(shape):
     assert d <= 2.0 ** -7 * float(np.abs(want).max()), d            # same products, another accumulation order: <= 1 bf16 ulp
 
 
-@pytest.mark.parametrize("shape", [(2, 84, 84), (41, 84, 84), (3, 83, 84), (2, 10, 80), (1, 85, 84)])
+@pytest.mark.parametrize("shape", [(2, 84, 84), (41, 84, 84), (3, 83, 84), (2, 10, 80), (1, 85, 84), (563, 84, 84)])
 def test_layer1_conv1_conv2_fused_from_the_image(shape):
     """conv1 + BN + LeakyReLU + conv2 + BN + LeakyReLU of layer1.0 (models/resnet_language.py:249-253) in ONE launch, the
     64-channel intermediate kept in LDS (conv64_resident.hip::conv64_fused_first_kernel), against the oracle (which rounds the
@@ -227,17 +227,20 @@ def test_layer1_conv1_conv2_fused_from_the_image(shape):
     w2 = _round_bf16((rs.standard_normal((64, 64, 3, 3)) * (1.4 / np.sqrt(576))).astype(np.float32))
     sc1 = rs.uniform(0.5, 1.5, 64).astype(np.float32)
     sh1, sh2 = (rs.standard_normal(64) * 0.3).astype(np.float32), (rs.standard_normal(64) * 0.3).astype(np.float32)
-    w1q = _round_bf16(w1 * sc1[:, None, None, None])
-    mid = rr.leaky_relu(rr.conv_nhwc(rr._nhwc(_round_bf16(x)).astype(np.float64), w1q.astype(np.float64)) + sh1)
-    mid = _round_bf16(mid.astype(np.float32)).astype(np.float64)               # the intermediate is bf16 in LDS
-    want = rr.leaky_relu(rr.conv_nhwc(mid, w2.astype(np.float64)) + sh2)
     xd, w1d, w2d, sh1d, sh2d = _t(x), _pack_w_first(w1, sc1), _pack_w(w2, "bf16"), _t(sh1), _t(sh2)
     y = torch.full((B * H * W * 64,), float("nan"), dtype=torch.bfloat16, device=_dev())
     _lib.check(lib.subreg_conv12_first_fused(_lib.ptr(xd), _lib.ptr(w1d), _lib.ptr(sh1d), _lib.ptr(w2d), _lib.ptr(sh2d), _lib.ptr(y), B, H, W,
                                              _lib.CONV_LRELU, _lib.BF16, _lib.stream_ptr()), "conv12_first_fused")
-    got = _nchw_host(y, B, 64, H, W, "bf16")
-    a, r = _tol("bf16", np.abs(want).max())
-    _cmp("conv1+conv2 fused", got, rr._nchw(want), a, r)
+    wmax = 4.0
+    if B <= 64:                    # (the 563-image case - every workgroup walks ~15 tiles, as in the benchmark - is checked against
+        w1q = _round_bf16(w1 * sc1[:, None, None, None])         # the two-launch route only: the NumPy oracle would need minutes)
+        mid = rr.leaky_relu(rr.conv_nhwc(rr._nhwc(_round_bf16(x)).astype(np.float64), w1q.astype(np.float64)) + sh1)
+        mid = _round_bf16(mid.astype(np.float32)).astype(np.float64)               # the intermediate is bf16 in LDS
+        want = rr.leaky_relu(rr.conv_nhwc(mid, w2.astype(np.float64)) + sh2)
+        got = _nchw_host(y, B, 64, H, W, "bf16")
+        a, r = _tol("bf16", np.abs(want).max())
+        _cmp("conv1+conv2 fused", got, rr._nchw(want), a, r)
+        wmax = float(np.abs(want).max())
     # two launches: conv1 from the image, then the 64 -> 64 kernel
     y1 = torch.empty(B * H * W * 64, dtype=torch.bfloat16, device=_dev())
     y2 = torch.full_like(y, float("nan"))
@@ -246,8 +249,9 @@ def test_layer1_conv1_conv2_fused_from_the_image(shape):
     _lib.check(lib.subreg_conv_fwd(_lib.ptr(y1), _lib.ptr(w2d), _lib.ptr(y2), None, _lib.ptr(sh2d), None, None, None, None, 0, B, H, W, 64, 64, 3,
                                    _lib.CONV_LRELU, _lib.BF16, _lib.stream_ptr()))
     torch.cuda.synchronize()
+    assert bool(torch.isfinite(y.float()).all())
     d = (y.float() - y2.float()).abs().max().item()
-    assert d <= 2.0 ** -7 * float(np.abs(want).max()), d            # same products, another accumulation order: <= 1 bf16 ulp
+    assert d <= 2.0 ** -7 * max(wmax, float(y2.float().abs().max())), d            # same products, another accumulation order: <= 1 bf16 ulp
     assert lib.subreg_conv12_first_fused(_lib.ptr(xd), _lib.ptr(w1d), _lib.ptr(sh1d), _lib.ptr(w2d), _lib.ptr(sh2d), _lib.ptr(y), B, 32, 32,
                                          _lib.CONV_LRELU, _lib.BF16, _lib.stream_ptr()) != 0     # 32x32: refused, not mis-computed
 
