@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-// block = 16 channels x 16 slice lanes: the slices of a channel are summed by 16 threads (fixed order, fp64), not by one.
+// block = 8 channels x 32 slice lanes: the slices of a channel are summed by 32 threads (fixed order, fp64), eight 16-byte
+// loads in flight each - 512 slices are two round trips (the 16 x 16 rolled form was 32 dependent ones, 11 us per BatchNorm).
 // Also emits the three per-channel coefficients of the apply pass:
 //   dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N) = k1*g + k2*raw + k3,
 //   k1 = gamma*invstd, k2 = -k1*invstd*dgamma/N, k3 = k1*(mean*invstd*dgamma - dbeta)/N.
@@ -182,20 +183,27 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
                                                               const float* __restrict__ gamma, double inv_n,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef) {
-    __shared__ double red[2][16][17];
-    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    __shared__ double red[2][32][9];
+    constexpr int UN = 8;
+    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
     double t1 = 0.0, t2 = 0.0;
     if (c < C)
-        for (int s = sl; s < slices; s += 16) {
-            t1 += partial[((size_t)s * C + c) * 2];
-            t2 += partial[((size_t)s * C + c) * 2 + 1];
+        for (int s0 = sl; s0 < slices; s0 += 32 * UN) {
+            double2 v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int s = s0 + u * 32;
+                v[u] = s < slices ? *reinterpret_cast<const double2*>(partial + ((size_t)s * C + c) * 2) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) { t1 += v[u].x; t2 += v[u].y; }
         }
     red[0][sl][cl] = t1;
     red[1][sl][cl] = t2;
     __syncthreads();
     if (sl == 0 && c < C) {
         t1 = 0.0; t2 = 0.0;
-        for (int l = 0; l < 16; ++l) { t1 += red[0][l][cl]; t2 += red[1][l][cl]; }
+        for (int l = 0; l < 32; ++l) { t1 += red[0][l][cl]; t2 += red[1][l][cl]; }
         dbeta[c] = (float)t1;
         dgamma[c] = (float)t2;
         const double is = invstd[c], k1 = (double)gamma[c] * is;
@@ -595,6 +603,30 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
     }
 }
 
+// 3x3 form of the same: for one output channel the packed [9][Cin] block and the OIHW [Cin][9] block are the same contiguous
+// 9*Cin floats, transposed.  Block = (output channel, chunk of CK input channels): coalesced reads of CK floats per tap and
+// split (fixed split order => deterministic), transpose through LDS, ONE contiguous 36*CK-byte write - the element-wise
+// kernel above writes 4 bytes every 36 (1.5 TB/s on the 640 x 640 layers, a third of what the streams sustain).
+template <int CK>
+__global__ __launch_bounds__(256) void unpack_wgrad3x3_kernel(const float* __restrict__ gw, float* __restrict__ grad, int Cout, int Cin,
+                                                              int splits) {
+    __shared__ float t[9][CK + 1];
+    const int o = blockIdx.x, c0 = blockIdx.y * CK;
+    const size_t n = (size_t)Cout * 9 * Cin;
+    const float* src = gw + ((size_t)o * 9) * Cin + c0;
+    for (int e = threadIdx.x; e < 9 * CK; e += 256) {
+        const int tap = e / CK, c = e % CK;
+        const float* q = src + (size_t)tap * Cin + c;
+        float v = 0.f;
+#pragma unroll 4
+        for (int sp = 0; sp < splits; ++sp) v += q[(size_t)sp * n];
+        t[tap][c] = v;
+    }
+    __syncthreads();
+    float* dst = grad + ((size_t)o * Cin + c0) * 9;
+    for (int e = threadIdx.x; e < 9 * CK; e += 256) dst[e] = t[e % 9][e / 9];
+}
+
 // OIHW fp32 -> dgrad operand: the forward weight layout [taps][Cout/32][Cin][32] T of the transposed conv (output
 // channels = Cin, reduction over Cout) with the taps flipped: dX = conv(dY, this)
 template <typename T>
@@ -803,7 +835,7 @@ extern "C" int subreg_bn_bwd(const void* dy, const void* act, const void* raw, c
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, slices, 256, lds, s, (const float*)dy, (const float*)act, (const float*)raw, mean, invstd, partial, npix, C, (int)pps),
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, slices, 256, lds, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, partial, npix, C, (int)pps));
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, (C + 15) / 16, 256, 0, s, partial, slices, C, mean, invstd, gamma, 1.0 / (double)npix,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, (C + 7) / 8, 256, 0, s, partial, slices, C, mean, invstd, gamma, 1.0 / (double)npix,
                        dgamma, dbeta, coef);
     long long ppb = (npix + 4095) / 4096;                   // apply pass: ~4096 blocks, whole unrolled rounds of the pixel lanes
     ppb = (ppb + 4 * lanes_ - 1) / (4 * lanes_) * (4 * lanes_);
@@ -896,6 +928,14 @@ extern "C" int subreg_unpack_wgrad(const float* gw_packed, float* grad_oihw, int
     SUBREG_CHECK_ARG(gw_packed && grad_oihw && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3) && splits >= 1);
     SUBREG_CHECK_ARG(mode == 0 || (mode == 1 && Cin == 3));
     const size_t n = mode == 0 ? (size_t)Cout * Cin * ksize * ksize : (size_t)Cout * 32;
+    // few splits: the scattered 4-byte writes dominate -> transposing kernel; many splits (layers 1-3: 16...370 partial copies):
+    // the coalesced split reads dominate and the element-wise kernel spreads them over 8 split lanes
+    if (mode == 0 && ksize == 3 && Cin % 32 == 0 && splits <= 8) {
+        if (Cin % 160 == 0) hipLaunchKernelGGL(unpack_wgrad3x3_kernel<160>, dim3(Cout, Cin / 160), dim3(256), 0, (hipStream_t)stream, gw_packed, grad_oihw, Cout, Cin, splits);
+        else if (Cin % 64 == 0) hipLaunchKernelGGL(unpack_wgrad3x3_kernel<64>, dim3(Cout, Cin / 64), dim3(256), 0, (hipStream_t)stream, gw_packed, grad_oihw, Cout, Cin, splits);
+        else hipLaunchKernelGGL(unpack_wgrad3x3_kernel<32>, dim3(Cout, Cin / 32), dim3(256), 0, (hipStream_t)stream, gw_packed, grad_oihw, Cout, Cin, splits);
+        return launch_status();
+    }
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, (hipStream_t)stream, gw_packed, grad_oihw,
                        Cout, Cin, ksize, mode, splits);
     return launch_status();

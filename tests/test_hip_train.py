@@ -67,7 +67,7 @@ def test_conv_wgrad_and_dgrad(shape, dtype):
     _cmp("dX", got, rr._nchw(dx_ref), tol * np.abs(dx_ref).max(), tol)
 
 
-@pytest.mark.parametrize("shape", [(64, 84, 84, 64, 64, 3), (64, 42, 42, 160, 160, 3), (64, 10, 10, 640, 640, 3)])
+@pytest.mark.parametrize("shape", [(64, 84, 84, 64, 64, 3), (64, 42, 42, 160, 160, 3), (64, 10, 10, 640, 640, 3), (64, 10, 10, 320, 640, 3)])
 def test_conv_wgrad_pretrain_batch(shape):
     """The streaming bf16 dW kernel at the pretraining batch (B = 64, train_supervised.py:205-268): its K = pixels split runs
     over ~2048 workgroups there, which the small cases above never reach.  Oracle: dW only (nine [O, pixels] x [pixels, C]
@@ -441,7 +441,10 @@ def test_fused_sgd_keeps_momentum_of_earlier_unfused_steps():
         torch.cuda.synchronize()
         after.append({n: p.detach().cpu().numpy() for n, p in net.named_parameters()})
     for n in after[0]:
-        _cmp("momentum carried " + n, after[0][n], after[1][n], 1e-5 * max(float(np.abs(after[1][n]).max()), 1e-3), 1e-5)
+        # not 1e-5: the 1x1 / first-layer dW kernels add with float atomics, so the two runs' first steps differ in the last bit
+        # and that can flip a bf16 rounding in the second forward (seen once in ~6 suite runs).  Lost momentum would be
+        # lr * 0.9 * |g| = 4.5e-2 |g| on every parameter - two orders of magnitude above this gate.
+        _cmp("momentum carried " + n, after[0][n], after[1][n], 1e-3 * max(float(np.abs(after[1][n]).max()), 1e-3), 1e-3)
 
 
 def _hip_stash_as_oracle_input(net, B, hw):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV: per kernel (short name) and, for the conv kernels, per launch geometry
-(= per layer shape).  Usage: prof_summary.py <kernel_trace.csv> [--top N] [--conv] [--images N]"""
+(= per layer shape).  Usage: prof_summary.py <kernel_trace.csv> [--top N] [--conv] [--images N] [--timeline N]
+(--timeline N: the last N launches in start order with duration, gap to the previous kernel's end and grid)"""
 import csv
 import re
 import sys
@@ -22,6 +23,19 @@ def short(name):
 
 def main():
     path = sys.argv[1]
+    if "--timeline" in sys.argv:
+        n = int(sys.argv[sys.argv.index("--timeline") + 1])
+        rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))[-n:]
+        prev, t0, busy = None, int(rows[0]["Start_Timestamp"]), 0.0
+        for r in rows:
+            s0, e0 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            gap = (s0 - prev) * 1e-3 if prev is not None else 0.0
+            busy += (e0 - s0) * 1e-3
+            print("%9.1f us  +%7.1f us  gap %6.1f  grid %6d x%-3d  %s" % ((s0 - t0) * 1e-3, (e0 - s0) * 1e-3, gap,
+                  int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), short(r["Kernel_Name"])[:70]))
+            prev = max(prev or 0, e0)
+        print("span %.1f us, kernel time %.1f us" % ((prev - t0) * 1e-3, busy))
+        return
     top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 25
     per, geo = defaultdict(lambda: [0, 0.0]), defaultdict(lambda: [0, 0.0])
     total = 0.0
