@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUBREG_ABI_VERSION 5
+#define SUBREG_ABI_VERSION 6
 
 #define SUBREG_OK 0
 #define SUBREG_EINVAL (-1)       /* bad argument (null pointer, shape not supported by contract) */
@@ -305,7 +305,7 @@ typedef struct subreg_step_desc {
     float* dlogits;          /* scratch [n_support+n_memory][n_classes] */
     float* rowloss;          /* scratch [n_support+n_memory] */
     int* rowcorrect;         /* scratch [n_support+n_memory] */
-    float* norms;            /* scratch [2] */
+    float* norms;            /* scratch [3] */
     float* rowl1;            /* scratch [n_classes] */
     subreg_loop_state* state;
     float* losses;           /* [max_epochs] loss of every epoch (what the reference prints / the stop rule reads) */
@@ -320,6 +320,14 @@ typedef struct subreg_step_desc {
     int adam;
     float beta1, beta2, adam_eps;
     float* exp_avg_sq;       /* [n_classes][dim], required with adam */
+    /* classifier WITH bias (nn.Linear(640, n, bias=opt.linear_bias), resnet_language.py:140; eval_incremental.py:96-103 takes it
+     * from the checkpoint): logits + bias, regloss adds lmbd_base*||bias[:n_base] - bias_base||^2 (:231-232, squared), the bias is
+     * updated like any parameter.  All four NULL for a classifier without bias.  bias together with use_prev_reg is refused:
+     * reglossnovel (:238) indexes the 1-D bias with two indices and raises in the reference. */
+    float* bias;              /* [n_classes] classifier.bias, updated in place */
+    float* bias_momentum_buf; /* [n_classes] */
+    float* bias_exp_avg_sq;   /* [n_classes], required with adam */
+    const float* bias_base;   /* [n_base] frozen base bias (:106-107) */
 } subreg_step_desc;
 
 /* the validation of ALL query sets so far (language_eval.py:321-326: one `validate` call over the list of sets) in one
@@ -327,8 +335,8 @@ typedef struct subreg_step_desc {
  * correct[slot*n_sets_max + j] += hits of set j, as subreg_validate does per set; correct_top5 (same layout, may be NULL)
  * counts the rows whose label is among the five largest logits (eval/util.py:26-40, topk=(1, 5)) */
 #define SUBREG_MAX_QUERY_SETS 32
-int subreg_validate_sets(const float* feat, const long long* labels, const float* weight, const int* set_rows, int n_sets, int N,
-                         int D, subreg_loop_state* state, int* correct, int* correct_top5, int n_sets_max, int mark_done,
+int subreg_validate_sets(const float* feat, const long long* labels, const float* weight, const float* bias /* [N] or NULL */,
+                         const int* set_rows, int n_sets, int N, int D, subreg_loop_state* state, int* correct, int* correct_top5, int n_sets_max, int mark_done,
                          void* stream);
 /* nn.CrossEntropyLoss() (mean) + eval/util.py:26-40 accuracy counters of one batch: rowloss[B] (scratch, required with
  * loss), loss[1] = mean, dlogits[B][N] = (softmax - onehot)/B, correct[0] += #(label is the argmax),
@@ -348,7 +356,7 @@ int subreg_loop_state_init(subreg_loop_state* state, void* stream);
 int subreg_finetune_step(const subreg_step_desc* d, void* stream);
 /* validate (:18-43) / eval_base (:46-69): correct[slot*n_sets_max + set_index] += #(argmax == label), slot =
  * state->epoch (0 when state == NULL); skipped once the stopped loop's last epoch is recorded; mark_done records it */
-int subreg_validate(const float* feat, const long long* labels, const float* weight, int B, int N, int D,
+int subreg_validate(const float* feat, const long long* labels, const float* weight, const float* bias /* [N] or NULL */, int B, int N, int D,
                     subreg_loop_state* state, int* correct, int set_index, int n_sets_max, int mark_done, void* stream);
 
 #ifdef __cplusplus

@@ -3,8 +3,11 @@
 Follows /root/reference/eval/language_eval.py::few_shot_finetune_incremental_test (:71-454)
 with validate (:18-43), eval_base (:46-69) and the helpers of eval/util.py
 (accuracy :26-40, freeze_backbone_weights :62-69, get_optim :92-102 -> torch SGD).
-Only the `distance2subspace` regularizer and the plain-linear classifier without
-bias are restated (the configuration of scripts/continual/slurm_subspace_reg.sh:33-54).
+The plain-linear classifier is restated with and without bias (eval_incremental.py:96-103 takes the bias from the
+checkpoint; scripts/continual/slurm_run_backbone.sh:39 trains without).  With a bias: logits + b, regloss adds
+lmbd * ||b[:n_base] - b_base||**2 (resnet_language.py:231-232, squared unlike the weight term), the optimiser updates it like
+any parameter, and reglossnovel indexes the 1-D bias with two indices (:238) - an IndexError from session 2 on whenever
+--lmbd_reg_novel is given, restated as such.
 
 Semantics that parity depends on, all restated here:
   * net.train() once per session (:211); validate() switches to eval (:19) and
@@ -73,12 +76,16 @@ class _Bump:
 
 
 def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=None,
-                    masks=None, memory_picks=None, reuse_features=True, n_base=60, embeds=None, names=None, mapping=None):
+                    masks=None, memory_picks=None, reuse_features=True, n_base=60, embeds=None, names=None, mapping=None,
+                    novel_bias_inits=None):
     """Run `len(sessions)` incremental sessions.  Returns a dict of everything the goldens pin."""
     f32 = np.float32
     bump = _Bump(net)
     W = net.sd["classifier.weight"].astype(f32).copy()          # live classifier.weight
     base_weight = W.copy()                                      # basenet._get_base_weights(), :106-107
+    bvec = net.sd.get("classifier.bias")                        # live classifier.bias or None (--no_linear_bias)
+    bvec = None if bvec is None else np.asarray(bvec, f32).copy()
+    base_bias = None if bvec is None else bvec.copy()
     base_x, base_y = base_batch
     out = dict(loss=[], test_acc=[], test_acc_top5=[], acc_base=[], weighted_avg=[], epochs=[], novel_acc=[],
                memory_inds=[], train_acc=[], novel_vals=[], base_vals=[])
@@ -90,7 +97,7 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
     # initial base evaluation, :128
     net.sd["classifier.weight"] = W
     base_feat = eval_feats(base_x)
-    acc_b, _ = accuracy_top1(linear(base_feat, W), base_y)
+    acc_b, _ = accuracy_top1(linear(base_feat, W, bvec), base_y)
     out["weighted_avg"].append(acc_b)
 
     query_x, query_ids = [], []
@@ -127,7 +134,10 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
         net.train()                                                             # :211
         W = np.concatenate([W, np.asarray(novel_inits[idx], f32)], 0)           # augment_base_classifier_, :214
         net.sd["classifier.weight"] = W
-        buf = None                                                              # fresh SGD, :231
+        if bvec is not None:
+            bvec = np.concatenate([bvec, np.asarray(novel_bias_inits[idx], f32)])
+            net.sd["classifier.bias"] = bvec
+        buf = bbuf = None                                                       # fresh SGD, :231
         train_loss, epoch, stable, go = 15, 1, 0, True
         losses, feat_cache = [], {}
         while go:
@@ -142,19 +152,29 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
                 else:
                     bump(1 if mem_x is None else 2)
                 feat_s, feat_m = feat_cache["s"], feat_cache["m"]
-            logits = linear(feat_s, W)
+            logits = linear(feat_s, W, bvec)
             loss, dlog = cross_entropy(logits, sid)                              # :252-253
             grad = dlog.T @ feat_s.astype(np.float64)
+            gb = dlog.sum(axis=0)                                                # d loss / d bias (used when there is one)
             loss = f32(loss)
             if feat_m is not None:                                               # :256-258
-                l2, d2 = cross_entropy(linear(feat_m, W), mem_y)
+                l2, d2 = cross_entropy(linear(feat_m, W, bvec), mem_y)
                 loss = f32(loss + f32(l2))
                 grad += d2.T @ feat_m.astype(np.float64)
+                gb = gb + d2.sum(axis=0)
             if opt.lmbd_reg_transform_w is not None:                             # :261-265
                 l, g = sr.frob_reg_and_grad(opt.lmbd_reg_transform_w, W[:n_base], base_weight)
-                loss = f32(loss + f32(l))
+                l = f32(l)
+                if bvec is not None:                                             # resnet_language.py:231-232: + lmbd * norm(db)**2
+                    db = bvec[:n_base].astype(np.float64) - base_bias.astype(np.float64)
+                    nb_ = f32(np.sqrt((db * db).sum()))
+                    l = f32(l + f32(f32(opt.lmbd_reg_transform_w) * f32(nb_ * nb_)))
+                    gb[:n_base] += 2.0 * opt.lmbd_reg_transform_w * db
+                loss = f32(loss + l)
                 grad[:n_base] += g
             if opt.lmbd_reg_novel is not None and idx > 0:                       # :268-274
+                if bvec is not None:                                             # resnet_language.py:238 `bias[rng1:rng2, :]`
+                    raise IndexError("too many indices for tensor of dimension 1")
                 k = reserve.shape[0]
                 l, g = sr.frob_reg_and_grad(opt.lmbd_reg_novel, W[n_base:n_base + k], reserve)
                 loss = f32(loss + f32(l))
@@ -178,12 +198,26 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
                 bc1, bc2 = 1.0 - 0.9 ** t_adam, 1.0 - 0.999 ** t_adam
                 denom = (np.sqrt(buf2) / f32(np.sqrt(bc2)) + f32(1e-8)).astype(f32)
                 W = (W - f32(opt.learning_rate / bc1) * (buf / denom)).astype(f32)
+                if bvec is not None:
+                    gb32 = gb.astype(f32) + f32(0.0005) * bvec
+                    if bbuf is None:
+                        bbuf, bbuf2 = np.zeros_like(bvec), np.zeros_like(bvec)
+                    bbuf = (bbuf + (gb32 - bbuf) * f32(1.0 - 0.9)).astype(f32)
+                    bbuf2 = (bbuf2 * f32(0.999) + f32(1.0 - 0.999) * gb32 * gb32).astype(f32)
+                    bden = (np.sqrt(bbuf2) / f32(np.sqrt(bc2)) + f32(1e-8)).astype(f32)
+                    bvec = (bvec - f32(opt.learning_rate / bc1) * (bbuf / bden)).astype(f32)
             else:
                 # ---- SGD step (torch.optim.SGD: wd added to grad, momentum buffer), :293-295
                 g32 = grad.astype(f32) + f32(opt.weight_decay) * W
                 buf = g32.copy() if buf is None else f32(opt.momentum) * buf + g32
                 W = (W - f32(opt.learning_rate) * buf).astype(f32)
+                if bvec is not None:                                             # the bias is a parameter like any other
+                    gb32 = gb.astype(f32) + f32(opt.weight_decay) * bvec
+                    bbuf = gb32.copy() if bbuf is None else f32(opt.momentum) * bbuf + gb32
+                    bvec = (bvec - f32(opt.learning_rate) * bbuf).astype(f32)
             net.sd["classifier.weight"] = W
+            if bvec is not None:
+                net.sd["classifier.bias"] = bvec
             # ---- stop rule, :298-318
             lv = float(loss)
             if opt.target_train_loss == 0:
@@ -205,9 +239,9 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
                     bump()
                 else:
                     feat_cache[key] = net.features(xq)
-                a, _ = accuracy_top1(linear(feat_cache[key], W), yq)
+                a, _ = accuracy_top1(linear(feat_cache[key], W, bvec), yq)
                 test_acc.append(a)
-                test_acc5.append(accuracy_topk(linear(feat_cache[key], W), yq, 5))   # validate's acc5, language_eval.py:40
+                test_acc5.append(accuracy_topk(linear(feat_cache[key], W, bvec), yq, 5))   # validate's acc5, language_eval.py:40
             epoch += 1
         # ---- memory pick, :353-359
         if opt.memory_replay:
@@ -217,7 +251,7 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
             mem_y = sid[inds] if mem_y is None else np.concatenate([mem_y, sid[inds]], 0)
         # ---- base eval with the updated net, :363-367 (eval mode; BN stats may have moved)
         base_feat = net.features(base_x)
-        acc_b, _ = accuracy_top1(linear(base_feat, W), base_y)
+        acc_b, _ = accuracy_top1(linear(base_feat, W, bvec), base_y)
         test_acc = [round(a, 2) for a in test_acc]                               # :372
         ta = float(np.array(test_acc).mean())
         w1 = 60 if getattr(opt, "dataset", "miniImageNet") == "miniImageNet" else 200      # :383 (hard-coded class counts)
@@ -235,4 +269,5 @@ def run_incremental(net, sessions, base_batch, opt, novel_inits, base_support=No
         out["weighted_avg"].append(round((w1 * acc_b + w2 * ta) / (w1 + w2), 2))
         out["epochs"].append(epoch - 1)
     out["classifier_weight"] = W
+    out["classifier_bias"] = bvec
     return out

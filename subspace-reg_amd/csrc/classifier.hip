@@ -272,7 +272,7 @@ struct StepArgs {
     float* dlogits;         // [Bs+Bm][N]
     float* rowloss;         // [Bs+Bm] un-scaled CE per row
     int* rowcorrect;        // [Bs+Bm] argmax == label
-    float* norms;           // [2] ||W[:nb]-Wbase||, ||W[nb:nb+np]-Wprev||
+    float* norms;           // [3] ||W[:nb]-Wbase||, ||W[nb:nb+np]-Wprev||, ||b[:nb]-b_base|| (classifier with bias)
     float* rowl1;           // [N] pull*||P_n - w_n||^2 for the novel rows, 0 elsewhere
     const float* target;    // [N - n_old][D] constant pullers (semantic / mapping variants) or null (projection onto Q)
     subreg_loop_state* st;
@@ -283,6 +283,11 @@ struct StepArgs {
     int adam;               // 0: SGD(momentum, wd); 1: torch.optim.Adam (mom = exp_avg, mom2 = exp_avg_sq)
     float beta1, beta2, adam_eps;
     float* mom2;
+    // classifier WITH bias (nn.Linear(640, n, bias=opt.linear_bias), resnet_language.py:140): all null without
+    float* bias;            // [N] live classifier.bias (updated in place)
+    float* bmom;            // [N] its momentum buffer / exp_avg
+    float* bmom2;           // [N] Adam exp_avg_sq
+    const float* bias_base; // [n_base] base bias of regloss (:231-232)
 };
 
 // phase A: grid = Bs+Bm row blocks (+2 norm blocks): logits, softmax-CE, dlogits, argmax
@@ -313,9 +318,17 @@ __global__ __launch_bounds__(512) void step_rows_kernel(const StepArgs a) {
         }
         s = block_sum(s, red);
         if (threadIdx.x == 0) a.norms[which] = (float)sqrt(s);
+        if (which == 0 && a.bias) {            // regloss' bias term: lmbd * ||b[:nb] - b_base||**2 (resnet_language.py:231-232)
+            double sb = 0.0;
+            if (a.use_base && a.bias_base)
+                for (int i = threadIdx.x; i < a.n_base; i += blockDim.x) { const float d = a.bias[i] - a.bias_base[i]; sb += (double)d * d; }
+            __syncthreads();
+            sb = block_sum(sb, red);
+            if (threadIdx.x == 0) a.norms[2] = (float)sqrt(sb);
+        }
         return;
     }
-    row_logits(a.feat + (size_t)b * a.D, a.W, nullptr, a.N, a.D, s_logit);
+    row_logits(a.feat + (size_t)b * a.D, a.W, a.bias, a.N, a.D, s_logit);
     __syncthreads();
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
@@ -414,6 +427,33 @@ __global__ __launch_bounds__(1024) void step_update_kernel(const StepArgs a) {
     }
     l1 = block_sum(l1, red);
     if (threadIdx.x == 0) a.rowl1[n] = novel ? (float)((double)a.pull * l1) : 0.f;
+    if (!a.bias) return;
+    // the bias element of this class: d loss / d b[n] = sum_b dlogits[b][n] (+ 2*lmbd*(b - b_base), regloss :231-232), then the
+    // same optimiser update as a weight element (the bias is in net.parameters(): weight decay applies to it too)
+    double gs = 0.0;
+    for (int b = threadIdx.x; b < Bt; b += blockDim.x) gs += (double)s_dl[b];
+    __syncthreads();
+    gs = block_sum(gs, red);
+    if (threadIdx.x != 0) return;
+    const float bw = a.bias[n];
+    float g = (float)gs;
+    if (a.use_base && a.bias_base && n < a.n_base) g += 2.f * a.lmbd_base * (bw - a.bias_base[n]);
+    g += a.wd * bw;
+    if (!a.adam) {
+        const float m = first ? g : a.momentum * a.bmom[n] + g;
+        a.bmom[n] = m;
+        a.bias[n] = bw - a.lr * m;
+    } else {
+        const float m0 = first ? 0.f : a.bmom[n], v0 = first ? 0.f : a.bmom2[n];
+        const float m = m0 + (g - m0) * (1.f - a.beta1);
+        const float v = v0 * a.beta2 + (1.f - a.beta2) * g * g;
+        a.bmom[n] = m;
+        a.bmom2[n] = v;
+        const double t = (double)(a.st->epoch + 1);
+        const double bc1 = 1.0 - pow((double)a.beta1, t), bc2 = 1.0 - pow((double)a.beta2, t);
+        const float denom = sqrtf(v) / (float)sqrt(bc2) + a.adam_eps;
+        a.bias[n] = bw - (float)((double)a.lr / bc1) * (m / denom);
+    }
 }
 
 // phase C: one block: assemble the loss, train accuracy, stop rule
@@ -436,7 +476,11 @@ __global__ __launch_bounds__(256) void step_finish_kernel(const StepArgs a) {
     // same fp32 accumulation order as the reference: CE_s (+ CE_m) (+ regloss) (+ reglossnovel) (+ loss1)
     float loss = (float)(ces / (double)a.Bs);
     if (a.Bm > 0) loss += (float)(cem / (double)a.Bm);
-    if (a.use_base) loss += a.lmbd_base * a.norms[0];
+    if (a.use_base) {                          // reg = lmbd*norm(dW); reg += lmbd*norm(db)**2; loss += reg   (resnet_language.py:229-233)
+        float reg = a.lmbd_base * a.norms[0];
+        if (a.bias) reg += a.lmbd_base * (a.norms[2] * a.norms[2]);
+        loss += reg;
+    }
     if (a.use_prev) loss += a.lmbd_prev * a.norms[1];
     if (a.use_pull) loss += (float)l1;
     const int epoch = st->epoch + 1;           // 1-based epoch that just ran
@@ -458,7 +502,7 @@ __global__ __launch_bounds__(256) void step_finish_kernel(const StepArgs a) {
 
 // validation: one block per query row: argmax == label -> integer counter for (epoch slot, set)
 __global__ __launch_bounds__(512) void validate_kernel(const float* __restrict__ feat, const long long* __restrict__ labels,
-                                                        const float* __restrict__ W, int N, int D,
+                                                        const float* __restrict__ W, const float* __restrict__ bias, int N, int D,
                                                         subreg_loop_state* st, int* __restrict__ correct, int set_index,
                                                         int n_sets_max, int is_last_set) {
     __shared__ float s_logit[MAX_CLS];
@@ -468,7 +512,7 @@ __global__ __launch_bounds__(512) void validate_kernel(const float* __restrict__
         slot = st->epoch;
     }
     const int b = blockIdx.x;
-    row_logits(feat + (size_t)b * D, W, nullptr, N, D, s_logit);
+    row_logits(feat + (size_t)b * D, W, bias, N, D, s_logit);
     __syncthreads();
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
@@ -493,8 +537,8 @@ struct ValidateSets {
     int end[SUBREG_MAX_QUERY_SETS];      // exclusive prefix sums of the sets' row counts
 };
 __global__ __launch_bounds__(512) void validate_sets_kernel(const float* __restrict__ feat, const long long* __restrict__ labels,
-                                                             const float* __restrict__ W, int N, int D, subreg_loop_state* st,
-                                                             int* __restrict__ correct, int* __restrict__ correct5, int n_sets_max,
+                                                             const float* __restrict__ W, const float* __restrict__ bias, int N, int D,
+                                                             subreg_loop_state* st, int* __restrict__ correct, int* __restrict__ correct5, int n_sets_max,
                                                              const ValidateSets vs) {
     __shared__ float s_logit[MAX_CLS];
     int slot = 0;
@@ -505,7 +549,7 @@ __global__ __launch_bounds__(512) void validate_sets_kernel(const float* __restr
     const int b = blockIdx.x;
     int set = 0;
     while (set + 1 < vs.n_sets && b >= vs.end[set]) ++set;
-    row_logits(feat + (size_t)b * D, W, nullptr, N, D, s_logit);
+    row_logits(feat + (size_t)b * D, W, bias, N, D, s_logit);
     __syncthreads();
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
@@ -695,8 +739,8 @@ extern "C" int subreg_frob(const float* a, const float* b, long long n, float lm
     return launch_status();
 }
 
-extern "C" int subreg_validate_sets(const float* feat, const long long* labels, const float* weight, const int* set_rows, int n_sets,
-                                    int N, int D, subreg_loop_state* state, int* correct, int* correct_top5, int n_sets_max,
+extern "C" int subreg_validate_sets(const float* feat, const long long* labels, const float* weight, const float* bias,
+                                    const int* set_rows, int n_sets, int N, int D, subreg_loop_state* state, int* correct, int* correct_top5, int n_sets_max,
                                     int mark_done, void* stream) {
     SUBREG_CHECK_ARG(feat && labels && weight && correct && set_rows && N > 0 && N <= MAX_CLS && D > 0);
     SUBREG_CHECK_ARG(n_sets >= 1 && n_sets <= SUBREG_MAX_QUERY_SETS && n_sets <= n_sets_max);
@@ -709,7 +753,7 @@ extern "C" int subreg_validate_sets(const float* feat, const long long* labels, 
         vs.end[j] = total;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(validate_sets_kernel, total, 512, 0, s, feat, labels, weight, N, D, state, correct, correct_top5, n_sets_max, vs);
+    hipLaunchKernelGGL(validate_sets_kernel, total, 512, 0, s, feat, labels, weight, bias, N, D, state, correct, correct_top5, n_sets_max, vs);
     if (mark_done && state) hipLaunchKernelGGL(validate_mark_kernel, 1, 64, 0, s, state);
     return launch_status();
 }
@@ -769,6 +813,11 @@ extern "C" int subreg_finetune_step(const subreg_step_desc* d, void* stream) {
     a.stable_mode = d->stable_mode; a.target_loss = d->target_loss; a.eps = d->convergence_eps;
     a.adam = d->adam; a.beta1 = d->beta1; a.beta2 = d->beta2; a.adam_eps = d->adam_eps; a.mom2 = d->exp_avg_sq;
     SUBREG_CHECK_ARG(!d->adam || d->exp_avg_sq);
+    a.bias = d->bias; a.bmom = d->bias_momentum_buf; a.bmom2 = d->bias_exp_avg_sq; a.bias_base = d->bias_base;
+    SUBREG_CHECK_ARG(!d->bias || (d->bias_momentum_buf && (!d->adam || d->bias_exp_avg_sq) && (!d->use_base_reg || d->bias_base)));
+    // reglossnovel indexes the 1-D bias with two indices (resnet_language.py:238): the reference raises there, so there is
+    // nothing to compute - the host mirror raises the same IndexError before it gets here
+    SUBREG_CHECK_ARG(!(d->bias && d->use_prev_reg));
     hipStream_t s = (hipStream_t)stream;
     const int Bt = a.Bs + a.Bm;
     // These launches are latency-bound (one short dependent chain per wave): more waves per block shorten the chains without
@@ -782,13 +831,13 @@ extern "C" int subreg_finetune_step(const subreg_step_desc* d, void* stream) {
     return launch_status();
 }
 
-extern "C" int subreg_validate(const float* feat, const long long* labels, const float* weight, int B, int N, int D,
+extern "C" int subreg_validate(const float* feat, const long long* labels, const float* weight, const float* bias, int B, int N, int D,
                                subreg_loop_state* state, int* correct, int set_index, int n_sets_max, int mark_done,
                                void* stream) {
     SUBREG_CHECK_ARG(feat && labels && weight && correct && B > 0 && N > 0 && N <= MAX_CLS && D > 0);
     SUBREG_CHECK_ARG(set_index >= 0 && set_index < n_sets_max);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(validate_kernel, B, 512, 0, s, feat, labels, weight, N, D, state, correct, set_index, n_sets_max, mark_done);
+    hipLaunchKernelGGL(validate_kernel, B, 512, 0, s, feat, labels, weight, bias, N, D, state, correct, set_index, n_sets_max, mark_done);
     if (mark_done && state) hipLaunchKernelGGL(validate_mark_kernel, 1, 64, 0, s, state);
     return launch_status();
 }

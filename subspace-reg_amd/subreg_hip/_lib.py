@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SUBREG_LIB") or os.path.join(_HERE, "libsubreg_hip.so
 F32, BF16 = 0, 1
 CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
 FWD_TRAIN = 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_QUERY_SETS = 32                          # SUBREG_MAX_QUERY_SETS
 
 c_void_p, c_int, c_float, c_longlong = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -70,7 +70,8 @@ class StepDesc(C.Structure):
                 ("rowl1", c_void_p), ("state", c_void_p), ("losses", c_void_p), ("train_acc", c_void_p),
                 ("max_epochs", c_int), ("min_epochs", c_int), ("stable_epochs", c_int), ("stable_mode", c_int),
                 ("target_loss", c_float), ("convergence_eps", c_float), ("pull_target", c_void_p),
-                ("adam", c_int), ("beta1", c_float), ("beta2", c_float), ("adam_eps", c_float), ("exp_avg_sq", c_void_p)]
+                ("adam", c_int), ("beta1", c_float), ("beta2", c_float), ("adam_eps", c_float), ("exp_avg_sq", c_void_p),
+                ("bias", c_void_p), ("bias_momentum_buf", c_void_p), ("bias_exp_avg_sq", c_void_p), ("bias_base", c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/subreg_hip.h declares
@@ -95,7 +96,7 @@ SIGNATURES = {
     "subreg_pack_conv_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "subreg_conv_wgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "subreg_conv_wgrad_splits": (_I, [_I, _I, _I, _I, _I, _I, _I]),
-    "subreg_validate_sets": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P]),
+    "subreg_validate_sets": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P]),
     "subreg_softmax_ce": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "subreg_semantic_target": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P]),
     "subreg_semantic_target_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P]),
@@ -129,7 +130,7 @@ SIGNATURES = {
     "subreg_frob": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
     "subreg_loop_state_init": (_I, [_P, _P]),
     "subreg_finetune_step": (_I, [C.POINTER(StepDesc), _P]),
-    "subreg_validate": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
+    "subreg_validate": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
 }
 
 _lib = None

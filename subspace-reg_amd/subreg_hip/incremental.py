@@ -52,7 +52,7 @@ class _SessionBuffers:
         self.dlogits = torch.empty(n_rows * n_cls, dtype=f32, device=dev)
         self.rowloss = torch.empty(n_rows, dtype=f32, device=dev)
         self.rowcorrect = torch.empty(n_rows, dtype=i32, device=dev)
-        self.norms = torch.zeros(2, dtype=f32, device=dev)
+        self.norms = torch.zeros(3, dtype=f32, device=dev)
         self.rowl1 = torch.zeros(n_cls, dtype=f32, device=dev)
         self.losses = torch.zeros(max_epochs, dtype=f32, device=dev)
         self.train_acc = torch.zeros(max_epochs, dtype=f32, device=dev)
@@ -60,6 +60,8 @@ class _SessionBuffers:
         self.correct5 = torch.zeros((max_epochs + 1) * n_sets, dtype=i32, device=dev)   # top-5 hits (validate :40, never used by the loop)
         self.mom = torch.zeros(n_cls * dim, dtype=f32, device=dev)      # SGD momentum buffer / Adam exp_avg
         self.mom2 = torch.zeros(n_cls * dim, dtype=f32, device=dev)     # Adam exp_avg_sq (--adam, eval/util.py:93-96)
+        self.bmom = torch.zeros(n_cls, dtype=f32, device=dev)           # the same two for classifier.bias (when there is one)
+        self.bmom2 = torch.zeros(n_cls, dtype=f32, device=dev)
 
 
 class IncrementalRunner:
@@ -70,7 +72,7 @@ class IncrementalRunner:
 
     def __init__(self, net, meta_valloader, base_val_loader, opt, base_support_loader=None, novel_inits=None,
                  memory_picks=None, epochs_per_sync=8, reuse_features=False, verbose=True, profile=False, use_graph=True,
-                 ckpt=None, row_shard=None):
+                 ckpt=None, row_shard=None, novel_bias_inits=None):
         if getattr(opt, "track_weights", False) or getattr(opt, "save_preds_0", False):
             raise NotImplementedError("CSV tracking is outside the hot path (SURVEY.md section 8)")
         ao = getattr(opt, "attraction_override", None)
@@ -83,8 +85,9 @@ class IncrementalRunner:
         # intra-seed data parallelism (sweep.RowShard): eval-mode forwards are split over the ranks of a group that hold the
         # same backbone, features exchanged with one all-gather per forward; None / size 1 = this rank does everything
         self.dp = row_shard if (row_shard is not None and row_shard.size > 1) else None
-        if net.classifier.bias is not None:
-            raise NotImplementedError("fused loop assumes --no_linear_bias backbones (slurm_run_backbone.sh:39)")
+        # classifier with bias (eval_incremental.py:96-103: whatever the checkpoint holds): handled by the fused step; the one
+        # combination the reference itself cannot run is refused where the reference fails (run_session)
+        self.novel_bias_inits = novel_bias_inits
         if int(getattr(opt, "freeze_backbone_at", 1)) != 1:
             # language_eval.py:247-249 trains the backbone with SGD until epoch == freeze_backbone_at; every script passes 1
             raise NotImplementedError("freeze_backbone_at=%r: the fused loop keeps the backbone frozen from epoch 1 "
@@ -142,7 +145,9 @@ class IncrementalRunner:
         feat = self._forward_eval(self.base_x)
         cnt = torch.zeros(1, dtype=torch.int32, device=self.dev)
         W = self.net.classifier.weight.detach()
-        _lib.check(self.lib.subreg_validate(_lib.ptr(feat), _lib.ptr(self.base_y), _lib.ptr(W), feat.shape[0], W.shape[0],
+        bias = self.net.classifier.bias
+        _lib.check(self.lib.subreg_validate(_lib.ptr(feat), _lib.ptr(self.base_y), _lib.ptr(W),
+                                            _lib.ptr(bias.detach()) if bias is not None else None, feat.shape[0], W.shape[0],
                                             self.D, None, _lib.ptr(cnt), 0, 1, 0, _lib.stream_ptr()), "validate(base)")
         return _acc(int(cnt.item()), feat.shape[0])
 
@@ -156,6 +161,7 @@ class IncrementalRunner:
         self.D = net.classifier.weight.shape[1]
         self.base_weight = net.classifier.weight.detach().clone()                # :106-107
         self.n_base = self.base_weight.shape[0]
+        self.base_bias = net.classifier.bias.detach().clone() if net.classifier.bias is not None else None
         # regularizer of the novel rows (:216-227, :277-290): projection onto span(W_base) ('distance2subspace', basis of the
         # constant W_base computed once) or a per-session constant target from the word embeddings (LangPuller.forward)
         self.pull_mode = None
@@ -222,8 +228,11 @@ class IncrementalRunner:
         query_x, query_id = self.query_x, self.query_id
         net.train()                                                            # :211
         net.augment_base_classifier_(len(novel_labels), novel_weight=None if self.novel_inits is None
-                                     else torch.as_tensor(self.novel_inits[idx]))
+                                     else torch.as_tensor(self.novel_inits[idx]),
+                                     novel_bias=None if (self.novel_bias_inits is None or self.base_bias is None)
+                                     else torch.as_tensor(self.novel_bias_inits[idx]))
         W = net.classifier.weight.data                                         # live [N, D], updated in place by the step
+        bias = net.classifier.bias.data if net.classifier.bias is not None else None   # live [N]
         N = W.shape[0]
         sx = support_xs.to(dev, torch.float32)
         sid = sid.to(dev)
@@ -252,6 +261,10 @@ class IncrementalRunner:
         d.weight, d.momentum_buf = W.data_ptr(), ses.mom.data_ptr()
         d.w_base = self.base_weight.data_ptr()
         use_prev = opt.lmbd_reg_novel is not None and idx > 0
+        if use_prev and bias is not None:
+            # resnet_language.py:238 `self.classifier.bias[rng1:rng2, :]` on the 1-D bias: the reference's first epoch of
+            # session 2 dies here whenever the classifier has a bias and --lmbd_reg_novel is given
+            raise IndexError("too many indices for tensor of dimension 1")
         d.w_prev = reserve.data_ptr() if use_prev else None
         d.basis = self.basis.data_ptr() if self.basis is not None else None
         d.pull_target = self.pullers.data_ptr() if self.pull_mode == "target" else None
@@ -262,6 +275,10 @@ class IncrementalRunner:
             d.exp_avg_sq = ses.mom2.data_ptr()
         else:
             d.adam, d.exp_avg_sq = 0, None
+        if bias is not None:
+            d.bias, d.bias_momentum_buf, d.bias_base = bias.data_ptr(), ses.bmom.data_ptr(), self.base_bias.data_ptr()
+            d.bias_exp_avg_sq = ses.bmom2.data_ptr() if d.adam else None
+        bias_p = _lib.ptr(bias) if bias is not None else None
         d.lmbd_base = opt.lmbd_reg_transform_w or 0.0
         d.lmbd_prev = opt.lmbd_reg_novel or 0.0
         d.pull = opt.label_pull or 0.0
@@ -278,12 +295,12 @@ class IncrementalRunner:
         def step_and_validate():
             _lib.check(lib.subreg_finetune_step(C.byref(d), s()), "finetune_step")
             if n_sets <= _lib.MAX_QUERY_SETS:          # all query sets in one launch (rows and labels are consecutive)
-                _lib.check(lib.subreg_validate_sets(_lib.ptr(feats[q_off[0]:]), _lib.ptr(query_labels), _lib.ptr(W), set_rows,
+                _lib.check(lib.subreg_validate_sets(_lib.ptr(feats[q_off[0]:]), _lib.ptr(query_labels), _lib.ptr(W), bias_p, set_rows,
                                                     n_sets, N, D, _lib.ptr(ses.state), _lib.ptr(ses.correct), _lib.ptr(ses.correct5),
                                                     n_sets, 1, s()), "validate_sets")
                 return
             for j in range(n_sets):
-                _lib.check(lib.subreg_validate(_lib.ptr(feats[q_off[j]:]), _lib.ptr(query_id[j]), _lib.ptr(W),
+                _lib.check(lib.subreg_validate(_lib.ptr(feats[q_off[j]:]), _lib.ptr(query_id[j]), _lib.ptr(W), bias_p,
                                                query_x[j].shape[0], N, D, _lib.ptr(ses.state), _lib.ptr(ses.correct), j,
                                                n_sets, int(j == n_sets - 1), s()), "validate")
 
@@ -401,7 +418,8 @@ class IncrementalRunner:
     def finish(self):
         run, p = self.run, self.p
         run.update(weighted_avg=self.weighted_avg_l, novel_acc=self.acc_novel_list, acc_base=self.acc_base_list,
-                   classifier_weight=self.net.classifier.weight.detach().cpu().numpy(), basis_info=self.basis_info)
+                   classifier_weight=self.net.classifier.weight.detach().cpu().numpy(), basis_info=self.basis_info,
+                   classifier_bias=(self.net.classifier.bias.detach().cpu().numpy() if self.net.classifier.bias is not None else None))
         self.net.last_run = run
         p("Overall continual accuracies: ", self.weighted_avg_l)
         p("Novel only incremental: ", self.acc_novel_list)
@@ -411,9 +429,10 @@ class IncrementalRunner:
 
 def few_shot_finetune_incremental_test(net, ckpt, criterion, meta_valloader, base_val_loader, opt, vis=False,
                                        base_support_loader=None, *, novel_inits=None, memory_picks=None,
-                                       epochs_per_sync=8, reuse_features=False, verbose=True):
+                                       epochs_per_sync=8, reuse_features=False, verbose=True, novel_bias_inits=None):
     """Drop-in for the reference function.  Extra keyword-only arguments (all optional):
       novel_inits     list of [n_ways, 640] init rows passed to augment_base_classifier_(novel_weight=...)
+      novel_bias_inits  list of [n_ways] init values passed as novel_bias=... (classifier with bias only)
       memory_picks    list of np.random.choice(n_shots, memory_replay) results (else drawn from np.random)
       epochs_per_sync epochs queued per host synchronisation
       reuse_features  opt-in: compute the (constant) eval-mode features once per session
@@ -422,7 +441,7 @@ def few_shot_finetune_incremental_test(net, ckpt, criterion, meta_valloader, bas
     if vis:
         raise NotImplementedError("visualisation is outside the hot path (SURVEY.md section 8)")
     r = IncrementalRunner(net, meta_valloader, base_val_loader, opt, base_support_loader, novel_inits, memory_picks,
-                          epochs_per_sync, reuse_features, verbose, ckpt=ckpt).start()
+                          epochs_per_sync, reuse_features, verbose, ckpt=ckpt, novel_bias_inits=novel_bias_inits).start()
     for idx in range(r.iter_num):
         r.run_session(idx)
     return r.finish()

@@ -151,6 +151,19 @@ def make_novel_inits(seed, n_sessions, n_ways=5, dim=640):
     return [rs.uniform(-b, b, (n_ways, dim)).astype(np.float32) for _ in range(n_sessions)]
 
 
+def make_novel_bias_inits(seed, n_sessions, n_ways=5, dim=640):
+    """Init values for augment_base_classifier_(novel_bias=...) of a classifier WITH bias: nn.Linear's default bias init
+    U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (resnet_language.py:216-219), from a NumPy stream like make_novel_inits."""
+    rs = np.random.RandomState(seed + 910000)
+    b = 1.0 / np.sqrt(dim)
+    return [rs.uniform(-b, b, (n_ways,)).astype(np.float32) for _ in range(n_sessions)]
+
+
+def make_classifier_bias(seed, n_cls=60, scale=0.1):
+    """classifier.bias of a backbone pretrained without --no_linear_bias (configs.py:177,213): N(0, scale)."""
+    return (np.random.RandomState(seed + 920000).standard_normal(n_cls) * scale).astype(np.float32)
+
+
 def make_linear_map(seed, indim=500, outdim=640, scale=0.002):
     """A synthetic LinearMap state (learn_mapping.py's product, ckpt['mapping_linear_label2image']): (map.weight, map.bias)."""
     rs = np.random.RandomState(seed)

@@ -678,9 +678,9 @@ def test_validate_sets_top1_and_top5_with_ties():
         c1 = torch.zeros(2 * 3, dtype=torch.int32, device="cuda")
         c5 = torch.zeros(2 * 3, dtype=torch.int32, device="cuda")
         set_rows = (C.c_int * 3)(*rows)
-        _lib.check(lib.subreg_validate_sets(_lib.ptr(ft), _lib.ptr(yt), _lib.ptr(wt), set_rows, 3, N, D, None, _lib.ptr(c1),
+        _lib.check(lib.subreg_validate_sets(_lib.ptr(ft), _lib.ptr(yt), _lib.ptr(wt), None, set_rows, 3, N, D, None, _lib.ptr(c1),
                                             _lib.ptr(c5), 3, 0, None), "validate_sets")
-        _lib.check(lib.subreg_validate_sets(_lib.ptr(ft), _lib.ptr(yt), _lib.ptr(wt), set_rows, 3, N, D, None, _lib.ptr(c1),
+        _lib.check(lib.subreg_validate_sets(_lib.ptr(ft), _lib.ptr(yt), _lib.ptr(wt), None, set_rows, 3, N, D, None, _lib.ptr(c1),
                                             None, 3, 0, None), "validate_sets without top-5")
         torch.cuda.synchronize()
         logits = f.astype(np.float64) @ w.T.astype(np.float64)
@@ -734,7 +734,7 @@ def test_validate_sets_out_of_range_label_is_a_miss():
     c1 = torch.zeros(1, dtype=torch.int32, device="cuda")
     c5 = torch.zeros(1, dtype=torch.int32, device="cuda")
     ft, yt, wt = _t(f), torch.from_numpy(y).cuda(), _t(w)            # (keep the device buffers alive across the launch)
-    _lib.check(lib.subreg_validate_sets(_lib.ptr(ft), _lib.ptr(yt), _lib.ptr(wt), (C.c_int * 1)(n), 1, N, D,
+    _lib.check(lib.subreg_validate_sets(_lib.ptr(ft), _lib.ptr(yt), _lib.ptr(wt), None, (C.c_int * 1)(n), 1, N, D,
                                         None, _lib.ptr(c1), _lib.ptr(c5), 1, 0, None), "validate_sets")
     torch.cuda.synchronize()
     ok = int(((y >= 0) & (y < N)).sum())

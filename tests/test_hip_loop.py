@@ -66,8 +66,13 @@ def build_case(g, dtype, embed_dir=None):
         kw["attraction_override"] = None if ao == "None" else ao
     if "embed.words" in g.files:
         kw["word_embed_path"] = write_embed_pickle(g, embed_dir)
+    if "final_bias" in g.files and int(g["opt.lmbd_reg_novel_is_none"]):
+        kw["lmbd_reg_novel"] = None
+    kw.pop("lmbd_reg_novel_is_none", None)
     opt = make_opt(set_seed=seed, neval_episodes=ns, memory_replay=1 if memory else 0, hip_dtype=dtype, **kw)
     sd = syn.make_state_dict(int(g["sd_seed"]))
+    if "final_bias" in g.files:                      # classifier with bias (eval_incremental.py:96-103: read off the checkpoint)
+        sd["classifier.bias"] = syn.make_classifier_bias(int(g["sd_seed"]))
     for k in g.files:
         if k.startswith("bn0."):
             sd[k[4:]] = g[k].copy()
@@ -102,7 +107,7 @@ def build_case(g, dtype, embed_dir=None):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw84_M", "hw32_sem", "hw32_map", "hw84_noM_s8", "hw84_noM_disc",
-                                 "hw84_stop", "hw84_sem", "hw84_map", "hw32_adam"])
+                                 "hw84_stop", "hw84_sem", "hw84_map", "hw32_adam", "hw32_bias"])
 def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
     """hw84_noM_s8 is the bench-scale case (BASELINE.json configs[1]: 8 sessions, -M, 84x84, 1000-image base batch) with 6
     epochs per session, so the per-epoch hipGraph is captured and replayed and up to 1125 images go through one launch
@@ -112,7 +117,8 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
     58-80 % and the base accuracy falls 95 -> 40 -> 20 %, with the wrong answers wrong by construction (hard_queries), so the
     bf16 gate on them is ONE query image.  hw84_sem / hw84_map: the semantic subspace regularizer and the linear-mapping target
     (scripts/continual/slurm_semantic_subspace_reg.sh, slurm_linear_mapping.sh) on the same kind of episodes at 84x84, 30 epochs,
-    with the reference's own word vectors.  hw32_adam: `--adam` (eval/util.py:92-97, torch.optim.Adam instead of SGD), +M, 3 sessions."""
+    with the reference's own word vectors.  hw32_adam: `--adam` (eval/util.py:92-97, torch.optim.Adam instead of SGD), +M, 3 sessions.
+    hw32_bias: a classifier WITH bias (backbone pretrained without --no_linear_bias), +M, 3 sessions, no --lmbd_reg_novel."""
     from subreg_hip.incremental import few_shot_finetune_incremental_test
     g = np.load(os.path.join(GOLDEN, "loop_%s.npz" % tag))
     net, opt, meta, base_loader, bsl, inits, picks = build_case(g, dtype, str(tmp_path / "word_embeds"))
@@ -122,7 +128,8 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
         ckpt = {"mapping_linear_label2image": {"map.weight": torch.from_numpy(mw), "map.bias": torch.from_numpy(mb)}}
     novel_avg, base_avg = few_shot_finetune_incremental_test(net, ckpt, None, meta, base_loader, opt, base_support_loader=bsl,
                                                              novel_inits=inits, memory_picks=picks, epochs_per_sync=4,
-                                                             verbose=False)
+                                                             verbose=False,
+                                                             novel_bias_inits=syn.make_novel_bias_inits(int(g["seed"]), int(g["n_sessions"])))
     run = net.last_run
     ns = int(g["n_sessions"])
     f32 = dtype == "f32"
@@ -165,6 +172,8 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
             # up to 9.2e-3 after 5 epochs at lr 0.002); fp32 stays at 1e-4
             tol_bf16 = 2.0 * float(g["opt.learning_rate"] if "opt.learning_rate" in g.files else 0.002) * int(g["opt.max_novel_epochs"])
         _cmp("final classifier", run["classifier_weight"], g["final_classifier"], 1e-4 if f32 else tol_bf16, 1e-4 if f32 else 5e-3)
+        if "final_bias" in g.files:
+            _cmp("final bias", run["classifier_bias"], g["final_bias"], 1e-5 if f32 else 2e-3, 1e-4 if f32 else 5e-3)
         if discriminating and not f32:
             dw = run["classifier_weight"].astype(np.float64) - g["final_classifier"].astype(np.float64)
             rel = float(np.linalg.norm(dw) / np.linalg.norm(g["final_classifier"].astype(np.float64)))
@@ -193,6 +202,21 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
         _cmp("novel avg", novel_avg, g["novel_avg"], (2 if not data_dependent_stop else 3) * one_image, 0)
         _cmp("base avg", base_avg, g["base_avg"],                                                       # <= 1 base image / 0.5 pt
              max(0.5, (300.0 if data_dependent_stop and discriminating else 100.0) / int(g["n_base_batch"]) + 1e-6), 0)
+
+
+def test_bias_with_novel_reg_fails_like_the_reference():
+    """resnet_language.py:238 indexes the 1-D bias with two indices: a classifier with bias and --lmbd_reg_novel dies with
+    IndexError in the first epoch of session 2 in the reference; the fused loop raises the same error at the same place
+    (session 1 runs), and the C entry point refuses the combination."""
+    from subreg_hip.incremental import IncrementalRunner
+    g = np.load(os.path.join(GOLDEN, "loop_hw32_bias.npz"))
+    net, opt, meta, base_loader, bsl, inits, picks = build_case(g, "f32")
+    opt.lmbd_reg_novel, opt.max_novel_epochs = 0.1, 2
+    r = IncrementalRunner(net, meta, base_loader, opt, bsl, inits, picks, verbose=False,
+                          novel_bias_inits=syn.make_novel_bias_inits(int(g["seed"]), 3)).start()
+    assert r.run_session(0) == 2
+    with pytest.raises(IndexError, match="too many indices"):
+        r.run_session(1)
 
 
 def test_feature_reuse_is_results_identical():

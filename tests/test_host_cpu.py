@@ -56,6 +56,9 @@ def test_struct_layouts_match_c():
     assert ctypes.sizeof(_lib.LoopState) == 20
     assert ctypes.sizeof(_lib.BlockDesc) == 4 * ctypes.sizeof(_lib.ConvDesc) + 8 + 8 + 8 + 8 + 8
     assert _lib.StepDesc.weight.offset == 32 and _lib.StepDesc.n_base.offset == 72
+    # offsetof(subreg_step_desc, exp_avg_sq / bias / bias_base), sizeof: gcc on include/subreg_hip.h
+    assert (_lib.StepDesc.exp_avg_sq.offset, _lib.StepDesc.bias.offset, _lib.StepDesc.bias_base.offset) == (232, 240, 264)
+    assert ctypes.sizeof(_lib.StepDesc) == 272
 
 
 def test_conv_tiling_index_emulation():

@@ -144,6 +144,10 @@ def _loop_setup(g):
     for k in g.files:
         if k.startswith("opt."):
             setattr(opt, k[4:], g[k].item())
+    if "final_bias" in g.files:                     # classifier with bias (tools/make_golden.py `bias`)
+        sd["classifier.bias"] = syn.make_classifier_bias(int(g["sd_seed"]))
+        if int(g["opt.lmbd_reg_novel_is_none"]):
+            opt.lmbd_reg_novel = None
     sessions = syn.make_sessions(seed, ns, hw, class_signal=signal)
     base = syn.make_base_batch(seed, int(g["n_base_batch"]), hw, class_signal=signal)
     bsup = syn.make_base_support(seed, hw, class_signal=signal) if memory else None
@@ -169,13 +173,16 @@ def _embed_kwargs(g):
     return kw
 
 
-@pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw32_sem", "hw32_map", "hw32_adam"])
+@pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw32_sem", "hw32_map", "hw32_adam", "hw32_bias"])
 def test_loop_against_reference(tag):
     g = _load("loop_%s.npz" % tag)
     sd, opt, sessions, base, bsup, inits, mseed, picks = _loop_setup(g)
     net = ResNetRef(sd)
     out = loop_ref.run_incremental(net, sessions, base, opt, inits, base_support=bsup,
-                                   masks=MaskSource(mseed), memory_picks=picks, **_embed_kwargs(g))
+                                   masks=MaskSource(mseed), memory_picks=picks,
+                                   novel_bias_inits=syn.make_novel_bias_inits(int(g["seed"]), len(sessions)), **_embed_kwargs(g))
+    if "final_bias" in g.files:
+        _close(out["classifier_bias"], g["final_bias"], 1e-5, 1e-4, "final bias")
     for s in range(len(sessions)):
         assert out["epochs"][s] == int(g["s%d.epochs" % s]), (s, out["epochs"], g["s%d.epochs" % s])
         _close(out["loss"][s], g["s%d.loss" % s], 2e-4, 2e-4, "loss s%d" % s)
@@ -186,6 +193,18 @@ def test_loop_against_reference(tag):
     for k in ("layer1.0.bn1", "layer4.1.bn3"):
         _close(sd[k + ".running_mean"], g[k + ".running_mean"], 1e-5, 1e-4, k)
         _close(sd[k + ".running_var"], g[k + ".running_var"], 1e-5, 1e-4, k)
+
+
+def test_loop_with_bias_and_novel_reg_fails_like_the_reference():
+    """resnet_language.py:238 indexes the 1-D bias with two indices: with a bias and --lmbd_reg_novel the reference raises
+    IndexError in the first epoch of session 2 (checked against the reference itself when the golden was generated:
+    `net.reglossnovel(0.1, w, b)` -> IndexError: too many indices for tensor of dimension 1)."""
+    g = _load("loop_hw32_bias.npz")
+    sd, opt, sessions, base, bsup, inits, mseed, picks = _loop_setup(g)
+    opt.lmbd_reg_novel, opt.max_novel_epochs = 0.1, 1
+    with pytest.raises(IndexError, match="too many indices"):
+        loop_ref.run_incremental(ResNetRef(sd), sessions, base, opt, inits, base_support=bsup, masks=MaskSource(mseed),
+                                 memory_picks=picks, novel_bias_inits=syn.make_novel_bias_inits(int(g["seed"]), len(sessions)))
 
 
 def test_memory_index_formula():

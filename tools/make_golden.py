@@ -359,6 +359,9 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False
              hard_queries=0, centre=False, base_norm=0.5, **optkw):
     opt = ref_opt(set_seed=seed, neval_episodes=n_sessions, memory_replay=1 if memory else 0, **optkw)
     sd = syn.make_state_dict(21 + seed)
+    with_bias = bool(getattr(opt, "linear_bias", False))
+    if with_bias:                                # eval_incremental.py:96-103: the checkpoint holds classifier.bias => linear_bias
+        sd["classifier.bias"] = syn.make_classifier_bias(21 + seed)
     net = ref_net(sd, opt)
     calibrate_bn(net, hw, signal, proto_grid)
     params0 = {}
@@ -372,6 +375,7 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False
     sessions = syn.make_sessions(seed, n_sessions, hw, class_signal=signal, proto_grid=proto_grid, hard_queries=hard_queries)
     base_x, base_y = syn.make_base_batch(seed, n_base_batch, hw, class_signal=signal, proto_grid=proto_grid)
     inits = syn.make_novel_inits(seed, n_sessions)
+    bias_inits = syn.make_novel_bias_inits(seed, n_sessions)
     names_base = ["b%d" % i for i in range(60)] + [""] * 40
     names_novel = ["n%d" % i for i in range(100)]
     ckpt = {}
@@ -395,7 +399,8 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False
     orig_aug = net.augment_base_classifier_
 
     def aug(n, novel_weight=None, novel_bias=None):
-        r = orig_aug(n, novel_weight=torch.from_numpy(inits[counter["i"]]))
+        r = orig_aug(n, novel_weight=torch.from_numpy(inits[counter["i"]]),
+                     novel_bias=torch.from_numpy(bias_inits[counter["i"]]) if with_bias else None)
         counter["i"] += 1
         rec["loss"].append([])
         rec["val"].append([])
@@ -442,6 +447,9 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False
         if v is not None:
             out["opt." + k] = np.array(v)
     out["attraction_override"] = np.array(str(opt.attraction_override))
+    if with_bias:                                # base bias = subreg_hip.synthetic.make_classifier_bias(sd_seed)
+        out["final_bias"] = t2n(net.classifier.bias)
+        out["opt.lmbd_reg_novel_is_none"] = np.array(int(opt.lmbd_reg_novel is None))
     if real_names:
         table_arrays(out)
         out["names_base"], out["names_novel"] = np.array(names_base), np.array(names_novel)
@@ -566,7 +574,7 @@ def gen_train_step():
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["blocks", "backbone", "reg", "train", "loop32", "adam", "semantic", "episodes", "loop84"]
+    what = sys.argv[1:] or ["blocks", "backbone", "reg", "train", "loop32", "adam", "bias", "semantic", "episodes", "loop84"]
     if "blocks" in what:
         gen_blocks()
     if "backbone" in what:
@@ -584,6 +592,11 @@ def main():
     if "adam" in what:
         # --adam (eval/util.py:92-97: torch.optim.Adam(lr, weight_decay=0.0005) instead of SGD), +M, three sessions
         gen_loop("hw32_adam", 32, 3, True, 40, seed=13, max_novel_epochs=5, adam=True)
+    if "bias" in what:
+        # classifier WITH bias (a backbone pretrained without --no_linear_bias; eval_incremental.py:96-103 reads it off the
+        # checkpoint), +M, three sessions.  --lmbd_reg_novel must be absent: with a bias the reference's reglossnovel
+        # (resnet_language.py:238) raises IndexError from session 2 on.
+        gen_loop("hw32_bias", 32, 3, True, 40, seed=14, max_novel_epochs=5, linear_bias=True, lmbd_reg_novel=None)
     if "semantic" in what:
         gen_semantic()
         gen_loop("hw32_sem", 32, 3, True, 40, seed=5, max_novel_epochs=4, real_names=True, attraction_override=None,
