@@ -54,9 +54,16 @@ class LangPuller(nn.Module):
 
     def __init__(self, opt, vocab_base, vocab_novel):
         super().__init__()
-        if getattr(opt, "use_synonyms", False):          # resnet_language.py:35-42 (synonym-averaged embeddings): not built
-            raise NotImplementedError("use_synonyms: the synonym branch of LangPuller.__init__ is not implemented "
-                                      "(no script under scripts/continual sets it)")
+        if getattr(opt, "use_synonyms", False):
+            # resnet_language.py:35-45: the synonym branch reads <dataset>_dim<dim>_base_synonyms.pickle (not shipped with the
+            # reference) into a Python LIST of per-label entries and then calls `.float()` on that list (:45) - it cannot get
+            # past __init__ in the reference.  Same failures here, in the same order: the missing file, a missing label, then
+            # the list that has no .float().
+            pth = os.path.join(opt.word_embed_path, "{0}_dim{1}_base_synonyms.pickle".format(opt.dataset, opt.word_embed_size))
+            with open(pth, "rb") as f:
+                label_syn_embeds = pickle.load(f)
+            base_embeds = [label_syn_embeds[base_label] for base_label in vocab_base]
+            raise AttributeError("'%s' object has no attribute 'float'" % type(base_embeds).__name__)
         self.mapping_model = None
         self.opt = opt
         self.vocab_base = vocab_base

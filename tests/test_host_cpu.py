@@ -111,6 +111,23 @@ def test_synthetic_episode_layout():
     assert abs(conv_flops_per_image(84) / 8.1219e9 - 1) < 1e-3
 
 
+def test_use_synonyms_fails_like_the_reference(tmp_path):
+    """models/resnet_language.py:35-45: `--use_synonyms` opens <dataset>_dim<dim>_base_synonyms.pickle (absent from the reference
+    repository), builds a Python list from it and calls .float() on the list - FileNotFoundError, then AttributeError."""
+    import pickle
+    from types import SimpleNamespace
+    from subreg_hip.resnet_language import LangPuller
+    opt = SimpleNamespace(use_synonyms=True, word_embed_path=str(tmp_path), dataset="miniImageNet", word_embed_size=500, temperature=1)
+    with pytest.raises(FileNotFoundError):
+        LangPuller(opt, ["a", "b"], ["c"])
+    with open(os.path.join(str(tmp_path), "miniImageNet_dim500_base_synonyms.pickle"), "wb") as f:
+        pickle.dump({"a": np.zeros(500), "b": np.ones(500)}, f)
+    with pytest.raises(AttributeError, match="'list' object has no attribute 'float'"):
+        LangPuller(opt, ["a", "b"], ["c"])
+    with pytest.raises(KeyError):
+        LangPuller(opt, ["a", "zzz"], ["c"])
+
+
 def test_checkpoint_round_trip_in_reference_format(tmp_path):
     """train_supervised.py:181-202 writer / eval_incremental.py:86-123 reader: same dict keys, 133 model keys, bias rule."""
     import argparse
