@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUBREG_ABI_VERSION 6
+#define SUBREG_ABI_VERSION 7
 
 #define SUBREG_OK 0
 #define SUBREG_EINVAL (-1)       /* bad argument (null pointer, shape not supported by contract) */
@@ -218,6 +218,7 @@ typedef struct subreg_block_train {
     void* out;            /* block output [B*Ho*Wo][cout] (after pool and keep mask) */
 } subreg_block_train;
 
+#define SUBREG_TRAIN_EVENTS 6
 typedef struct subreg_train_desc {
     const subreg_block_train* blocks; /* HOST array, one per block of the backbone desc */
     void* g[2];            /* activation-sized gradient ping-pong (w.r.t. block outputs / inputs) */
@@ -231,7 +232,20 @@ typedef struct subreg_train_desc {
     const float* zero_shift; /* [Cmax] zeros */
     void* const* grad_out_dump; /* optional HOST array [n_blocks] of device buffers: receives d(loss)/d(block output)
                                    (NHWC, compute dtype) of every block for diagnostics; NULL = off */
+    /* Optional two-stream schedule (all NULL = one stream, the order of train_supervised.py:229-244's autograd graph): the
+     * weight-gradient chains and the shortcut branch run on `side_stream` beside the BatchNorm-backward -> dX chain (and the
+     * shortcut conv of the forward beside conv1..conv3).  Ordering is by the events only; every call joins the side stream
+     * before it returns, so callers keep single-stream semantics on `stream`. */
+    void* side_stream;       /* a second hipStream_t of the same device */
+    void* events[SUBREG_TRAIN_EVENTS]; /* from subreg_event_create */
+    void* dr_alt;            /* activation-sized, like dr (the two alternate) */
+    double* bn_partial_side; /* like bn_partial, for the shortcut branch's BatchNorm backward */
+    float* stats_side;       /* like subreg_backbone_desc.stats, for the shortcut conv's batch statistics in the forward */
 } subreg_train_desc;
+
+/* hipEvent_t (timing disabled) for subreg_train_desc.events; destroy when the descriptor is retired */
+int subreg_event_create(void** event);
+int subreg_event_destroy(void* event);
 
 /* train-mode forward that keeps what the backward needs (raw conv outputs, activations, batch statistics) */
 int subreg_backbone_forward_stash(const subreg_backbone_desc* d, const subreg_train_desc* t, const float* x_nchw, int B,

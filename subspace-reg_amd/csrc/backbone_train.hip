@@ -14,23 +14,52 @@ namespace {
 
 // raw conv + batch statistics; scale/shift of this batch, mean/invstd saved for the backward
 int conv_stash(const subreg_backbone_desc* d, const subreg_conv_desc& c, const subreg_conv_train& tc, const void* x, int B, int H,
-               int W, void* stream) {
-    TRY(subreg_conv_fwd(x, c.w, tc.raw, nullptr, nullptr, nullptr, d->stats, nullptr, nullptr, 0, B, H, W, c.cin, c.cout, c.ksize,
+               int W, float* stats, void* stream) {
+    TRY(subreg_conv_fwd(x, c.w, tc.raw, nullptr, nullptr, nullptr, stats, nullptr, nullptr, 0, B, H, W, c.cin, c.cout, c.ksize,
                         SUBREG_CONV_RAW_STATS, d->dtype, stream));
     const int rows = subreg_conv_stats_rows(d->dtype, B, H, W, c.cout);
-    return subreg_bn_train_finalize(d->stats, rows, c.cout, (long long)B * H * W, c.bn_weight, c.bn_bias, c.running_mean,
+    return subreg_bn_train_finalize(stats, rows, c.cout, (long long)B * H * W, c.bn_weight, c.bn_bias, c.running_mean,
                                     c.running_var, d->bn_momentum, d->bn_eps, tc.bscale, tc.bshift, tc.mean, tc.invstd, stream);
 }
 
-// BN backward (+ fused LeakyReLU' of `act`) then the weight gradient of the conv that produced `raw`
-int bn_and_wgrad(const subreg_backbone_desc* d, const subreg_train_desc* t, const subreg_conv_desc& c, const subreg_conv_train& tc,
-                 const void* dy, const void* act, const void* conv_input, void* draw, int B, int H, int W, void* stream) {
-    TRY(subreg_bn_bwd(dy, act, tc.raw, tc.mean, tc.invstd, c.bn_weight, t->bn_partial, tc.grad_gamma, tc.grad_beta, draw,
-                      (long long)B * H * W, c.cout, d->dtype, stream));
+// BN backward (+ fused LeakyReLU' of `act`): d(raw conv output) into `draw`, d gamma / d beta
+int bn_backward(const subreg_backbone_desc* d, const subreg_conv_desc& c, const subreg_conv_train& tc, const void* dy, const void* act,
+                void* draw, double* partial, int B, int H, int W, void* stream) {
+    return subreg_bn_bwd(dy, act, tc.raw, tc.mean, tc.invstd, c.bn_weight, partial, tc.grad_gamma, tc.grad_beta, draw,
+                         (long long)B * H * W, c.cout, d->dtype, stream);
+}
+
+// the weight gradient of the conv that produced `raw`, from d(raw) and the conv's input
+int weight_grad(const subreg_backbone_desc* d, const subreg_train_desc* t, const subreg_conv_desc& c, const subreg_conv_train& tc,
+                const void* conv_input, const void* draw, int B, int H, int W, void* stream) {
     TRY(subreg_conv_wgrad(conv_input, draw, tc.gw_packed, t->pad_x, t->pad_dy, B, H, W, c.cin, c.cout, c.ksize, d->dtype, stream));
     return subreg_unpack_wgrad(tc.gw_packed, tc.grad_w, c.cout, c.cin_raw, c.ksize_raw, c.cin_raw == 3 ? 1 : 0,
                                subreg_conv_wgrad_splits(B, H, W, c.cin, c.cout, c.ksize, d->dtype), stream);
 }
+
+// Two-stream schedule of the step (subreg_train_desc.side_stream): the weight-gradient chain of a conv (pad copies, dW kernel,
+// unpack) and the whole shortcut branch depend only on d(raw) / d(sum), not on each other or on the dX chain, and at the
+// pretraining batch most of these launches cannot fill 256 CUs (52-200 workgroups on the 10x10 / 5x5 maps) - so they go to a
+// second stream and overlap with the main stream's BatchNorm-backward -> dX chain.  Ordering is by events only (no host
+// synchronisation): `ready` = main produced a buffer the side stream reads, `done` = the side stream finished reading it.
+struct Fork {
+    hipStream_t main, side;
+    hipEvent_t ev[SUBREG_TRAIN_EVENTS];
+    bool on;
+    Fork(const subreg_train_desc* t, void* stream) : main((hipStream_t)stream), side((hipStream_t)t->side_stream), on(false) {
+        on = t->side_stream != nullptr && t->side_stream != stream;
+        for (int i = 0; i < SUBREG_TRAIN_EVENTS; ++i) {
+            ev[i] = (hipEvent_t)t->events[i];
+            if (!ev[i]) on = false;
+        }
+        if (!on) side = main;
+    }
+    // the side stream continues after everything the main stream has been given so far
+    int main_to_side(int e) { return !on || (hipEventRecord(ev[e], main) == hipSuccess && hipStreamWaitEvent(side, ev[e], 0) == hipSuccess) ? SUBREG_OK : SUBREG_EHIP; }
+    int mark_side(int e) { return !on || hipEventRecord(ev[e], side) == hipSuccess ? SUBREG_OK : SUBREG_EHIP; }
+    int main_waits(int e) { return !on || hipStreamWaitEvent(main, ev[e], 0) == hipSuccess ? SUBREG_OK : SUBREG_EHIP; }
+};
+enum { EV_FORK = 0, EV_DOWN = 1, EV_READY0 = 2, EV_READY1 = 3, EV_DONE0 = 4, EV_DONE1 = 5 };
 
 }  // namespace
 
@@ -39,6 +68,8 @@ extern "C" int subreg_backbone_forward_stash(const subreg_backbone_desc* d, cons
     SUBREG_CHECK_ARG(d && t && d->blocks && t->blocks && d->n_blocks > 0 && x_nchw && feat && B > 0 && H > 0 && W > 0);
     SUBREG_CHECK_ARG(d->col && d->stats);
     const int dt = d->dtype;
+    Fork f(t, stream);
+    if (!t->stats_side) f.on = false, f.side = f.main;
     TRY(subreg_pack_input(x_nchw, d->col, B, H, W, dt, stream));
     const void* cur = d->col;
     int h = H, w = W;
@@ -47,20 +78,23 @@ extern "C" int subreg_backbone_forward_stash(const subreg_backbone_desc* d, cons
         const subreg_block_train& tb = t->blocks[i];
         const int pflag = b.stride == 2 ? SUBREG_CONV_POOL2 : 0;
         SUBREG_CHECK_ARG(tb.conv1.raw && tb.conv1.act && tb.conv2.raw && tb.conv2.act && tb.conv3.raw && tb.out);
-        TRY(conv_stash(d, b.conv1, tb.conv1, cur, B, h, w, stream));
-        TRY(subreg_bn_apply(tb.conv1.raw, tb.conv1.bscale, tb.conv1.bshift, nullptr, nullptr, nullptr, nullptr, 1.f, tb.conv1.act, B, h,
-                            w, b.conv1.cout, SUBREG_CONV_LRELU, dt, stream));
-        TRY(conv_stash(d, b.conv2, tb.conv2, tb.conv1.act, B, h, w, stream));
-        TRY(subreg_bn_apply(tb.conv2.raw, tb.conv2.bscale, tb.conv2.bshift, nullptr, nullptr, nullptr, nullptr, 1.f, tb.conv2.act, B, h,
-                            w, b.conv2.cout, SUBREG_CONV_LRELU, dt, stream));
-        TRY(conv_stash(d, b.conv3, tb.conv3, tb.conv2.act, B, h, w, stream));
         const void* res = cur;
         const float *rsc = nullptr, *rsh = nullptr;
-        if (b.down.w) {
+        if (b.down.w) {                    // the 1x1 shortcut conv + its statistics: beside conv1..conv3 on the side stream
             SUBREG_CHECK_ARG(tb.down.raw != nullptr);
-            TRY(conv_stash(d, b.down, tb.down, cur, B, h, w, stream));
+            TRY(f.main_to_side(EV_FORK));
+            TRY(conv_stash(d, b.down, tb.down, cur, B, h, w, f.on ? t->stats_side : d->stats, f.side));
+            TRY(f.mark_side(EV_DOWN));
             res = tb.down.raw; rsc = tb.down.bscale; rsh = tb.down.bshift;
         }
+        TRY(conv_stash(d, b.conv1, tb.conv1, cur, B, h, w, d->stats, stream));
+        TRY(subreg_bn_apply(tb.conv1.raw, tb.conv1.bscale, tb.conv1.bshift, nullptr, nullptr, nullptr, nullptr, 1.f, tb.conv1.act, B, h,
+                            w, b.conv1.cout, SUBREG_CONV_LRELU, dt, stream));
+        TRY(conv_stash(d, b.conv2, tb.conv2, tb.conv1.act, B, h, w, d->stats, stream));
+        TRY(subreg_bn_apply(tb.conv2.raw, tb.conv2.bscale, tb.conv2.bshift, nullptr, nullptr, nullptr, nullptr, 1.f, tb.conv2.act, B, h,
+                            w, b.conv2.cout, SUBREG_CONV_LRELU, dt, stream));
+        TRY(conv_stash(d, b.conv3, tb.conv3, tb.conv2.act, B, h, w, d->stats, stream));
+        if (b.down.w) TRY(f.main_waits(EV_DOWN));
         TRY(subreg_bn_apply(tb.conv3.raw, tb.conv3.bscale, tb.conv3.bshift, res, rsc, rsh, b.keep_mask, b.mask_scale, tb.out, B, h, w,
                             b.conv3.cout, SUBREG_CONV_LRELU | pflag, dt, stream));
         cur = tb.out;
@@ -82,6 +116,25 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
     // d(loss)/d(output of block i) lives in g[(nb - 1 - i) & 1]: the ping-pong index is a function of the block, so the
     // backward can be issued in several calls (descending, contiguous block ranges)
     if (last_block == nb - 1) TRY(subreg_avgpool_bwd(dfeat, t->g[0], B, h, w, d->blocks[nb - 1].conv3.cout, dt, stream));
+    Fork f(t, stream);
+    if (!t->dr_alt || !t->bn_partial_side) f.on = false, f.side = f.main;
+    void* const drb[2] = {t->dr, f.on ? t->dr_alt : t->dr};     // d(raw) ping-pong: the side stream reads one while main fills the other
+    bool busy[2] = {false, false};                              // the side stream has been given work that reads drb[k]
+    bool down_busy = false;
+    int use = 0;
+    // BN backward on main into drb[k]; its dW chain on the side stream; returns the buffer for the dX convolution on main
+    auto bn_then_wgrad = [&](const subreg_conv_desc& c, const subreg_conv_train& tc, const void* dy, const void* act,
+                             const void* conv_input, int bh, int bw, const void** draw_out) -> int {
+        const int k = use++ & 1;
+        if (busy[k]) TRY(f.main_waits(EV_DONE0 + k));
+        TRY(bn_backward(d, c, tc, dy, act, drb[k], t->bn_partial, B, bh, bw, stream));
+        TRY(f.main_to_side(EV_READY0 + k));
+        TRY(weight_grad(d, t, c, tc, conv_input, drb[k], B, bh, bw, f.side));
+        TRY(f.mark_side(EV_DONE0 + k));
+        busy[k] = f.on;
+        *draw_out = drb[k];
+        return SUBREG_OK;
+    };
     for (int i = last_block; i >= first_block; --i) {
         const int gi = (nb - 1 - i) & 1;
         const subreg_block_desc& b = d->blocks[i];
@@ -98,29 +151,55 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
         TRY(subreg_block_tail_bwd(t->g[gi], b.keep_mask, b.mask_scale, tb.conv3.raw, tb.conv3.bscale, tb.conv3.bshift, res,
                                   b.down.w ? tb.down.bscale : nullptr, b.down.w ? tb.down.bshift : nullptr, t->dv, B, bh, bw, C,
                                   b.stride == 2, dt, stream));
+        // shortcut branch (BN backward -> dr2, dW): needs only dv; all of it on the side stream
+        if (b.down.w) {
+            TRY(f.main_to_side(EV_FORK));
+            TRY(bn_backward(d, b.down, tb.down, t->dv, nullptr, t->dr2, f.on ? t->bn_partial_side : t->bn_partial, B, bh, bw, f.side));
+            TRY(weight_grad(d, t, b.down, tb.down, xin, t->dr2, B, bh, bw, f.side));
+            TRY(f.mark_side(EV_DOWN));
+            down_busy = f.on;
+        }
         // main branch: bn3/conv3 -> bn2/conv2 -> bn1/conv1
-        TRY(bn_and_wgrad(d, t, b.conv3, tb.conv3, t->dv, nullptr, tb.conv2.act, t->dr, B, bh, bw, stream));
-        TRY(subreg_conv_fwd(t->dr, tb.conv3.w_dgrad, t->dt, nullptr, t->zero_shift, nullptr, nullptr, nullptr, nullptr, 0, B, bh, bw,
+        const void* dr = nullptr;
+        TRY(bn_then_wgrad(b.conv3, tb.conv3, t->dv, nullptr, tb.conv2.act, bh, bw, &dr));
+        TRY(subreg_conv_fwd(dr, tb.conv3.w_dgrad, t->dt, nullptr, t->zero_shift, nullptr, nullptr, nullptr, nullptr, 0, B, bh, bw,
                             b.conv3.cout, b.conv3.cin, b.conv3.ksize_raw, 0, dt, stream));
-        TRY(bn_and_wgrad(d, t, b.conv2, tb.conv2, t->dt, tb.conv2.act, tb.conv1.act, t->dr, B, bh, bw, stream));
-        TRY(subreg_conv_fwd(t->dr, tb.conv2.w_dgrad, t->dt, nullptr, t->zero_shift, nullptr, nullptr, nullptr, nullptr, 0, B, bh, bw,
+        TRY(bn_then_wgrad(b.conv2, tb.conv2, t->dt, tb.conv2.act, tb.conv1.act, bh, bw, &dr));
+        TRY(subreg_conv_fwd(dr, tb.conv2.w_dgrad, t->dt, nullptr, t->zero_shift, nullptr, nullptr, nullptr, nullptr, 0, B, bh, bw,
                             b.conv2.cout, b.conv2.cin, b.conv2.ksize_raw, 0, dt, stream));
-        TRY(bn_and_wgrad(d, t, b.conv1, tb.conv1, t->dt, tb.conv1.act, xin, t->dr, B, bh, bw, stream));
-        // shortcut branch
-        if (b.down.w) TRY(bn_and_wgrad(d, t, b.down, tb.down, t->dv, nullptr, xin, t->dr2, B, bh, bw, stream));
+        TRY(bn_then_wgrad(b.conv1, tb.conv1, t->dt, tb.conv1.act, xin, bh, bw, &dr));
+        // the shortcut branch's results (dr2) and its reads of dv: main continues after them
+        if (down_busy) { TRY(f.main_waits(EV_DOWN)); down_busy = false; }
         if (i == 0) break;                 // no gradient w.r.t. the images
         // d(block input) = dX(conv1) + (dX(shortcut conv) | d(pre-activation sum))
         SUBREG_CHECK_ARG(tb.conv1.w_dgrad && (!b.down.w || tb.down.w_dgrad));
         const int go = gi ^ 1;
         if (b.down.w) {
-            TRY(subreg_conv_fwd(t->dr, tb.conv1.w_dgrad, t->g[go], nullptr, t->zero_shift, nullptr, nullptr, t->dr2, tb.down.w_dgrad,
+            TRY(subreg_conv_fwd(dr, tb.conv1.w_dgrad, t->g[go], nullptr, t->zero_shift, nullptr, nullptr, t->dr2, tb.down.w_dgrad,
                                 b.down.cout, B, bh, bw, b.conv1.cout, b.conv1.cin, b.conv1.ksize_raw, 0, dt, stream));
         } else {
-            TRY(subreg_conv_fwd(t->dr, tb.conv1.w_dgrad, t->g[go], nullptr, t->zero_shift, t->dv, nullptr, nullptr, nullptr, 0, B, bh,
+            TRY(subreg_conv_fwd(dr, tb.conv1.w_dgrad, t->g[go], nullptr, t->zero_shift, t->dv, nullptr, nullptr, nullptr, 0, B, bh,
                                 bw, b.conv1.cout, b.conv1.cin, b.conv1.ksize_raw, 0, dt, stream));
         }
     }
+    // join: every gradient of these blocks is complete in main-stream order when this call's work is
+    if (down_busy) TRY(f.main_waits(EV_DOWN));
+    for (int k = 0; k < 2; ++k)
+        if (busy[k]) TRY(f.main_waits(EV_DONE0 + k));
     return SUBREG_OK;
+}
+
+extern "C" int subreg_event_create(void** event) {
+    SUBREG_CHECK_ARG(event);
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return SUBREG_EHIP;
+    *event = (void*)e;
+    return SUBREG_OK;
+}
+
+extern "C" int subreg_event_destroy(void* event) {
+    SUBREG_CHECK_ARG(event);
+    return hipEventDestroy((hipEvent_t)event) == hipSuccess ? SUBREG_OK : SUBREG_EHIP;
 }
 
 extern "C" int subreg_backbone_backward(const subreg_backbone_desc* d, const subreg_train_desc* t, const float* dfeat, int B, int H,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SUBREG_LIB") or os.path.join(_HERE, "libsubreg_hip.so
 F32, BF16 = 0, 1
 CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
 FWD_TRAIN = 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_QUERY_SETS = 32                          # SUBREG_MAX_QUERY_SETS
 
 c_void_p, c_int, c_float, c_longlong = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -51,7 +51,9 @@ class BlockTrain(C.Structure):
 class TrainDesc(C.Structure):
     _fields_ = [("blocks", C.POINTER(BlockTrain)), ("g", c_void_p * 2), ("dv", c_void_p), ("dr", c_void_p), ("dt", c_void_p),
                 ("dr2", c_void_p), ("bn_partial", c_void_p), ("pad_x", c_void_p), ("pad_dy", c_void_p),
-                ("zero_shift", c_void_p), ("grad_out_dump", C.POINTER(c_void_p))]
+                ("zero_shift", c_void_p), ("grad_out_dump", C.POINTER(c_void_p)),
+                ("side_stream", c_void_p), ("events", c_void_p * 6), ("dr_alt", c_void_p), ("bn_partial_side", c_void_p),
+                ("stats_side", c_void_p)]
 
 
 class LoopState(C.Structure):
@@ -107,6 +109,8 @@ SIGNATURES = {
     "subreg_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_sgd_momentum": (_I, [_P, _P, _P, _L, _F, _F, _F, _I, _P]),
     "subreg_backbone_forward_stash": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P, _I, _I, _I, _P, _P]),
+    "subreg_event_create": (_I, [C.POINTER(c_void_p)]),
+    "subreg_event_destroy": (_I, [_P]),
     "subreg_backbone_backward": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P, _I, _I, _I, _P]),
     "subreg_backbone_backward_blocks": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P, _I, _I, _I, _I, _I, _P]),
     "subreg_backbone_pack_train": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P]),

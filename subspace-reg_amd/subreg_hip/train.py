@@ -5,6 +5,7 @@ backbone's parameters require grad, `ResNet.features` routes through `BackboneTr
 gradients of all conv weights and BN affine parameters with the gfx950 kernels of csrc/backward.hip.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -105,6 +106,32 @@ class TrainStash:
         z = torch.zeros(cmax, dtype=f32, device=dev)
         self.keep.append(z)
         self.desc.zero_shift = z.data_ptr()
+        # two-stream schedule (subreg_train_desc.side_stream; SUBREG_TRAIN_ONE_STREAM=1 keeps the step on one stream for A/B runs):
+        # dW chains and the shortcut branch beside the BatchNorm-backward -> dX chain.  The stream, the events and the three extra
+        # buffers live as long as this stash.
+        self.side_stream, self._events = None, []
+        if os.environ.get("SUBREG_TRAIN_ONE_STREAM", "0") != "1":
+            self.side_stream = torch.cuda.Stream(device=dev)
+            self.desc.side_stream = self.side_stream.cuda_stream
+            for i in range(len(self.desc.events)):
+                e = C.c_void_p()
+                _lib.check(lib.subreg_event_create(C.byref(e)), "event_create")
+                self._events.append(e)
+                self.desc.events[i] = e.value
+            self.desc.dr_alt = buf(amax).data_ptr()
+            self.desc.bn_partial_side = buf(lib.subreg_bn_bwd_slices(B * H * W) * cmax * 2, torch.float64).data_ptr()
+            self.desc.stats_side = buf(lib.subreg_backbone_stats_floats(C.byref(hb._desc), B, H, W), f32).data_ptr()
+
+    def __del__(self):
+        # the events are the only thing here that torch's allocator does not own
+        try:
+            if self._events:
+                torch.cuda.synchronize()
+                for e in self._events:
+                    self.hb.lib.subreg_event_destroy(e)
+                self._events = []
+        except Exception:
+            pass
 
     def repack_dgrad(self):
         s = _lib.stream_ptr()

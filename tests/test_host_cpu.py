@@ -59,6 +59,9 @@ def test_struct_layouts_match_c():
     # offsetof(subreg_step_desc, exp_avg_sq / bias / bias_base), sizeof: gcc on include/subreg_hip.h
     assert (_lib.StepDesc.exp_avg_sq.offset, _lib.StepDesc.bias.offset, _lib.StepDesc.bias_base.offset) == (232, 240, 264)
     assert ctypes.sizeof(_lib.StepDesc) == 272
+    # offsetof(subreg_train_desc, side_stream / dr_alt / stats_side), sizeof
+    assert (_lib.TrainDesc.side_stream.offset, _lib.TrainDesc.dr_alt.offset, _lib.TrainDesc.stats_side.offset) == (96, 152, 168)
+    assert ctypes.sizeof(_lib.TrainDesc) == 176
 
 
 def test_conv_tiling_index_emulation():

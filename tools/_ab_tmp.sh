@@ -1,11 +1,10 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_hip_kernels.py -x -q -m gpu -k "conv" 2>&1 | tail -3
-B=$GRAFT_REPO_ROOT/subspace-reg_amd/build/libsubreg_hip_base.so
+timeout 900 python -m pytest tests/test_hip_train.py -x -q -m gpu 2>&1 | tail -3
 for r in 1 2; do
-echo "== base"; SUBREG_LIB=$B python tools/bench_conv.py --batch 700 --only L3.1 2>&1 | grep -v amdgpu; SUBREG_LIB=$B python tools/bench_conv.py --batch 700 --only L4.1 2>&1 | grep -v amdgpu
-echo "== new"; python tools/bench_conv.py --batch 700 --only L3.1 2>&1 | grep -v amdgpu; python tools/bench_conv.py --batch 700 --only L4.1 2>&1 | grep -v amdgpu
+echo "== one stream"; SUBREG_TRAIN_ONE_STREAM=1 python tools/bench_train.py --steps 30 2>&1 | grep -v amdgpu
+echo "== two streams"; python tools/bench_train.py --steps 30 2>&1 | grep -v amdgpu
 done
-echo "== base fwd"; SUBREG_LIB=$B python tools/bench_forward.py --lanes 2 --batches 500,750 2>&1 | grep -v amdgpu
-echo "== new fwd"; python tools/bench_forward.py --lanes 2 --batches 500,750 2>&1 | grep -v amdgpu
-echo "== base fwd"; SUBREG_LIB=$B python tools/bench_forward.py --lanes 2 --batches 500,750 2>&1 | grep -v amdgpu
-echo "== new fwd"; python tools/bench_forward.py --lanes 2 --batches 500,750 2>&1 | grep -v amdgpu
+echo "== one stream 128"; SUBREG_TRAIN_ONE_STREAM=1 python tools/bench_train.py --steps 20 --batch 128 2>&1 | grep -v amdgpu
+echo "== two streams 128"; python tools/bench_train.py --steps 20 --batch 128 2>&1 | grep -v amdgpu
+echo "== one stream 8"; SUBREG_TRAIN_ONE_STREAM=1 python tools/bench_train.py --steps 20 --batch 8 2>&1 | grep -v amdgpu
+echo "== two streams 8"; python tools/bench_train.py --steps 20 --batch 8 2>&1 | grep -v amdgpu
