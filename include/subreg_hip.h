@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUBREG_ABI_VERSION 7
+#define SUBREG_ABI_VERSION 8
 
 #define SUBREG_OK 0
 #define SUBREG_EINVAL (-1)       /* bad argument (null pointer, shape not supported by contract) */
@@ -71,6 +71,13 @@ int subreg_nhwc_to_nchw(const void* x_nhwc, float* y_nchw, int B, int C, int H, 
 int subreg_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* shift, const void* residual,
                     float* stats_partial, const void* x2, const void* w2, int Cin2, int B, int H, int W, int Cin, int Cout,
                     int ksize, int flags, int dtype, void* stream);
+/* The same with a caller-owned fp32 workspace: small-M 3x3 layers (the 10x10 / 5x5 maps at the pretraining batch: 52-100 tiles
+ * for 256 CUs) split K over several workgroups per tile and finish in a second launch.  Used only when workspace_floats >=
+ * subreg_conv_splitk_floats(...) > 0 and there is no pooling / residual / fused shortcut; otherwise exactly subreg_conv_fwd. */
+int subreg_conv_fwd_ws(const void* x, const void* w, void* y, const float* scale, const float* shift, const void* residual,
+                       float* stats_partial, const void* x2, const void* w2, int Cin2, int B, int H, int W, int Cin, int Cout,
+                       int ksize, int flags, int dtype, float* workspace, long long workspace_floats, void* stream);
+long long subreg_conv_splitk_floats(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
 int subreg_conv_stats_rows(int dtype, int B, int H, int W, int Cout);
 /* First layer without an im2col buffer (bf16, Cout = 64, eval mode): y = [lrelu](conv3x3(x_nchw, w) + shift) straight from the
  * fp32 NCHW image of the reference's loaders (models/resnet_language.py:249-251 with the BN scale folded into w);
@@ -241,6 +248,8 @@ typedef struct subreg_train_desc {
     void* dr_alt;            /* activation-sized, like dr (the two alternate) */
     double* bn_partial_side; /* like bn_partial, for the shortcut branch's BatchNorm backward */
     float* stats_side;       /* like subreg_backbone_desc.stats, for the shortcut conv's batch statistics in the forward */
+    float* splitk_ws;        /* optional workspace of subreg_conv_fwd_ws for the step's 3x3 convolutions (forward and dX) */
+    long long splitk_ws_floats; /* >= max over them of subreg_conv_splitk_floats */
 } subreg_train_desc;
 
 /* hipEvent_t (timing disabled) for subreg_train_desc.events; destroy when the descriptor is retired */

@@ -14,9 +14,9 @@ namespace {
 
 // raw conv + batch statistics; scale/shift of this batch, mean/invstd saved for the backward
 int conv_stash(const subreg_backbone_desc* d, const subreg_conv_desc& c, const subreg_conv_train& tc, const void* x, int B, int H,
-               int W, float* stats, void* stream) {
-    TRY(subreg_conv_fwd(x, c.w, tc.raw, nullptr, nullptr, nullptr, stats, nullptr, nullptr, 0, B, H, W, c.cin, c.cout, c.ksize,
-                        SUBREG_CONV_RAW_STATS, d->dtype, stream));
+               int W, float* stats, float* ws, long long ws_floats, void* stream) {
+    TRY(subreg_conv_fwd_ws(x, c.w, tc.raw, nullptr, nullptr, nullptr, stats, nullptr, nullptr, 0, B, H, W, c.cin, c.cout, c.ksize,
+                           SUBREG_CONV_RAW_STATS, d->dtype, ws, ws_floats, stream));
     const int rows = subreg_conv_stats_rows(d->dtype, B, H, W, c.cout);
     return subreg_bn_train_finalize(stats, rows, c.cout, (long long)B * H * W, c.bn_weight, c.bn_bias, c.running_mean,
                                     c.running_var, d->bn_momentum, d->bn_eps, tc.bscale, tc.bshift, tc.mean, tc.invstd, stream);
@@ -83,17 +83,17 @@ extern "C" int subreg_backbone_forward_stash(const subreg_backbone_desc* d, cons
         if (b.down.w) {                    // the 1x1 shortcut conv + its statistics: beside conv1..conv3 on the side stream
             SUBREG_CHECK_ARG(tb.down.raw != nullptr);
             TRY(f.main_to_side(EV_FORK));
-            TRY(conv_stash(d, b.down, tb.down, cur, B, h, w, f.on ? t->stats_side : d->stats, f.side));
+            TRY(conv_stash(d, b.down, tb.down, cur, B, h, w, f.on ? t->stats_side : d->stats, nullptr, 0, f.side));
             TRY(f.mark_side(EV_DOWN));
             res = tb.down.raw; rsc = tb.down.bscale; rsh = tb.down.bshift;
         }
-        TRY(conv_stash(d, b.conv1, tb.conv1, cur, B, h, w, d->stats, stream));
+        TRY(conv_stash(d, b.conv1, tb.conv1, cur, B, h, w, d->stats, t->splitk_ws, t->splitk_ws_floats, stream));
         TRY(subreg_bn_apply(tb.conv1.raw, tb.conv1.bscale, tb.conv1.bshift, nullptr, nullptr, nullptr, nullptr, 1.f, tb.conv1.act, B, h,
                             w, b.conv1.cout, SUBREG_CONV_LRELU, dt, stream));
-        TRY(conv_stash(d, b.conv2, tb.conv2, tb.conv1.act, B, h, w, d->stats, stream));
+        TRY(conv_stash(d, b.conv2, tb.conv2, tb.conv1.act, B, h, w, d->stats, t->splitk_ws, t->splitk_ws_floats, stream));
         TRY(subreg_bn_apply(tb.conv2.raw, tb.conv2.bscale, tb.conv2.bshift, nullptr, nullptr, nullptr, nullptr, 1.f, tb.conv2.act, B, h,
                             w, b.conv2.cout, SUBREG_CONV_LRELU, dt, stream));
-        TRY(conv_stash(d, b.conv3, tb.conv3, tb.conv2.act, B, h, w, d->stats, stream));
+        TRY(conv_stash(d, b.conv3, tb.conv3, tb.conv2.act, B, h, w, d->stats, t->splitk_ws, t->splitk_ws_floats, stream));
         if (b.down.w) TRY(f.main_waits(EV_DOWN));
         TRY(subreg_bn_apply(tb.conv3.raw, tb.conv3.bscale, tb.conv3.bshift, res, rsc, rsh, b.keep_mask, b.mask_scale, tb.out, B, h, w,
                             b.conv3.cout, SUBREG_CONV_LRELU | pflag, dt, stream));
@@ -162,11 +162,11 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
         // main branch: bn3/conv3 -> bn2/conv2 -> bn1/conv1
         const void* dr = nullptr;
         TRY(bn_then_wgrad(b.conv3, tb.conv3, t->dv, nullptr, tb.conv2.act, bh, bw, &dr));
-        TRY(subreg_conv_fwd(dr, tb.conv3.w_dgrad, t->dt, nullptr, t->zero_shift, nullptr, nullptr, nullptr, nullptr, 0, B, bh, bw,
-                            b.conv3.cout, b.conv3.cin, b.conv3.ksize_raw, 0, dt, stream));
+        TRY(subreg_conv_fwd_ws(dr, tb.conv3.w_dgrad, t->dt, nullptr, t->zero_shift, nullptr, nullptr, nullptr, nullptr, 0, B, bh, bw,
+                               b.conv3.cout, b.conv3.cin, b.conv3.ksize_raw, 0, dt, t->splitk_ws, t->splitk_ws_floats, stream));
         TRY(bn_then_wgrad(b.conv2, tb.conv2, t->dt, tb.conv2.act, tb.conv1.act, bh, bw, &dr));
-        TRY(subreg_conv_fwd(dr, tb.conv2.w_dgrad, t->dt, nullptr, t->zero_shift, nullptr, nullptr, nullptr, nullptr, 0, B, bh, bw,
-                            b.conv2.cout, b.conv2.cin, b.conv2.ksize_raw, 0, dt, stream));
+        TRY(subreg_conv_fwd_ws(dr, tb.conv2.w_dgrad, t->dt, nullptr, t->zero_shift, nullptr, nullptr, nullptr, nullptr, 0, B, bh, bw,
+                               b.conv2.cout, b.conv2.cin, b.conv2.ksize_raw, 0, dt, t->splitk_ws, t->splitk_ws_floats, stream));
         TRY(bn_then_wgrad(b.conv1, tb.conv1, t->dt, tb.conv1.act, xin, bh, bw, &dr));
         // the shortcut branch's results (dr2) and its reads of dv: main continues after them
         if (down_busy) { TRY(f.main_waits(EV_DOWN)); down_busy = false; }

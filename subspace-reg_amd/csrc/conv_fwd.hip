@@ -72,6 +72,8 @@ struct ConvArgs {
     int Cin, Cin2, Cout;
     int act;             // LeakyReLU(0.1) after scale/shift/residual
     int raw;             // write the un-normalised conv + stats partials
+    float* part;         // SPLITK kernels: fp32 partial sums [ksplit][M][Cout] (grid.y = ksplit); splitk_reduce_kernel finishes
+    int ksplit;
 };
 
 template <int TR> struct AccT;                       // accumulator registers of one TR x TR tile (TR*TR/64 per lane)
@@ -110,7 +112,11 @@ __device__ __forceinline__ void mma_step<float>(const uint4& a, const uint4& b, 
 // WK = 2: every output tile is owned by TWO waves that take alternate k-steps of each step and add their accumulators
 // through LDS at the end - twice the waves per CU for grids that cannot fill the chip (one 4-wave workgroup per CU leaves
 // one wave per SIMD and nothing to hide its DMA issue, waits and barriers behind).
-template <typename T, int NI, int NJ, int WAVES_M, int WAVES_N, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1>
+// SPLITK: grid.y workgroups share one output tile, each takes a contiguous range of the 32-channel chunks of Cin and writes its
+// fp32 accumulators to a.part; splitk_reduce_kernel adds them up and runs the epilogue (raw + statistics, or scale / shift / act).
+// For the 10x10 / 5x5 maps at the pretraining batch: 52-100 tiles on 256 CUs, every tile a chain of 30-60 steps that cannot be
+// shorter than one L2 / MALL round trip each (the next step's weights are staged one step ahead).
+template <typename T, int NI, int NJ, int WAVES_M, int WAVES_N, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1, bool SPLITK = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kernel(const ConvArgs a) {
     using K = KT<T>;
     constexpr int NWMN = WAVES_M * WAVES_N, NW = NWMN * WK;
@@ -218,6 +224,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     //      (nch1 chunks, centre tap only).  Patch of chunk c lives in buffer c&1, weights of step s in buffer s%NWB.
     const int nch0 = a.Cin / 32, nch1 = a.x2 ? a.Cin2 / 32 : 0;
     const int nchunks = nch0 + nch1;
+    // chunk range of this workgroup: everything, or its share of the K split (no shortcut GEMM in split launches)
+    const int c_beg = SPLITK ? (int)((long long)nch0 * blockIdx.y / a.ksplit) : 0;
+    const int c_end = SPLITK ? (int)((long long)nch0 * (blockIdx.y + 1) / a.ksplit) : nchunks;
     constexpr bool STAMPS = SUBREG_DIAG == 3;
     unsigned long long t_begin = 0, t_loop = 0, t_issue = 0, t_wait = 0, t_bar = 0, t_mma = 0, tq = 0, r_begin = 0;
     if (STAMPS) { t_begin = __builtin_amdgcn_s_memtime(); r_begin = __builtin_amdgcn_s_memrealtime(); }
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     const unsigned wtile = (unsigned)a.Cout * ROWB, wtap = (unsigned)nch0 * wtile;     // bytes of one (tap, chunk) tile / of one tap
     auto stage_w_piece = [&](int sc, int stg, int tt, int kw, int wb) {
         const int q = kw * NW + wid;
-        if (sc >= nchunks || q >= TN / RPP) return 0;
+        if (sc >= c_end || q >= TN / RPP) return 0;
         const unsigned dst = lds_base + B_BASE + wb * BBUF + tt * BTAP + q * 1024;
         if (sc < nch0) {                                              // tile (tap, chunk): Cout contiguous rows
             dma16(a.w, (unsigned)(stg * TPS + tt) * wtap + (unsigned)sc * wtile + wvoff[kw], dst);
@@ -239,9 +248,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     auto advance = [&](int& sc, int& stg) {
         if (sc >= nch0 || stg == NG - 1) { ++sc; stg = 0; } else { ++stg; }
     };
-    stage_patch(false, 0, 0);
+    stage_patch(false, c_beg, c_beg & 1);
 #pragma unroll
-    for (int k = 0; k < TPS * PW; ++k) stage_w_piece(0, 0, k / PW, k % PW, 0);
+    for (int k = 0; k < TPS * PW; ++k) stage_w_piece(c_beg, 0, k / PW, k % PW, 0);
     // per-lane LDS addresses of this lane's A rows for every tap (k-step 0; k-step s is addr ^ 16*LG*s): logical slot
     // LG*s + lh of the row, physical slot = logical ^ swz.  Kept as 16-bit halves (every patch buffer is < 64 KiB):
     // the 16x16 MFMA shape needs MI = 4 row addresses per tap and the accumulators leave no room for 36 registers.
@@ -284,9 +293,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     constexpr int PA = (AROWS / RPP + NW * PSTEPS - 1) / (NW * PSTEPS);
     int step = 0;
     if (STAMPS) t_loop = __builtin_amdgcn_s_memtime();
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = c_beg; c < c_end; ++c) {
         const bool ph1 = c >= nch0;
-        const bool more = c + 1 < nchunks;
+        const bool more = c + 1 < c_end;
         const bool nsecond = c + 1 >= nch0;                           // the next chunk belongs to the shortcut GEMM
         const int nck = nsecond ? c + 1 - nch0 : c + 1;
         const int nbuf = (c + 1) & 1;                                 // patch buffer of the next chunk
@@ -451,6 +460,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
             __syncthreads();
         }
         if (wave_k != 0) return;
+    }
+    if constexpr (SPLITK) {
+        // fp32 partial sums of this K range: [split][m][n]; lanes of a row group write 64 / 128 contiguous bytes
+        float* const part = a.part + (size_t)blockIdx.y * g.M * a.Cout;
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            const int n = n0 + (wave_n * MJ + j) * TR + lr;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int mb = m0 + (wave_m * MI + i) * TR + 4 * lh;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m < g.M && n < a.Cout) part[(size_t)m * a.Cout + n] = acc[i][j][r];
+                }
+            }
+        }
+        return;
     }
     struct EpilogueStamp {                  // DIAG=3: cycles from the end of the main loop to the kernel's last instruction
         float* dst;
@@ -628,6 +655,53 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     }
 }
 
+// Second pass of a SPLITK launch: y[m][n] = epilogue(sum over splits of part[s][m][n]).  Block = 32 rows x 32 channels
+// (thread = one row, four channels: 16-byte loads, the splits added in a fixed order).  raw: y = the sum rounded to bf16 and
+// stats[row_group][n] = (sum, sum of squares) of the UNROUNDED sums over the block's 32 rows - the same partition into
+// 32-row groups (m-tile x 4 + wave) the 128-row-tile kernel writes, so subreg_conv_stats_rows and the finalize pass are unchanged.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ksplit, int M, int Cout,
+                                                            __bf16* __restrict__ y, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int act, int raw,
+                                                            float* __restrict__ stats) {
+    __shared__ float r1[32][33], r2[32][33];
+    const int cq = threadIdx.x & 7, row = threadIdx.x >> 3;
+    const int n = blockIdx.x * 32 + cq * 4, m = blockIdx.y * 32 + row;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < M) {
+        const float* p = part + (size_t)m * Cout + n;
+        const size_t stride = (size_t)M * Cout;
+#pragma unroll 4
+        for (int sp = 0; sp < ksplit; ++sp) {
+            const float4 t = *reinterpret_cast<const float4*>(p + sp * stride);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        float o[4] = {v.x, v.y, v.z, v.w};
+        if (!raw) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = o[k] * (scale ? scale[n + k] : 1.f) + (shift ? shift[n + k] : 0.f);
+                if (act) o[k] = fmaxf(o[k], o[k] * 0.1f);
+            }
+        }
+        __bf16 ob[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ob[k] = ElemTraits<__bf16>::from_float(o[k]);
+        *reinterpret_cast<uint2*>(y + (size_t)m * Cout + n) = *reinterpret_cast<const uint2*>(ob);
+    }
+    if (!raw) return;
+    const float vv[4] = {v.x, v.y, v.z, v.w};            // zeros for the rows beyond M
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { r1[row][cq * 4 + k] = vv[k]; r2[row][cq * 4 + k] = vv[k] * vv[k]; }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < 32; ++r) { s1 += r1[r][threadIdx.x]; s2 += r2[r][threadIdx.x]; }
+        float* dst = stats + ((size_t)blockIdx.y * Cout + blockIdx.x * 32 + threadIdx.x) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
+    }
+}
+
 // ---------------------------------------------------------------------------- host side
 template <bool POOL>
 static int worst_patch_rows(const ConvGeom& g, int TM) {
@@ -640,22 +714,22 @@ static int worst_patch_rows(const ConvGeom& g, int TM) {
     return worst;
 }
 
-template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1>
+template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1, bool SPLITK = false>
 static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     using K = KT<T>;
     constexpr int TM = WM * NI * 32, TN = WN * NJ * 32;
     constexpr int ABUF = (AROWS + 1) * K::ROWB, BBUF = TPS * TN * K::ROWB;
     const size_t lds = 2 * (size_t)ABUF + 2 * (size_t)BBUF + 2 * TN * sizeof(float);   // patch x2, weights x2, shift/scale
-    auto kern = conv_fwd_kernel<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AROWS, MINW, WK>;
+    auto kern = conv_fwd_kernel<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AROWS, MINW, WK, SPLITK>;
     static std::atomic<unsigned long long> lds_set{0};   // per instantiation
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set)) return rc;
-    dim3 grid(((a.g.M + TM - 1) / TM) * ((a.Cout + TN - 1) / TN));   // 1-D: the kernel decodes (m-tile, n-tile) itself
+    dim3 grid(((a.g.M + TM - 1) / TM) * ((a.Cout + TN - 1) / TN), SPLITK ? a.ksplit : 1);   // x: the kernel decodes (m-tile, n-tile) itself
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * WK * 64), lds, stream, a);
     return launch_status();
 }
 
 // AR_S / AR_L: small and large LDS patch capacities (rows); the small one allows more workgroups per CU
-template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AR_S, int AR_L, int MINW, int WK = 1>
+template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AR_S, int AR_L, int MINW, int WK = 1, bool SPLITK = false>
 static int launch_rows(const ConvArgs& a, hipStream_t s) {
     if ((long long)a.g.M * a.Cout >= (1LL << 31) || (long long)a.g.npix * a.Cout >= (1LL << 31)) return SUBREG_EUNSUPPORTED;
     // DMA sources are addressed as base pointer + 32-bit byte offset
@@ -663,8 +737,8 @@ static int launch_rows(const ConvArgs& a, hipStream_t s) {
         (long long)a.g.taps * a.Cin * a.Cout * KT<T>::ELEM >= (1LL << 32))
         return SUBREG_EUNSUPPORTED;
     const int worst = worst_patch_rows<POOL>(a.g, WM * NI * 32);
-    if (worst <= AR_S) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_S, MINW, WK>(a, s);
-    if (worst <= AR_L) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_L, MINW, WK>(a, s);
+    if (worst <= AR_S) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_S, MINW, WK, SPLITK>(a, s);
+    if (worst <= AR_L) return launch_cfg<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AR_L, MINW, WK, SPLITK>(a, s);
     return SUBREG_EUNSUPPORTED;      // image too wide for the LDS patch
 }
 
@@ -752,9 +826,49 @@ extern "C" int subreg_conv_fwd_image_shortcut(const void* x, const void* w, void
                            (hipStream_t)stream, img_nchw);
 }
 
+// K splits of the SPLITK path for this problem (1 = not used): bf16, 3x3, Cout % 160 == 0, un-pooled, 128-row tiles that
+// leave at least half of the 256 CUs without a workgroup; every split keeps >= 2 chunks of 32 input channels
+static int splitk_plan(int dtype, int B, int H, int W, int Cin, int Cout, int ksize) {
+    static const bool on = [] { const char* e = getenv("SUBREG_NO_SPLITK"); return !(e && e[0] == '1'); }();   // A/B switch
+    if (!on || dtype != SUBREG_BF16 || ksize != 3 || Cout % 160 != 0 || Cin % 32 != 0) return 1;
+    const long long M = (long long)B * H * W;
+    if (M * Cout >= (1LL << 31) || wide_takes_256_rows((int)M, Cout, W)) return 1;
+    const long long blocks = ((M + 127) / 128) * (Cout / 160);
+    if (blocks > 128) return 1;
+    long long ks = 256 / blocks;
+    if (ks > Cin / 64) ks = Cin / 64;
+    if (ks > 8) ks = 8;
+    return ks >= 2 ? (int)ks : 1;
+}
+
+extern "C" long long subreg_conv_splitk_floats(int B, int H, int W, int Cin, int Cout, int ksize, int dtype) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    const int ks = splitk_plan(dtype, B, H, W, Cin, Cout, ksize);
+    return ks > 1 ? (long long)ks * B * H * W * Cout : 0;
+}
+
+static int conv_fwd_impl(const void* x, const void* w, void* y, const float* scale, const float* shift, const void* residual,
+                         float* stats_partial, const void* x2, const void* w2, int Cin2, int B, int H, int W, int Cin, int Cout,
+                         int ksize, int flags, int dtype, float* ws, long long ws_floats, void* stream);
+
 extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* shift,
                                const void* residual, float* stats_partial, const void* x2, const void* w2, int Cin2, int B,
                                int H, int W, int Cin, int Cout, int ksize, int flags, int dtype, void* stream) {
+    return conv_fwd_impl(x, w, y, scale, shift, residual, stats_partial, x2, w2, Cin2, B, H, W, Cin, Cout, ksize, flags, dtype,
+                         nullptr, 0, stream);
+}
+
+extern "C" int subreg_conv_fwd_ws(const void* x, const void* w, void* y, const float* scale, const float* shift,
+                                  const void* residual, float* stats_partial, const void* x2, const void* w2, int Cin2, int B,
+                                  int H, int W, int Cin, int Cout, int ksize, int flags, int dtype, float* workspace,
+                                  long long workspace_floats, void* stream) {
+    return conv_fwd_impl(x, w, y, scale, shift, residual, stats_partial, x2, w2, Cin2, B, H, W, Cin, Cout, ksize, flags, dtype,
+                         workspace, workspace_floats, stream);
+}
+
+static int conv_fwd_impl(const void* x, const void* w, void* y, const float* scale, const float* shift, const void* residual,
+                         float* stats_partial, const void* x2, const void* w2, int Cin2, int B, int H, int W, int Cin, int Cout,
+                         int ksize, int flags, int dtype, float* ws, long long ws_floats, void* stream) {
     SUBREG_CHECK_ARG(x && w && y);
     SUBREG_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
     SUBREG_CHECK_ARG(ksize == 1 || ksize == 3);
@@ -773,8 +887,25 @@ extern "C" int subreg_conv_fwd(const void* x, const void* w, void* y, const floa
     a.Cin = Cin; a.Cout = Cout;
     a.act = (flags & SUBREG_CONV_LRELU) ? 1 : 0;
     a.raw = raw ? 1 : 0;
+    a.part = nullptr; a.ksplit = 1;
     hipStream_t s = (hipStream_t)stream;
     const bool wide = (Cout % 160 == 0);
+    if (ws && !pool && !residual && !x2) {
+        // small-M 3x3 layers with a caller-provided workspace: K split over workgroups + reduce pass (see conv_fwd_kernel)
+        const int ks = splitk_plan(dtype, B, H, W, Cin, Cout, ksize);
+        if (ks > 1 && ws_floats >= (long long)ks * a.g.M * Cout) {
+            a.part = ws; a.ksplit = ks;
+            const int rc = launch_rows<__bf16, 1, 5, 4, 1, 9, 3, false, 192, 432, 2, 2, true>(a, s);
+            if (rc == SUBREG_OK) {
+                const int srows = raw ? stats_rows_for(dtype, a.g.M, Cout, W) : (a.g.M + 31) / 32;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(Cout / 32, srows), dim3(256), 0, s, ws, ks, a.g.M, Cout, (__bf16*)y,
+                                   raw ? nullptr : scale, raw ? nullptr : shift, raw ? 0 : a.act, raw ? 1 : 0, stats_partial);
+                return launch_status();
+            }
+            if (rc != SUBREG_EUNSUPPORTED) return rc;
+            a.part = nullptr; a.ksplit = 1;
+        }
+    }
     // LDS per block = 2 patch buffers + 2 weight buffers, sized so that >= 2 workgroups fit a CU (160 KiB).
     // Tile height by problem size: the chip has 256 CUs x 2 resident workgroups, so small-M layers (10x10, 5x5
     // feature maps) take 128- or 64-row tiles to fill it.

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SUBREG_LIB") or os.path.join(_HERE, "libsubreg_hip.so
 F32, BF16 = 0, 1
 CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
 FWD_TRAIN = 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_QUERY_SETS = 32                          # SUBREG_MAX_QUERY_SETS
 
 c_void_p, c_int, c_float, c_longlong = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -53,7 +53,7 @@ class TrainDesc(C.Structure):
                 ("dr2", c_void_p), ("bn_partial", c_void_p), ("pad_x", c_void_p), ("pad_dy", c_void_p),
                 ("zero_shift", c_void_p), ("grad_out_dump", C.POINTER(c_void_p)),
                 ("side_stream", c_void_p), ("events", c_void_p * 6), ("dr_alt", c_void_p), ("bn_partial_side", c_void_p),
-                ("stats_side", c_void_p)]
+                ("stats_side", c_void_p), ("splitk_ws", c_void_p), ("splitk_ws_floats", c_longlong)]
 
 
 class LoopState(C.Structure):
@@ -88,6 +88,7 @@ SIGNATURES = {
     "subreg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "subreg_conv_fwd_ws": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "subreg_conv_stats_rows": (_I, [_I, _I, _I, _I, _I]),
     "subreg_conv_first_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "subreg_conv_fwd_image_shortcut": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -109,6 +110,7 @@ SIGNATURES = {
     "subreg_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_sgd_momentum": (_I, [_P, _P, _P, _L, _F, _F, _F, _I, _P]),
     "subreg_backbone_forward_stash": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P, _I, _I, _I, _P, _P]),
+    "subreg_conv_splitk_floats": (_L, [_I, _I, _I, _I, _I, _I, _I]),
     "subreg_event_create": (_I, [C.POINTER(c_void_p)]),
     "subreg_event_destroy": (_I, [_P]),
     "subreg_backbone_backward": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P, _I, _I, _I, _P]),

@@ -106,6 +106,15 @@ class TrainStash:
         z = torch.zeros(cmax, dtype=f32, device=dev)
         self.keep.append(z)
         self.desc.zero_shift = z.data_ptr()
+        # K-split workspace of the small-M 3x3 convolutions (subreg_conv_fwd_ws): forward shapes and dX shapes (channels swapped)
+        need, h, w = 0, H, W
+        for bi, (name, cin, cout, stride, ds, _db) in enumerate(hb.blocks):
+            for ci, co in ((cin, cout), (cout, cout), (cout, cin)):
+                if ci % 32 == 0:
+                    need = max(need, lib.subreg_conv_splitk_floats(B, h, w, ci, co, 3, hb.dtype))
+            h, w = h // stride, w // stride
+        if need > 0:
+            self.desc.splitk_ws, self.desc.splitk_ws_floats = buf(need, f32).data_ptr(), need
         # two-stream schedule (subreg_train_desc.side_stream; SUBREG_TRAIN_ONE_STREAM=1 keeps the step on one stream for A/B runs):
         # dW chains and the shortcut branch beside the BatchNorm-backward -> dX chain.  The stream, the events and the three extra
         # buffers live as long as this stash.

@@ -510,6 +510,55 @@ def test_conv_raw_stats_and_bn_train(shape, dtype):
     _cmp("running_var", drv.cpu().numpy(), wrv, 1e-5 if dtype == "f32" else 2e-3, 1e-4 if dtype == "f32" else 1e-2)
 
 
+@pytest.mark.parametrize("shape", [(64, 5, 5, 640, 640), (16, 10, 10, 320, 320), (64, 5, 5, 320, 640), (5, 5, 5, 640, 320), (3, 9, 7, 160, 160)])
+def test_conv_split_k_with_workspace(shape):
+    """subreg_conv_fwd_ws on the small-M 3x3 layers of the pretraining step (layer 3.1 / 4.x at B = 64: 52-100 tiles): K split
+    over several workgroups per tile + reduce pass, in both of its modes - raw conv + batch-statistics partials (train-mode
+    forward) and plain scale / shift / LeakyReLU (the dX convolutions) - against the oracle, and against the one-launch path
+    (same bf16 results up to the summation order of the fp32 partial sums)."""
+    B, H, W, Cin, Cout = shape
+    lib = _lib.load()
+    dt = _lib.BF16
+    need = lib.subreg_conv_splitk_floats(B, H, W, Cin, Cout, 3, dt)
+    assert need >= 2 * B * H * W * Cout, "the K split was not planned for this shape"
+    assert lib.subreg_conv_splitk_floats(700, 42, 42, 160, 160, 3, dt) == 0          # big layers: never
+    assert lib.subreg_conv_splitk_floats(B, H, W, Cin, Cout, 1, dt) == 0 and lib.subreg_conv_splitk_floats(B, H, W, Cin, Cout, 3, _lib.F32) == 0
+    rs = np.random.RandomState(17)
+    x = _round_bf16(rs.standard_normal((B, Cin, H, W)).astype(np.float32))
+    w = _round_bf16((rs.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32))
+    raw = rr.conv_nhwc(rr._nhwc(x).astype(np.float64), w.astype(np.float64))
+    xd, wd = _nhwc_dev(x, "bf16"), _pack_w(w, "bf16")
+    ws = torch.full((need,), float("nan"), dtype=torch.float32, device=_dev())
+    M = B * H * W
+    rows = lib.subreg_conv_stats_rows(dt, B, H, W, Cout)
+    outs = []
+    for use_ws in (True, False):
+        stats = torch.full((rows * Cout * 2,), float("nan"), dtype=torch.float32, device=_dev())
+        y = torch.empty(M * Cout, dtype=torch.bfloat16, device=_dev())
+        _lib.check(lib.subreg_conv_fwd_ws(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), None, None, None, _lib.ptr(stats), None, None, 0,
+                                          B, H, W, Cin, Cout, 3, _lib.CONV_RAW_STATS, dt, _lib.ptr(ws) if use_ws else None,
+                                          need if use_ws else 0, _lib.stream_ptr()))
+        st = stats.cpu().numpy().reshape(rows, Cout, 2).astype(np.float64)
+        assert np.isfinite(st).all()
+        outs.append((y.float().cpu().numpy().reshape(M, Cout), st.sum(axis=0)))
+    a, r = _tol("bf16", np.abs(raw).max())
+    flat = raw.reshape(M, Cout)
+    _cmp("raw (split)", outs[0][0], flat, a, r)
+    _cmp("sum", outs[0][1][:, 0], flat.sum(0), 1e-3 * np.abs(flat).sum(0).max(), 1e-4)
+    _cmp("sumsq", outs[0][1][:, 1], (flat * flat).sum(0), 1e-3 * (flat * flat).sum(0).max(), 1e-4)
+    _cmp("raw: split vs one launch", outs[0][0], outs[1][0], 2.0 ** -7 * np.abs(flat).max(), 0)   # one bf16 ulp at the largest value
+    _cmp("stats: split vs one launch", outs[0][1], outs[1][1], 1e-4 * np.abs(outs[1][1]).max(), 1e-5)
+    # plain mode with scale, shift and LeakyReLU (the dX convolutions pass shift = 0, no activation)
+    sc, sh = rs.uniform(0.5, 1.5, Cout).astype(np.float32), (rs.standard_normal(Cout) * 0.2).astype(np.float32)
+    want = rr.leaky_relu(flat * sc + sh)
+    scd, shd = _t(sc), _t(sh)
+    y = torch.empty(M * Cout, dtype=torch.bfloat16, device=_dev())
+    _lib.check(lib.subreg_conv_fwd_ws(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), _lib.ptr(scd), _lib.ptr(shd), None, None, None, None, 0,
+                                      B, H, W, Cin, Cout, 3, _lib.CONV_LRELU, dt, _lib.ptr(ws), need, _lib.stream_ptr()))
+    a, r = _tol("bf16", np.abs(want).max())
+    _cmp("scale/shift/act (split)", y.float().cpu().numpy().reshape(M, Cout), want, a, r)
+
+
 # ---------------------------------------------------------------- backbone against the reference's golden vectors
 def _params_from_sd(sd):
     return {k: _t(v) for k, v in sd.items() if v.dtype != np.int64}

@@ -1,10 +1,8 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_hip_train.py -x -q -m gpu 2>&1 | tail -3
-for r in 1 2; do
-echo "== one stream"; SUBREG_TRAIN_ONE_STREAM=1 python tools/bench_train.py --steps 30 2>&1 | grep -v amdgpu
-echo "== two streams"; python tools/bench_train.py --steps 30 2>&1 | grep -v amdgpu
+for r in 1 2 3; do
+echo "== no split"; SUBREG_NO_SPLITK=1 python tools/bench_train.py --steps 100 2>&1 | grep -v amdgpu
+echo "== split-K"; python tools/bench_train.py --steps 100 2>&1 | grep -v amdgpu
 done
-echo "== one stream 128"; SUBREG_TRAIN_ONE_STREAM=1 python tools/bench_train.py --steps 20 --batch 128 2>&1 | grep -v amdgpu
-echo "== two streams 128"; python tools/bench_train.py --steps 20 --batch 128 2>&1 | grep -v amdgpu
-echo "== one stream 8"; SUBREG_TRAIN_ONE_STREAM=1 python tools/bench_train.py --steps 20 --batch 8 2>&1 | grep -v amdgpu
-echo "== two streams 8"; python tools/bench_train.py --steps 20 --batch 8 2>&1 | grep -v amdgpu
+echo "== one stream, no split"; SUBREG_TRAIN_ONE_STREAM=1 SUBREG_NO_SPLITK=1 python tools/bench_train.py --steps 100 2>&1 | grep -v amdgpu
+echo "== one stream, split"; SUBREG_TRAIN_ONE_STREAM=1 python tools/bench_train.py --steps 100 2>&1 | grep -v amdgpu
+for b in 128 512 8; do echo "== split B=$b"; python tools/bench_train.py --steps 40 --batch $b 2>&1 | grep -v amdgpu; done

@@ -31,7 +31,8 @@ def main():
             s0, e0 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
             gap = (s0 - prev) * 1e-3 if prev is not None else 0.0
             busy += (e0 - s0) * 1e-3
-            print("%9.1f us  +%7.1f us  gap %6.1f  grid %6d x%-3d  %s" % ((s0 - t0) * 1e-3, (e0 - s0) * 1e-3, gap,
+            q = r.get("Stream_Id") or r.get("Queue_Id") or "?"
+            print("%9.1f us  +%7.1f us  gap %6.1f  q%-3s grid %6d x%-3d  %s" % ((s0 - t0) * 1e-3, (e0 - s0) * 1e-3, gap, q,
                   int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), short(r["Kernel_Name"])[:70]))
             prev = max(prev or 0, e0)
         print("span %.1f us, kernel time %.1f us" % ((prev - t0) * 1e-3, busy))
