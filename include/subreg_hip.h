@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUBREG_ABI_VERSION 8
+#define SUBREG_ABI_VERSION 9
 
 #define SUBREG_OK 0
 #define SUBREG_EINVAL (-1)       /* bad argument (null pointer, shape not supported by contract) */
@@ -108,7 +108,8 @@ int subreg_bn_train_finalize(const float* stats_partial, int rows, int C, long l
                              float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
 /* train second pass: y = keep*mask_scale * [pool2]([lrelu]( x*scale+shift + residual*res_scale+res_shift )) */
 int subreg_bn_apply(const void* x, const float* scale, const float* shift, const void* residual, const float* res_scale,
-                    const float* res_shift, const unsigned char* keep_mask, float mask_scale, void* y, int B, int H, int W,
+                    const float* res_shift, const unsigned char* keep_mask, float mask_scale,
+                    const float* mask_scale_dev /* device override of mask_scale, or NULL */, void* y, int B, int H, int W,
                     int C, int flags, int dtype, void* stream);
 /* F.dropout (:299) / DropBlock (:311-325) masks: NCHW {0,1} floats -> NHWC u8 keep mask (invert: keep = 1-mask) */
 int subreg_mask_nchw_to_nhwc(const float* mask_nchw, unsigned char* keep_nhwc, int B, int C, int H, int W, int invert,
@@ -116,6 +117,9 @@ int subreg_mask_nchw_to_nhwc(const float* mask_nchw, unsigned char* keep_nhwc, i
 /* counter-based Bernoulli(1-p_drop) keep mask for free-running train forwards; kept_count may be NULL */
 int subreg_random_keep_mask(unsigned char* keep, long long n, unsigned long long seed, float p_drop, unsigned int* kept_count,
                             void* stream);
+/* DropBlock's rescale factor numel / max(count, 1) (resnet_language.py:318-323) from the counter the mask kernels fill, written
+ * to a device float for subreg_block_desc.mask_scale_dev */
+int subreg_mask_scale(const unsigned int* kept_count, long long numel, float* scale, void* stream);
 /* DropBlock._compute_block_mask (:327-357) for block_size > 1: sample [B][C][H-bs+1][W-bs+1] u8 (1 = seed, NCHW order like
  * the reference's Bernoulli sample) -> keep mask NHWC u8 and the number of kept elements (scale = numel / kept, :320-323);
  * restates the reference's seed / offset pairing (nz.repeat vs offsets.repeat). */
@@ -146,6 +150,8 @@ typedef struct subreg_block_desc {
     int stride;                     /* 2: MaxPool2d(2); 1: identity */
     const unsigned char* keep_mask; /* train: NHWC u8 keep mask of the block output, NULL = keep all */
     float mask_scale;               /* 1/(1-p) for dropout, countM/count_ones for DropBlock */
+    const float* mask_scale_dev;    /* non-NULL: the factor is read from this DEVICE float instead (subreg_mask_scale: DropBlock's
+                                       count_ones stays on the device, as in the reference - no host read per step) */
 } subreg_block_desc;
 
 typedef struct subreg_backbone_desc {
@@ -192,7 +198,8 @@ int subreg_bn_bwd(const void* dy, const void* act, const void* raw, const float*
                   void* stream);
 /* backward of  out = keep*mask_scale * [pool2](lrelu(raw3*scale3+shift3 + residual*res_scale+res_shift))  w.r.t. the
  * pre-activation sum (MaxPool2d: first maximum of the window; BasicBlock.forward :288-299) */
-int subreg_block_tail_bwd(const void* grad_out, const unsigned char* keep_mask, float mask_scale, const void* raw3,
+int subreg_block_tail_bwd(const void* grad_out, const unsigned char* keep_mask, float mask_scale,
+                          const float* mask_scale_dev /* device override or NULL */, const void* raw3,
                           const float* scale3, const float* shift3, const void* residual, const float* res_scale,
                           const float* res_shift, void* dv, int B, int H, int W, int C, int pool, int dtype, void* stream);
 int subreg_avgpool_bwd(const float* dfeat, void* dx, int B, int H, int W, int C, int dtype, void* stream);

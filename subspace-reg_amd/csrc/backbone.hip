@@ -172,10 +172,10 @@ extern "C" int subreg_backbone_forward(const subreg_backbone_desc* d, const floa
             out_slot = fs[0];
         } else {
             TRY(conv_train(d, b.conv1, cur, A, B, h, w, stream));
-            TRY(subreg_bn_apply(A, b.conv1.scale, b.conv1.shift, nullptr, nullptr, nullptr, nullptr, 1.f, A, B, h, w,
+            TRY(subreg_bn_apply(A, b.conv1.scale, b.conv1.shift, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, A, B, h, w,
                                 b.conv1.cout, SUBREG_CONV_LRELU, dt, stream));
             TRY(conv_train(d, b.conv2, A, Bf, B, h, w, stream));
-            TRY(subreg_bn_apply(Bf, b.conv2.scale, b.conv2.shift, nullptr, nullptr, nullptr, nullptr, 1.f, Bf, B, h, w,
+            TRY(subreg_bn_apply(Bf, b.conv2.scale, b.conv2.shift, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, Bf, B, h, w,
                                 b.conv2.cout, SUBREG_CONV_LRELU, dt, stream));
             TRY(conv_train(d, b.conv3, Bf, A, B, h, w, stream));
             const void* res = cur;
@@ -184,7 +184,7 @@ extern "C" int subreg_backbone_forward(const subreg_backbone_desc* d, const floa
                 TRY(conv_train(d, b.down, cur, C, B, h, w, stream));
                 res = C; rsc = b.down.scale; rsh = b.down.shift;
             }
-            TRY(subreg_bn_apply(A, b.conv3.scale, b.conv3.shift, res, rsc, rsh, b.keep_mask, b.mask_scale, Bf, B, h, w,
+            TRY(subreg_bn_apply(A, b.conv3.scale, b.conv3.shift, res, rsc, rsh, b.keep_mask, b.mask_scale, b.mask_scale_dev, Bf, B, h, w,
                                 b.conv3.cout, SUBREG_CONV_LRELU | pflag, dt, stream));
             out_slot = fs[1];
         }

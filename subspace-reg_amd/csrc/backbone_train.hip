@@ -88,14 +88,14 @@ extern "C" int subreg_backbone_forward_stash(const subreg_backbone_desc* d, cons
             res = tb.down.raw; rsc = tb.down.bscale; rsh = tb.down.bshift;
         }
         TRY(conv_stash(d, b.conv1, tb.conv1, cur, B, h, w, d->stats, t->splitk_ws, t->splitk_ws_floats, stream));
-        TRY(subreg_bn_apply(tb.conv1.raw, tb.conv1.bscale, tb.conv1.bshift, nullptr, nullptr, nullptr, nullptr, 1.f, tb.conv1.act, B, h,
+        TRY(subreg_bn_apply(tb.conv1.raw, tb.conv1.bscale, tb.conv1.bshift, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, tb.conv1.act, B, h,
                             w, b.conv1.cout, SUBREG_CONV_LRELU, dt, stream));
         TRY(conv_stash(d, b.conv2, tb.conv2, tb.conv1.act, B, h, w, d->stats, t->splitk_ws, t->splitk_ws_floats, stream));
-        TRY(subreg_bn_apply(tb.conv2.raw, tb.conv2.bscale, tb.conv2.bshift, nullptr, nullptr, nullptr, nullptr, 1.f, tb.conv2.act, B, h,
+        TRY(subreg_bn_apply(tb.conv2.raw, tb.conv2.bscale, tb.conv2.bshift, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, tb.conv2.act, B, h,
                             w, b.conv2.cout, SUBREG_CONV_LRELU, dt, stream));
         TRY(conv_stash(d, b.conv3, tb.conv3, tb.conv2.act, B, h, w, d->stats, t->splitk_ws, t->splitk_ws_floats, stream));
         if (b.down.w) TRY(f.main_waits(EV_DOWN));
-        TRY(subreg_bn_apply(tb.conv3.raw, tb.conv3.bscale, tb.conv3.bshift, res, rsc, rsh, b.keep_mask, b.mask_scale, tb.out, B, h, w,
+        TRY(subreg_bn_apply(tb.conv3.raw, tb.conv3.bscale, tb.conv3.bshift, res, rsc, rsh, b.keep_mask, b.mask_scale, b.mask_scale_dev, tb.out, B, h, w,
                             b.conv3.cout, SUBREG_CONV_LRELU | pflag, dt, stream));
         cur = tb.out;
         if (b.stride == 2) { h /= 2; w /= 2; }
@@ -148,7 +148,7 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
                                hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return SUBREG_EHIP;
         }
         // d(pre-activation sum) from d(out): keep mask, max-pool routing, LeakyReLU'
-        TRY(subreg_block_tail_bwd(t->g[gi], b.keep_mask, b.mask_scale, tb.conv3.raw, tb.conv3.bscale, tb.conv3.bshift, res,
+        TRY(subreg_block_tail_bwd(t->g[gi], b.keep_mask, b.mask_scale, b.mask_scale_dev, tb.conv3.raw, tb.conv3.bscale, tb.conv3.bshift, res,
                                   b.down.w ? tb.down.bscale : nullptr, b.down.w ? tb.down.bshift : nullptr, t->dv, B, bh, bw, C,
                                   b.stride == 2, dt, stream));
         // shortcut branch (BN backward -> dr2, dW): needs only dv; all of it on the side stream

@@ -28,12 +28,14 @@ __device__ __forceinline__ float lrelu_grad(float pre) { return pre > 0.f ? 1.f 
 // edge also zero the column / row that floor pooling drops, so dV needs no separate zero-fill pass.
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void block_tail_bwd_kernel(const T* __restrict__ gout, const unsigned char* __restrict__ keep,
-                                                             float mask_scale, const T* __restrict__ raw3,
+                                                             float mask_scale_host, const float* __restrict__ mask_scale_dev,
+                                                             const T* __restrict__ raw3,
                                                              const float* __restrict__ sc3, const float* __restrict__ sh3,
                                                              const T* __restrict__ res, const float* __restrict__ rsc,
                                                              const float* __restrict__ rsh, T* __restrict__ dv, int H, int W, int C,
                                                              long long npo, int ppb) {
     constexpr int VEC = 16 / sizeof(T);
+    const float mask_scale = mask_scale_dev ? *mask_scale_dev : mask_scale_host;
     const int ngrp = C / VEC, lanes = 256 / ngrp;
     const int cg = threadIdx.x % ngrp, pl = threadIdx.x / ngrp;
     if (pl >= lanes) return;
@@ -789,7 +791,8 @@ using namespace subreg;
     else if ((dtype) == SUBREG_BF16) { CALL_BF16; } \
     else return SUBREG_EINVAL;
 
-extern "C" int subreg_block_tail_bwd(const void* grad_out, const unsigned char* keep_mask, float mask_scale, const void* raw3,
+extern "C" int subreg_block_tail_bwd(const void* grad_out, const unsigned char* keep_mask, float mask_scale,
+                                     const float* mask_scale_dev, const void* raw3,
                                      const float* scale3, const float* shift3, const void* residual, const float* res_scale,
                                      const float* res_shift, void* dv, int B, int H, int W, int C, int pool, int dtype,
                                      void* stream) {
@@ -803,7 +806,7 @@ extern "C" int subreg_block_tail_bwd(const void* grad_out, const unsigned char* 
     ppb = (ppb + lanes - 1) / lanes * lanes;
     if (ppb < lanes) ppb = lanes;
     const int grid = (int)((npo + ppb - 1) / ppb);
-#define BTB(TT, P) hipLaunchKernelGGL((block_tail_bwd_kernel<TT, P>), grid, 256, 0, s, (const TT*)grad_out, keep_mask, mask_scale, (const TT*)raw3, \
+#define BTB(TT, P) hipLaunchKernelGGL((block_tail_bwd_kernel<TT, P>), grid, 256, 0, s, (const TT*)grad_out, keep_mask, mask_scale, mask_scale_dev, (const TT*)raw3, \
                                       scale3, shift3, (const TT*)residual, res_scale, res_shift, (TT*)dv, H, W, C, npo, (int)ppb)
     DISPATCH_T(dtype, if (pool) BTB(float, true); else BTB(float, false), if (pool) BTB(__bf16, true); else BTB(__bf16, false));
 #undef BTB

@@ -188,10 +188,12 @@ template <typename T, bool POOL, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const T* __restrict__ res,
                                                        const float* __restrict__ rscale, const float* __restrict__ rshift,
-                                                       const unsigned char* __restrict__ keep, float mask_scale,
+                                                       const unsigned char* __restrict__ keep, float mask_scale_host,
+                                                       const float* __restrict__ mask_scale_dev,
                                                        T* __restrict__ y, int H, int W, int C, int act, long long npo,
                                                        int ppb) {
     constexpr int VEC = 16 / sizeof(T), UN = POOL ? 1 : 4;
+    const float mask_scale = mask_scale_dev ? *mask_scale_dev : mask_scale_host;   // DropBlock: numel / count, still on the device
     const int ngrp = C / VEC, lanes = 256 / ngrp;
     const int cg = threadIdx.x % ngrp, pl = threadIdx.x / ngrp;
     if (pl >= lanes) return;
@@ -481,7 +483,8 @@ extern "C" int subreg_bn_train_finalize(const float* stats_partial, int rows, in
 
 extern "C" int subreg_bn_apply(const void* x, const float* scale, const float* shift, const void* residual,
                                const float* res_scale, const float* res_shift, const unsigned char* keep_mask,
-                               float mask_scale, void* y, int B, int H, int W, int C, int flags, int dtype, void* stream) {
+                               float mask_scale, const float* mask_scale_dev, void* y, int B, int H, int W, int C, int flags,
+                               int dtype, void* stream) {
     SUBREG_CHECK_ARG(x && scale && shift && y && B > 0 && H > 0 && W > 0 && C > 0);
     const int act = (flags & SUBREG_CONV_LRELU) ? 1 : 0, pool = (flags & SUBREG_CONV_POOL2) ? 1 : 0;
     SUBREG_CHECK_ARG(!pool || (H >= 2 && W >= 2));
@@ -498,7 +501,7 @@ extern "C" int subreg_bn_apply(const void* x, const float* scale, const float* s
     if (ppb < step) ppb = step;
     const int grid = (int)((npo + ppb - 1) / ppb);
 #define BNA(TT, P, R) hipLaunchKernelGGL((bn_apply_kernel<TT, P, R>), grid, 256, 0, s, (const TT*)x, scale, shift, (const TT*)residual, \
-                                         res_scale, res_shift, keep_mask, mask_scale, (TT*)y, H, W, C, act, npo, (int)ppb)
+                                         res_scale, res_shift, keep_mask, mask_scale, mask_scale_dev, (TT*)y, H, W, C, act, npo, (int)ppb)
 #define BNA_T(TT) do { if (pool) { if (residual) BNA(TT, true, true); else BNA(TT, true, false); } \
                        else { if (residual) BNA(TT, false, true); else BNA(TT, false, false); } } while (0)
     DISPATCH_T(dtype, BNA_T(float), BNA_T(__bf16));
@@ -521,6 +524,18 @@ extern "C" int subreg_random_keep_mask(unsigned char* keep, long long n, unsigne
     SUBREG_CHECK_ARG(keep && n > 0 && p_drop >= 0.f && p_drop < 1.f);
     hipLaunchKernelGGL(random_keep_kernel, dim3((unsigned)(((size_t)n + 4095) / 4096)), dim3(256), 0, (hipStream_t)stream, keep,
                        (size_t)n, seed, p_drop, kept_count);
+    return launch_status();
+}
+
+// DropBlock's rescale factor countM / count_ones (resnet_language.py:318-323) from the device-side counter of the mask kernels:
+// (float)(numel / max(count, 1)) in double like the host expression it replaces - without the host reading the counter
+__global__ void mask_scale_kernel(const unsigned int* __restrict__ count, double numel, float* __restrict__ scale) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned int c = *count; *scale = (float)(numel / (double)(c > 0 ? c : 1)); }
+}
+
+extern "C" int subreg_mask_scale(const unsigned int* kept_count, long long numel, float* scale, void* stream) {
+    SUBREG_CHECK_ARG(kept_count && scale && numel > 0);
+    hipLaunchKernelGGL(mask_scale_kernel, 1, 64, 0, (hipStream_t)stream, kept_count, (double)numel, scale);
     return launch_status();
 }
 

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SUBREG_LIB") or os.path.join(_HERE, "libsubreg_hip.so
 F32, BF16 = 0, 1
 CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
 FWD_TRAIN = 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_QUERY_SETS = 32                          # SUBREG_MAX_QUERY_SETS
 
 c_void_p, c_int, c_float, c_longlong = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
 class BlockDesc(C.Structure):
     _fields_ = [("conv1", ConvDesc), ("conv2", ConvDesc), ("conv3", ConvDesc), ("down", ConvDesc),
                 ("w_identity", c_void_p), ("shift3", c_void_p), ("stride", c_int), ("keep_mask", c_void_p),
-                ("mask_scale", c_float)]
+                ("mask_scale", c_float), ("mask_scale_dev", c_void_p)]
 
 
 class BackboneDesc(C.Structure):
@@ -106,7 +106,7 @@ SIGNATURES = {
     "subreg_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_bn_bwd_slices": (_I, [_L]),
     "subreg_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
-    "subreg_block_tail_bwd": (_I, [_P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "subreg_block_tail_bwd": (_I, [_P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "subreg_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_sgd_momentum": (_I, [_P, _P, _P, _L, _F, _F, _F, _I, _P]),
     "subreg_backbone_forward_stash": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P, _I, _I, _I, _P, _P]),
@@ -117,7 +117,8 @@ SIGNATURES = {
     "subreg_backbone_backward_blocks": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P, _I, _I, _I, _I, _I, _P]),
     "subreg_backbone_pack_train": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P]),
     "subreg_sgd_pack_train": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P, _P, _P, _F, _F, _F, _I, _P]),
-    "subreg_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "subreg_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "subreg_mask_scale": (_I, [_P, _L, _P, _P]),
     "subreg_mask_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_random_keep_mask": (_I, [_P, _L, C.c_ulonglong, _F, _P, _P]),
     "subreg_dropblock_mask": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),

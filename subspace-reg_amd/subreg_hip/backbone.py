@@ -207,10 +207,24 @@ class HipBackbone:
         self._keep = []
         s = _lib.stream_ptr()
         h, w = H, W
+        # DropBlock's count_ones and the rescale factor numel / count_ones stay on the device (one counter and one float per
+        # block), as in the reference (:318-323): reading them back cost two host synchronisations per training step
+        counts = torch.zeros(len(self.blocks), dtype=torch.int32, device=self.device)
+        self._mask_scale_dev = torch.ones(len(self.blocks), dtype=torch.float32, device=self.device)
+        self._mask_counts = counts
+
+        def device_scale(bi, n):
+            if os.environ.get("SUBREG_MASK_HOST_COUNT") == "1":      # A/B switch: the earlier host read of the counter
+                return n / max(int(counts[bi].item()), 1)
+            _lib.check(self.lib.subreg_mask_scale(_lib.ptr(counts[bi:]), n, _lib.ptr(self._mask_scale_dev[bi:]), s), "mask_scale")
+            self._blk[bi].mask_scale_dev = self._mask_scale_dev[bi:].data_ptr()
+            return 0.0                             # the host-side field is not read when mask_scale_dev is set
+
         for bi, (name, _cin, cout, stride, _ds, db) in enumerate(self.blocks):
             h, w = h // stride, w // stride
             n = B * cout * h * w
             keep = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._blk[bi].mask_scale_dev = None
             if not db:
                 scale = float(np.float32(1.0) / np.float32(1.0 - DROP_RATE))
                 if masks is None:
@@ -224,10 +238,9 @@ class HipBackbone:
                 gamma = dropblock_gamma(self.nbt[bi], h, bs)
                 shape = (B, cout, h - (bs - 1), w - (bs - 1))
                 if masks is None and bs == 1:
-                    cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
                     _lib.check(self.lib.subreg_random_keep_mask(_lib.ptr(keep), n, int(torch.randint(0, 2 ** 62, (1,))),
-                                                                float(gamma), _lib.ptr(cnt), s), "random_keep_mask")
-                    scale = n / max(int(cnt.item()), 1)
+                                                                float(gamma), _lib.ptr(counts[bi:]), s), "random_keep_mask")
+                    scale = device_scale(bi, n)
                 elif bs == 1:                                   # injected element mask (block_size 1)
                     bm = 1.0 - masks.bernoulli(shape, gamma)
                     scale = bm.size / bm.sum()
@@ -243,13 +256,18 @@ class HipBackbone:
                         sample = torch.empty(ns, dtype=torch.uint8, device=self.device)
                         _lib.check(self.lib.subreg_random_keep_mask(_lib.ptr(sample), ns, int(torch.randint(0, 2 ** 62, (1,))),
                                                                     float(1.0 - gamma), None, s), "random_keep_mask")   # 1 with probability gamma
-                    cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
-                    _lib.check(self.lib.subreg_dropblock_mask(_lib.ptr(sample), _lib.ptr(keep), B, cout, h, w, bs, _lib.ptr(cnt), s),
+                    _lib.check(self.lib.subreg_dropblock_mask(_lib.ptr(sample), _lib.ptr(keep), B, cout, h, w, bs, _lib.ptr(counts[bi:]), s),
                                "dropblock_mask")
-                    scale = n / max(int(cnt.item()), 1)
+                    scale = device_scale(bi, n)
             self._keep.append(keep)
             self._blk[bi].keep_mask = keep.data_ptr()
             self._blk[bi].mask_scale = float(scale)
+
+    def mask_scale(self, bi):
+        """The rescale factor of block bi's keep mask as a host float (tests / diagnostics: synchronises when it lives on the device)."""
+        if self._blk[bi].mask_scale_dev:
+            return float(self._mask_scale_dev[bi].item())
+        return float(self._blk[bi].mask_scale)
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, train=False, masks=None, return_stages=False, out=None, check_params=True):

@@ -501,7 +501,7 @@ def test_conv_raw_stats_and_bn_train(shape, dtype):
     _lib.check(lib.subreg_bn_train_finalize(_lib.ptr(stats), rows, Cout, B * H * W, _lib.ptr(gwd), _lib.ptr(gbd),
                                             _lib.ptr(drm), _lib.ptr(drv), 0.1, 1e-5, _lib.ptr(sc), _lib.ptr(sh), None, None,
                                             _lib.stream_ptr()))
-    _lib.check(lib.subreg_bn_apply(_lib.ptr(y), _lib.ptr(sc), _lib.ptr(sh), None, None, None, None, 1.0, _lib.ptr(y), B, H, W,
+    _lib.check(lib.subreg_bn_apply(_lib.ptr(y), _lib.ptr(sc), _lib.ptr(sh), None, None, None, None, 1.0, None, _lib.ptr(y), B, H, W,
                                    Cout, _lib.CONV_LRELU, dt, _lib.stream_ptr()))
     got = _nchw_host(y, B, Cout, H, W, dtype)
     a, r = _tol(dtype, np.abs(want).max())

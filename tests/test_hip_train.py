@@ -162,7 +162,7 @@ def test_block_tail_backward(pool, dtype):
     r3, rd, gd, kd = f(raw3), f(res), f(gout), torch.from_numpy(keep.astype(np.uint8)).to(dev)
     scd, shd, rscd, rshd = _t(sc), _t(sh), _t(rsc), _t(rsh)
     dv = torch.full((B * H * W * Cc,), float("nan"), device=dev, dtype=_td(dtype))
-    _lib.check(lib.subreg_block_tail_bwd(_lib.ptr(gd), _lib.ptr(kd), 1.25, _lib.ptr(r3), _lib.ptr(scd), _lib.ptr(shd), _lib.ptr(rd),
+    _lib.check(lib.subreg_block_tail_bwd(_lib.ptr(gd), _lib.ptr(kd), 1.25, None, _lib.ptr(r3), _lib.ptr(scd), _lib.ptr(shd), _lib.ptr(rd),
                                          _lib.ptr(rscd), _lib.ptr(rshd), _lib.ptr(dv), B, H, W, Cc, pool, _lib.dtype_code(dtype), _lib.stream_ptr()))
     torch.cuda.synchronize()
     tol = 1e-5 if dtype == "f32" else 1e-2
@@ -465,7 +465,7 @@ def _hip_stash_as_oracle_input(net, B, hw):
         d["act1"], d["act2"] = grab((bi, "conv1", "act")), grab((bi, "conv2", "act"))
         ho = h // stride
         d["out"] = grab((bi, "out"), hh=ho)
-        d["keep"] = hb._keep[bi].cpu().numpy().reshape(B, ho, ho, cout).astype(np.float64) * float(hb._blk[bi].mask_scale)
+        d["keep"] = hb._keep[bi].cpu().numpy().reshape(B, ho, ho, cout).astype(np.float64) * hb.mask_scale(bi)
         out[name] = d
         h = ho
     return out

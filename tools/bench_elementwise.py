@@ -70,12 +70,12 @@ def main():
         partial = torch.empty(lib.subreg_bn_bwd_slices(npix) * Cc * 2, dtype=torch.float64, device=dev)
         P = _lib.ptr
         # train-mode forward, second pass of bn1 / bn2: act = lrelu(raw * scale + shift)
-        us = t_of(lambda: _lib.check(lib.subreg_bn_apply(P(raw), P(sc), P(sh), None, None, None, None, 1.0, P(act), B, H, H, Cc,
+        us = t_of(lambda: _lib.check(lib.subreg_bn_apply(P(raw), P(sc), P(sh), None, None, None, None, 1.0, None, P(act), B, H, H, Cc,
                                                          _lib.CONV_LRELU, dt, s())))
         line("bn_apply (bn1/bn2 + LeakyReLU)", name, us, 2 * n * 2)
         # block tail: out = keep * pool(lrelu(bn3(raw3) + bn_ds(res)))
         fl = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0)
-        us = t_of(lambda: _lib.check(lib.subreg_bn_apply(P(raw), P(sc), P(sh), P(res), P(sc), P(sh), P(keep), 1.11, P(out), B, H, H, Cc,
+        us = t_of(lambda: _lib.check(lib.subreg_bn_apply(P(raw), P(sc), P(sh), P(res), P(sc), P(sh), P(keep), 1.11, None, P(out), B, H, H, Cc,
                                                          fl, dt, s())))
         line("bn_apply (block tail, +res, pool)", name, us, 2 * n * 2 + nout * 3)
         # BN backward (reduce + finalize + apply), with and without the fused LeakyReLU'
@@ -86,7 +86,7 @@ def main():
             line("bn_bwd (reduce+finalize+apply)%s" % (" +act" if with_act else ""), name, us, (2 * nt + 1) * n * 2)
         # block tail backward
         dv = torch.empty(n, device=dev, dtype=bf)
-        us = t_of(lambda: _lib.check(lib.subreg_block_tail_bwd(P(gout), P(keep), 1.11, P(raw), P(sc), P(sh), P(res), P(sc), P(sh), P(dv), B, H,
+        us = t_of(lambda: _lib.check(lib.subreg_block_tail_bwd(P(gout), P(keep), 1.11, None, P(raw), P(sc), P(sh), P(res), P(sc), P(sh), P(dv), B, H,
                                                                H, Cc, 1 if pool else 0, dt, s())))
         line("block_tail_bwd", name, us, nout * 3 + 3 * n * 2)
     # first-layer packing and the global average pool

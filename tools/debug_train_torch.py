@@ -74,7 +74,7 @@ gout = outs[bi].grad.permute(0, 2, 3, 1).float().contiguous()
 dv, dr, dt = [torch.zeros(Bq * H * W * C, device="cuda") for _ in range(3)]
 keep = hb._keep[bi]
 xin = nm[(bi - 1, "out")]
-_lib.check(lib.subreg_block_tail_bwd(_lib.ptr(gout), _lib.ptr(keep), float(hb._blk[bi].mask_scale), _lib.ptr(nm[(bi, "conv3", "raw")]),
+_lib.check(lib.subreg_block_tail_bwd(_lib.ptr(gout), _lib.ptr(keep), hb.mask_scale(bi), None, _lib.ptr(nm[(bi, "conv3", "raw")]),
            _lib.ptr(nm[(bi, "conv3", "bscale")]), _lib.ptr(nm[(bi, "conv3", "bshift")]), _lib.ptr(xin), None, None, _lib.ptr(dv), Bq, H, W, C, 0, 0, sp()))
 part = torch.zeros(lib.subreg_bn_bwd_slices(Bq * H * W) * C * 2, dtype=torch.float64, device="cuda")
 dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
