@@ -61,6 +61,16 @@ struct Fork {
 };
 enum { EV_FORK = 0, EV_DOWN = 1, EV_READY0 = 2, EV_READY1 = 3, EV_DONE0 = 4, EV_DONE1 = 5 };
 
+// Every event record / wait between two kernels of a stream costs a ~6 us bubble there (in-trace gaps), so the fork only pays
+// where the launches it overlaps leave CUs idle.  First block (counted from the input) whose backward / forward forks; measured
+// with tools/bench_train.py (profiles/r03_ab_train_two_streams.txt).  Environment overrides are for such measurements.
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+int fork_bwd_from() { static const int v = env_int("SUBREG_TRAIN_FORK_FROM", 0); return v; }
+int fork_fwd_from() { static const int v = env_int("SUBREG_TRAIN_FORK_FWD_FROM", 0); return v; }
+
 }  // namespace
 
 extern "C" int subreg_backbone_forward_stash(const subreg_backbone_desc* d, const subreg_train_desc* t, const float* x_nchw, int B,
@@ -80,11 +90,12 @@ extern "C" int subreg_backbone_forward_stash(const subreg_backbone_desc* d, cons
         SUBREG_CHECK_ARG(tb.conv1.raw && tb.conv1.act && tb.conv2.raw && tb.conv2.act && tb.conv3.raw && tb.out);
         const void* res = cur;
         const float *rsc = nullptr, *rsh = nullptr;
+        const bool fork = f.on && i >= fork_fwd_from();
         if (b.down.w) {                    // the 1x1 shortcut conv + its statistics: beside conv1..conv3 on the side stream
             SUBREG_CHECK_ARG(tb.down.raw != nullptr);
-            TRY(f.main_to_side(EV_FORK));
-            TRY(conv_stash(d, b.down, tb.down, cur, B, h, w, f.on ? t->stats_side : d->stats, nullptr, 0, f.side));
-            TRY(f.mark_side(EV_DOWN));
+            if (fork) TRY(f.main_to_side(EV_FORK));
+            TRY(conv_stash(d, b.down, tb.down, cur, B, h, w, fork ? t->stats_side : d->stats, nullptr, 0, fork ? f.side : f.main));
+            if (fork) TRY(f.mark_side(EV_DOWN));
             res = tb.down.raw; rsc = tb.down.bscale; rsh = tb.down.bshift;
         }
         TRY(conv_stash(d, b.conv1, tb.conv1, cur, B, h, w, d->stats, t->splitk_ws, t->splitk_ws_floats, stream));
@@ -94,7 +105,7 @@ extern "C" int subreg_backbone_forward_stash(const subreg_backbone_desc* d, cons
         TRY(subreg_bn_apply(tb.conv2.raw, tb.conv2.bscale, tb.conv2.bshift, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, tb.conv2.act, B, h,
                             w, b.conv2.cout, SUBREG_CONV_LRELU, dt, stream));
         TRY(conv_stash(d, b.conv3, tb.conv3, tb.conv2.act, B, h, w, d->stats, t->splitk_ws, t->splitk_ws_floats, stream));
-        if (b.down.w) TRY(f.main_waits(EV_DOWN));
+        if (b.down.w && fork) TRY(f.main_waits(EV_DOWN));
         TRY(subreg_bn_apply(tb.conv3.raw, tb.conv3.bscale, tb.conv3.bshift, res, rsc, rsh, b.keep_mask, b.mask_scale, b.mask_scale_dev, tb.out, B, h, w,
                             b.conv3.cout, SUBREG_CONV_LRELU | pflag, dt, stream));
         cur = tb.out;
@@ -123,15 +134,27 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
     bool down_busy = false;
     int use = 0;
     // BN backward on main into drb[k]; its dW chain on the side stream; returns the buffer for the dX convolution on main
+    bool fork = false;                                          // this block's dW chains / shortcut branch go to the side stream
+    auto join = [&]() -> int {                                  // main continues after everything the side stream was given
+        if (down_busy) TRY(f.main_waits(EV_DOWN));
+        for (int k = 0; k < 2; ++k)
+            if (busy[k]) TRY(f.main_waits(EV_DONE0 + k));
+        down_busy = busy[0] = busy[1] = false;
+        return SUBREG_OK;
+    };
     auto bn_then_wgrad = [&](const subreg_conv_desc& c, const subreg_conv_train& tc, const void* dy, const void* act,
                              const void* conv_input, int bh, int bw, const void** draw_out) -> int {
         const int k = use++ & 1;
-        if (busy[k]) TRY(f.main_waits(EV_DONE0 + k));
+        if (busy[k]) { TRY(f.main_waits(EV_DONE0 + k)); busy[k] = false; }
         TRY(bn_backward(d, c, tc, dy, act, drb[k], t->bn_partial, B, bh, bw, stream));
-        TRY(f.main_to_side(EV_READY0 + k));
-        TRY(weight_grad(d, t, c, tc, conv_input, drb[k], B, bh, bw, f.side));
-        TRY(f.mark_side(EV_DONE0 + k));
-        busy[k] = f.on;
+        if (fork) {
+            TRY(f.main_to_side(EV_READY0 + k));
+            TRY(weight_grad(d, t, c, tc, conv_input, drb[k], B, bh, bw, f.side));
+            TRY(f.mark_side(EV_DONE0 + k));
+            busy[k] = true;
+        } else {
+            TRY(weight_grad(d, t, c, tc, conv_input, drb[k], B, bh, bw, stream));
+        }
         *draw_out = drb[k];
         return SUBREG_OK;
     };
@@ -142,6 +165,9 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
         const void* xin = i == 0 ? d->col : t->blocks[i - 1].out;
         const int bh = hs[i], bw = ws[i], C = b.conv3.cout;
         const void* res = b.down.w ? tb.down.raw : xin;
+        const bool fork_now = f.on && i >= fork_bwd_from();
+        if (fork && !fork_now) TRY(join());     // the one-stream blocks use the dW scratch buffers (pad_x, pad_dy, gw) on main
+        fork = fork_now;
         if (t->grad_out_dump && t->grad_out_dump[i]) {
             const int oh = b.stride == 2 ? bh / 2 : bh, ow = b.stride == 2 ? bw / 2 : bw;
             if (hipMemcpyAsync(t->grad_out_dump[i], t->g[gi], (size_t)B * oh * ow * C * (dt == SUBREG_BF16 ? 2 : 4),
@@ -152,12 +178,12 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
                                   b.down.w ? tb.down.bscale : nullptr, b.down.w ? tb.down.bshift : nullptr, t->dv, B, bh, bw, C,
                                   b.stride == 2, dt, stream));
         // shortcut branch (BN backward -> dr2, dW): needs only dv; all of it on the side stream
-        if (b.down.w) {
+        if (b.down.w && fork) {
             TRY(f.main_to_side(EV_FORK));
-            TRY(bn_backward(d, b.down, tb.down, t->dv, nullptr, t->dr2, f.on ? t->bn_partial_side : t->bn_partial, B, bh, bw, f.side));
+            TRY(bn_backward(d, b.down, tb.down, t->dv, nullptr, t->dr2, t->bn_partial_side, B, bh, bw, f.side));
             TRY(weight_grad(d, t, b.down, tb.down, xin, t->dr2, B, bh, bw, f.side));
             TRY(f.mark_side(EV_DOWN));
-            down_busy = f.on;
+            down_busy = true;
         }
         // main branch: bn3/conv3 -> bn2/conv2 -> bn1/conv1
         const void* dr = nullptr;
@@ -168,6 +194,10 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
         TRY(subreg_conv_fwd_ws(dr, tb.conv2.w_dgrad, t->dt, nullptr, t->zero_shift, nullptr, nullptr, nullptr, nullptr, 0, B, bh, bw,
                                b.conv2.cout, b.conv2.cin, b.conv2.ksize_raw, 0, dt, t->splitk_ws, t->splitk_ws_floats, stream));
         TRY(bn_then_wgrad(b.conv1, tb.conv1, t->dt, tb.conv1.act, xin, bh, bw, &dr));
+        if (b.down.w && !fork) {           // shortcut branch on the main stream (after conv1's chain: they share the dW scratch)
+            TRY(bn_backward(d, b.down, tb.down, t->dv, nullptr, t->dr2, t->bn_partial, B, bh, bw, stream));
+            TRY(weight_grad(d, t, b.down, tb.down, xin, t->dr2, B, bh, bw, stream));
+        }
         // the shortcut branch's results (dr2) and its reads of dv: main continues after them
         if (down_busy) { TRY(f.main_waits(EV_DOWN)); down_busy = false; }
         if (i == 0) break;                 // no gradient w.r.t. the images
@@ -183,10 +213,7 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
         }
     }
     // join: every gradient of these blocks is complete in main-stream order when this call's work is
-    if (down_busy) TRY(f.main_waits(EV_DOWN));
-    for (int k = 0; k < 2; ++k)
-        if (busy[k]) TRY(f.main_waits(EV_DONE0 + k));
-    return SUBREG_OK;
+    return join();
 }
 
 extern "C" int subreg_event_create(void** event) {

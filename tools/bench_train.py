@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--host-time", action="store_true", help="also print the host-side enqueue time of a step")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     net = create_model("resnet18", 60, SimpleNamespace(no_dropblock=True, linear_bias=False, hip_dtype=a.dtype))
@@ -43,6 +44,17 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
+    if a.host_time:
+        # host enqueue time of one step: the device is idle and its queues empty when the step's calls start, so what is timed
+        # is Python + launch overhead alone (the step is host-bound wherever this exceeds the device time)
+        ht = []
+        for _ in range(a.steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step()
+            ht.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        print("host enqueue time per step B=%d: median %.2f ms, min %.2f ms" % (a.batch, 1e3 * float(np.median(ht)), 1e3 * min(ht)))
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()

@@ -36,6 +36,26 @@ def main():
                   int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), short(r["Kernel_Name"])[:70]))
             prev = max(prev or 0, e0)
         print("span %.1f us, kernel time %.1f us" % ((prev - t0) * 1e-3, busy))
+        if "--step" in sys.argv:
+            # one training step = from one `--step <kernel substring>` launch to the next: span, union of busy intervals, idle gaps
+            key = sys.argv[sys.argv.index("--step") + 1]
+            marks = [i for i, r in enumerate(rows) if key in r["Kernel_Name"]]
+            if len(marks) >= 2:
+                seg = rows[marks[-2]:marks[-1]]
+                iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in seg)
+                cur_s, cur_e, union, gaps = iv[0][0], iv[0][1], 0, []
+                for a, b in iv[1:]:
+                    if a > cur_e:
+                        union += cur_e - cur_s
+                        gaps.append((a - cur_e, cur_e - iv[0][0]))
+                        cur_s, cur_e = a, b
+                    else:
+                        cur_e = max(cur_e, b)
+                union += cur_e - cur_s
+                span = int(rows[marks[-1]]["Start_Timestamp"]) - iv[0][0]
+                print("step: %d launches, span %.1f us, busy (union) %.1f us, idle %.1f us; sum of kernel times %.1f us" %
+                      (len(seg), span * 1e-3, union * 1e-3, (span - union) * 1e-3, sum(b - a for a, b in iv) * 1e-3))
+                print("largest idle gaps (us @ offset): " + ", ".join("%.1f@%.0f" % (g * 1e-3, o * 1e-3) for g, o in sorted(gaps, reverse=True)[:12]))
         return
     top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 25
     per, geo = defaultdict(lambda: [0, 0.0]), defaultdict(lambda: [0, 0.0])
