@@ -1,7 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for r in 1 2; do
-for k in 0 1 2 3 4 6; do echo "== bwd fork from block $k (fwd 0)"; SUBREG_TRAIN_FORK_FROM=$k python tools/bench_train.py --steps 80 2>&1 | grep -v amdgpu; done
-for k in 1 2 3 6; do echo "== fwd fork from block $k (bwd 0)"; SUBREG_TRAIN_FORK_FWD_FROM=$k python tools/bench_train.py --steps 80 2>&1 | grep -v amdgpu; done
-done
-for k in 0 2 6; do echo "== B=128 bwd fork from $k"; SUBREG_TRAIN_FORK_FROM=$k python tools/bench_train.py --steps 40 --batch 128 2>&1 | grep -v amdgpu; done
-for k in 2 6; do echo "== B=128 fwd fork from $k"; SUBREG_TRAIN_FORK_FWD_FROM=$k python tools/bench_train.py --steps 40 --batch 128 2>&1 | grep -v amdgpu; done
+timeout 900 python -m pytest tests/test_hip_kernels.py tests/test_hip_train.py -x -q -m gpu -k "linear or train" 2>&1 | tail -3
+for r in 1 2 3; do python tools/bench_train.py --steps 100 2>&1 | grep -v amdgpu; done
+python tools/bench_train.py --steps 40 --batch 128 2>&1 | grep -v amdgpu
