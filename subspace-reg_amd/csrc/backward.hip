@@ -557,13 +557,15 @@ __global__ __launch_bounds__(64, 2) void conv_wgrad3x3_stream_kernel(const __bf1
         }
 }
 
-// K splits of the streaming kernel: one wave per workgroup, ~1536 waves on the chip (6 per CU).  Every split writes its own
+// K splits of the streaming kernel: one wave per workgroup, ~1024 waves on the chip (4 per CU).  Every split writes its own
 // partial dW, which unpack_wgrad re-reads: at the 2048 waves that fill all 8 wave slots per CU the extra partials cost more
-// than the occupancy buys (B = 64 train step, same box: 6.08 ms at 2048, 5.85 at 1536, 5.87 at 1024, 6.11 at 3072;
-// profiles/r03_train_step.txt).  SUBREG_WGRAD_WAVES overrides (measurements).
+// than the occupancy buys (B = 64 train step on ONE stream, same box: 6.08 ms at 2048, 5.85 at 1536, 5.87 at 1024, 6.11 at
+// 3072; profiles/r03_train_step.txt).  With the dW chains on the side stream they share the CUs with the dX convolutions and
+// fewer, longer waves win: 4.97 / 4.80 / 4.80 / 4.87 / 5.00 ms at 512 / 768 / 1024 / 1536 / 2048, and 376 / 391 / 402 / 397 / 393
+// TFLOP/s at B = 128 (profiles/r03_ab_train_two_streams.txt).  SUBREG_WGRAD_WAVES overrides (measurements).
 static void wgrad_stream_plan(long long Q, int Cin, int Cout, int* splits, int* rows_per_block) {
     const int tiles = (Cout / 32) * (Cin / 32);
-    static const int target = [] { const char* e = getenv("SUBREG_WGRAD_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1536; }();
+    static const int target = [] { const char* e = getenv("SUBREG_WGRAD_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
     long long sp = (target + tiles - 1) / tiles;
     long long rpb = ((Q + sp - 1) / sp + 63) / 64 * 64;
     if (rpb < 64) rpb = 64;

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_hip_kernels.py tests/test_hip_train.py -x -q -m gpu -k "linear or train" 2>&1 | tail -3
-for r in 1 2 3; do python tools/bench_train.py --steps 100 2>&1 | grep -v amdgpu; done
-python tools/bench_train.py --steps 40 --batch 128 2>&1 | grep -v amdgpu
+for r in 1 2; do for wv in 512 768 1024 1280; do echo "== WGRAD_WAVES=$wv"; SUBREG_WGRAD_WAVES=$wv python tools/bench_train.py --steps 80 2>&1 | grep -v amdgpu; done; done
+for wv in 512 768 1024; do echo "== B=128 WGRAD_WAVES=$wv"; SUBREG_WGRAD_WAVES=$wv python tools/bench_train.py --steps 40 --batch 128 2>&1 | grep -v amdgpu; done
