@@ -429,7 +429,12 @@ def test_fused_sgd_keeps_momentum_of_earlier_unfused_steps():
     y = torch.from_numpy(np.random.RandomState(6).randint(0, 60, 6)).cuda()
     after = []
     for second_fused in (True, False):
-        net = _train_net("bf16")
+        # The float atomics of the 1x1 / first-layer dW kernels make two runs differ in the last bit of some step-0 gradients, and
+        # that can flip ONE MaxPool argmax / LeakyReLU side in the second forward: in f32 mode a handful of weight-gradient elements
+        # then take one of two values (measured over 24 runs: 7-111 elements of one tensor off by 3e-5...7e-5, either way round); in
+        # bf16 mode a weight can also move by a bf16 ulp and whole tensors shift by per cents.  So: f32, and the gate is each
+        # tensor's L2 difference against what LOSING the momentum would change, lr * 0.9 * |momentum buffer after step 0|.
+        net = _train_net("f32")
         opt = SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
         for step in range(2):
             _grads_of(net, x, y)
@@ -437,14 +442,20 @@ def test_fused_sgd_keeps_momentum_of_earlier_unfused_steps():
                 for p in net.parameters():
                     p.grad = p.grad.clone()
             opt.step()
+            if step == 0:
+                torch.cuda.synchronize()
+                lost = {n: 0.05 * 0.9 * float(torch.linalg.vector_norm(opt.bufs[i].double()))
+                        for i, (n, _p) in enumerate(net.named_parameters())}
         assert bool(opt._stash_mom) == second_fused
         torch.cuda.synchronize()
         after.append({n: p.detach().cpu().numpy() for n, p in net.named_parameters()})
+    worst = 0.0
     for n in after[0]:
-        # not 1e-5: the 1x1 / first-layer dW kernels add with float atomics, so the two runs' first steps differ in the last bit
-        # and that can flip a bf16 rounding in the second forward (seen once in ~6 suite runs).  Lost momentum would be
-        # lr * 0.9 * |g| = 4.5e-2 |g| on every parameter - two orders of magnitude above this gate.
-        _cmp("momentum carried " + n, after[0][n], after[1][n], 1e-3 * max(float(np.abs(after[1][n]).max()), 1e-3), 1e-3)
+        diff = float(np.linalg.norm(after[0][n].astype(np.float64) - after[1][n].astype(np.float64)))
+        ratio = diff / max(lost[n], 1e-30)
+        worst = max(worst, ratio)
+        assert ratio < 0.05, ("momentum carried", n, diff, lost[n])       # measured over 14 runs: <= 8e-4 (kink flips); lost momentum: 1.0
+    print("momentum carry-over: worst (difference / effect of losing the momentum) %.2e" % worst)
 
 
 def _hip_stash_as_oracle_input(net, B, hw):

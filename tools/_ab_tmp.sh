@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for r in 1 2; do for wv in 512 768 1024 1280; do echo "== WGRAD_WAVES=$wv"; SUBREG_WGRAD_WAVES=$wv python tools/bench_train.py --steps 80 2>&1 | grep -v amdgpu; done; done
-for wv in 512 768 1024; do echo "== B=128 WGRAD_WAVES=$wv"; SUBREG_WGRAD_WAVES=$wv python tools/bench_train.py --steps 40 --batch 128 2>&1 | grep -v amdgpu; done
+for i in $(seq 1 14); do timeout 300 python -m pytest tests/test_hip_train.py -x -q -s -m gpu -k "fused_sgd_keeps" 2>&1 | grep -E "^E  |passed|failed|worst" | head -3; done
