@@ -35,12 +35,22 @@ ff=$(find /tmp/ev_fetch -name "*counter_collection.csv" | head -1); fw=$(find /t
 $R/tools/probes/stream_bw 1024 > $O/stream_bw.txt 2>&1
 python3 $R/tools/bench_elementwise.py 2>&1 | $G > $O/hbm_kernels.txt
 # --- pretraining step
-python3 $R/tools/bench_train.py --steps 20 2>&1 | $G > $O/train_step.txt
-python3 $R/tools/bench_train.py --steps 20 --batch 128 2>&1 | $G >> $O/train_step.txt
-python3 $R/tools/bench_train.py --steps 20 --batch 8 2>&1 | $G >> $O/train_step.txt
-python3 $R/tools/bench_train.py --steps 10 --batch 512 2>&1 | $G >> $O/train_step.txt
-rocprofv3 --kernel-trace --output-format csv -d /tmp/ev_train -o t -- python3 $R/tools/bench_train.py --steps 10 > /dev/null 2>&1
-f=$(find /tmp/ev_train -name "*kernel_trace.csv" | head -1); python3 $R/tools/prof_summary.py "$f" --top 30 > $O/train_kernel_summary.txt 2>&1
+python3 $R/tools/bench_train.py --steps 60 --host-time 2>&1 | $G > $O/train_step.txt
+python3 $R/tools/bench_train.py --steps 40 --batch 128 2>&1 | $G >> $O/train_step.txt
+python3 $R/tools/bench_train.py --steps 40 --batch 8 2>&1 | $G >> $O/train_step.txt
+python3 $R/tools/bench_train.py --steps 20 --batch 512 2>&1 | $G >> $O/train_step.txt
+for v in SUBREG_TRAIN_ONE_STREAM=1 SUBREG_NO_SPLITK=1 "SUBREG_TRAIN_ONE_STREAM=1 SUBREG_NO_SPLITK=1"; do
+  echo "== $v" >> $O/train_step.txt
+  env $v python3 $R/tools/bench_train.py --steps 60 2>&1 | $G >> $O/train_step.txt
+done
+echo "== all on (again)" >> $O/train_step.txt
+python3 $R/tools/bench_train.py --steps 60 2>&1 | $G >> $O/train_step.txt
+# kernel summary of the step: ONE stream (with two streams kernels overlap and per-kernel durations stretch), then the two-stream
+# step's span / busy time / idle gaps from the trace
+SUBREG_TRAIN_ONE_STREAM=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/ev_train -o t -- python3 $R/tools/bench_train.py --steps 10 > /dev/null 2>&1
+f=$(find /tmp/ev_train -name "*kernel_trace.csv" | head -1); python3 $R/tools/prof_summary.py "$f" --top 34 > $O/train_kernel_summary.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/ev_train2 -o t -- python3 $R/tools/bench_train.py --steps 6 > /dev/null 2>&1
+f=$(find /tmp/ev_train2 -name "*kernel_trace.csv" | head -1); python3 $R/tools/prof_summary.py "$f" --timeline 300 --step sgd_pack_train > $O/train_timeline_two_streams.txt 2>&1
 # --- SQ / GRBM counters of four layers
 bash $R/tools/pmc_layers.sh > $O/pmc_raw.txt 2>&1
 # --- multi-rank paths on the one GPU
