@@ -508,9 +508,45 @@ __global__ __launch_bounds__(64, 2) void conv_wgrad3x3_stream_kernel(const __bf1
     const unsigned lane_part = (unsigned)((8 * (grp >> 1) + qr) * 64 + (16 * (grp & 1) + 4 * pc) * 2);
     int base_slot = (int)(qb - halo - qbase);                           // ring slot of row q0 - halo (0..15 at the start)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- software-pipelined fragment reads.  A chunk is 36 "elements" e = 9*ks + t (k-step ks of 16 pixels, tap t): one MFMA each,
+    //      fed by two transposing reads of X (+ two of dY when t == 0).  Element e + 4 is read while element e multiplies: its
+    //      registers are ring slot (e + 4) % 6 - those of element e - 2, whose MFMA issued two MFMAs ago - and the dY fragments
+    //      alternate between two sets.  LDS returns in order, so "at most 8 reads outstanding" = element e has landed.  (Reading
+    //      all 20 fragments of a k-step, waiting, then issuing its 9 MFMAs left the matrix pipe idle for every LDS round trip:
+    //      at the 4 waves per CU the two-stream schedule runs this kernel with nothing else hides them.)
+    constexpr int NE = (KCH / 16) * 9, AHEAD = 4, RING = 6;
+    static_assert(NE % RING == 0, "ring slots must repeat per chunk");
+    uint2 fa[2][2], fb0[RING], fb1[RING];
+    auto issue = [&](int e, unsigned dbuf_l, int bslot) {             // e: compile-time after unrolling
+        const int ks = e / 9, t = e % 9;
+        if (t == 0) {
+            fa[ks & 1][0] = tr_read(dbuf_l + (16 * ks) * 64);
+            fa[ks & 1][1] = tr_read(dbuf_l + (16 * ks + 4) * 64);
+        }
+        int slot = bslot + 16 * ks + halo + (t / 3 - 1) * Wrow + (t % 3 - 1);       // wave-uniform: scalar ALU
+        if (slot >= R) slot -= R;
+        const unsigned ad = sX + (unsigned)slot * 64 + lane_part;
+        fb0[e % RING] = tr_read(ad);
+        fb1[e % RING] = tr_read(ad + 4 * 64);
+    };
+    auto wait_lgkm = [&](int n) {
+        switch (n) {
+        case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
+        }
+    };
+    {
+        const unsigned dbuf0 = sD + lane_part;
+#pragma unroll
+        for (int e = 0; e < AHEAD; ++e) issue(e, dbuf0, base_slot);
+    }
     int it = 0;
     for (long long q0 = qb; q0 < qe; q0 += KCH, ++it) {
-        if (q0 + KCH < qe) {                                            // stage the next chunk while this one computes
+        const bool more = q0 + KCH < qe;
+        if (more) {                                                     // stage the next chunk while this one computes
 #pragma unroll
             for (int k = 0; k < KCH / 16; ++k) {
                 stage_x(fq, fslot);
@@ -521,30 +557,29 @@ __global__ __launch_bounds__(64, 2) void conv_wgrad3x3_stream_kernel(const __bf1
             stage_d(q0 + KCH, (it + 1) & 1);
         }
         const unsigned dbuf = sD + (unsigned)(it & 1) * (KCH * 64) + lane_part;
+        const unsigned dbuf_n = sD + (unsigned)((it + 1) & 1) * (KCH * 64) + lane_part;
+        int bslot_n = base_slot + KCH;
+        if (bslot_n >= R) bslot_n -= R;
 #pragma unroll
-        for (int ks = 0; ks < KCH / 16; ++ks) {
-            const uint2 a0 = tr_read(dbuf + (16 * ks) * 64), a1 = tr_read(dbuf + (16 * ks + 4) * 64);
-            uint2 b0[9], b1[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                int slot = base_slot + 16 * ks + halo + (t / 3 - 1) * Wrow + (t % 3 - 1);   // wave-uniform: scalar ALU
-                if (slot >= R) slot -= R;
-                const unsigned ad = sX + (unsigned)slot * 64 + lane_part;
-                b0[t] = tr_read(ad);
-                b1[t] = tr_read(ad + 4 * 64);
+        for (int i = 0; i < NE; ++i) {
+            if (i + AHEAD < NE) {
+                issue(i + AHEAD, dbuf, base_slot);
+                wait_lgkm(2 * AHEAD);
+            } else if (more) {
+                if (i + AHEAD == NE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk landed (staged NE - AHEAD MFMAs ago)
+                issue(i + AHEAD - NE, dbuf_n, bslot_n);
+                wait_lgkm(2 * AHEAD);
+            } else {
+                wait_lgkm(2 * (NE - 1 - i));                            // last chunk: nothing left to read ahead
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            const uint4 av = make_uint4(a0.x, a0.y, a1.x, a1.y);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const uint4 bv = make_uint4(b0[t].x, b0[t].y, b1[t].x, b1[t].y);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
-            }
+            const int ks = i / 9;
+            const uint4 av = make_uint4(fa[ks & 1][0].x, fa[ks & 1][0].y, fa[ks & 1][1].x, fa[ks & 1][1].y);
+            const uint4 bv = make_uint4(fb0[i % RING].x, fb0[i % RING].y, fb1[i % RING].x, fb1[i % RING].y);
+            acc[i % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[i % 9], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        base_slot += KCH;
-        if (base_slot >= R) base_slot -= R;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the next chunk landed
+        base_slot = bslot_n;
     }
     float* const out = gw_part + (size_t)blockIdx.y * ((size_t)Cout * 9 * Cin);
     const int lr = lane & 31, lh = lane >> 5;
