@@ -592,15 +592,187 @@ __global__ __launch_bounds__(64, 2) void conv_wgrad3x3_stream_kernel(const __bf1
         }
 }
 
+// ---------------------------------------------------------------- the same, FOUR waves per workgroup sharing the staged rows
+// The one-wave kernel above streams 128 bytes per pixel (32 channels of X, 32 of dY) for its 32 x 32 x 9 tile, and every 32-channel
+// slice of X / dY is re-read by Cout/32 / Cin/32 workgroups: 472 MB for one 640 x 640 layer at B = 64, arriving at 3-4.7 TB/s on
+// every layer shape - the kernel is bound by that operand stream (tools/bench_wgrad.py: 30 % fewer LDS reads or software-pipelined
+// reads change nothing; profiles/r03_ab_wgrad_tile.txt).  Here a workgroup of 2 x 2 waves owns 64 output x 64 input channels: X rows
+// are 128 bytes (both input-channel halves) in ONE ring, dY rows 128 bytes in one double buffer, each staged once per workgroup by
+// LDS-DMA (8-row pieces, two X + two dY pieces per wave and chunk) - half the bytes per MFMA.  One barrier per 64-pixel chunk,
+// placed where the register pipeline crosses into the next chunk.  Ragged channel counts (160 = 64 + 64 + 32): the waves beyond
+// Cout / Cin stage and synchronise but neither read fragments nor multiply; their half of a row is a duplicate of a valid half.
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_tile_kernel(const __bf16* __restrict__ xq, const __bf16* __restrict__ dyq,
+                                                                    float* __restrict__ gw_part, long long Q, int Wrow, int Cin,
+                                                                    int Cout, int rows_per_block, int ring_rows) {
+    constexpr int KCH = 64, MIRROR = 32, XS = 128, DS = 128, NWAVE = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_o = wid >> 1, wave_c = wid & 1;
+    const int halo = Wrow + 1;
+    const int ncg = (Cin + 63) / 64;
+    const int ob = (blockIdx.x / ncg) * 64, cb = (blockIdx.x % ncg) * 64;       // the workgroup's channel origin
+    const int o0 = ob + 32 * wave_o, c0 = cb + 32 * wave_c;
+    const bool active = o0 < Cout && c0 < Cin;
+    const long long qb = (long long)blockIdx.y * rows_per_block;
+    long long qe = qb + rows_per_block;
+    if (qe > Q) qe = Q;
+    const unsigned sX = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned sD = sX + (unsigned)(ring_rows + MIRROR) * XS;
+    const int R = ring_rows;
+    // ---- staging: a piece = 8 rows x 128 bytes; lane l supplies row l / 8, bytes 16 * (l % 8) ...: the second 64-byte half of a
+    //      row falls back to the first where the tensor has no such channels
+    const int prow = lane >> 3, pbyte = (lane & 7) * 16;
+    const int xhalf = (cb + 32 + (pbyte >= 64 ? 32 : 0) <= Cin || pbyte < 64) ? pbyte : pbyte - 64;
+    const int dhalf = (ob + 32 + (pbyte >= 64 ? 32 : 0) <= Cout || pbyte < 64) ? pbyte : pbyte - 64;
+    const char* const xbase = reinterpret_cast<const char*>(xq + cb);
+    const char* const dbase = reinterpret_cast<const char*>(dyq + ob);
+    const long long qbase = ((qb - halo) >> 4) << 4;                   // floor to a 16-row boundary (may be negative)
+    auto stage_x8 = [&](long long q8, int slot8) {                     // rows q8 .. q8+7 into ring slots slot8 .. slot8+7
+        long long row = q8 + prow;
+        row = row < 0 ? 0 : (row >= Q ? Q - 1 : row);                   // outside the tensor: any finite row (its dY factor is a border zero)
+        const unsigned voff = (unsigned)row * (unsigned)(Cin * 2) + xhalf;
+        dma16(xbase, voff, sX + (unsigned)slot8 * XS);
+        if (slot8 < MIRROR) dma16(xbase, voff, sX + (unsigned)(R + slot8) * XS);
+    };
+    auto stage_d8 = [&](long long q8, int buf, int piece) {
+        const long long row = q8 + prow;
+        const unsigned srow = row < qe ? (unsigned)row : 0u;           // beyond the split: row 0 of padded dY, a zero border row
+        dma16(dbase, srow * (unsigned)(Cout * 2) + dhalf, sD + (unsigned)buf * (KCH * DS) + piece * 1024);
+    };
+    // this wave's share of 64 new X rows starting at absolute row fq (ring slot fslot) and of the dY chunk at q0
+    auto stage_chunk = [&](long long fq, int fslot, long long q0, int buf) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int piece = wid + NWAVE * k;                            // 0..7
+            int slot = fslot + 8 * piece;
+            if (slot >= R) slot -= R;
+            stage_x8(fq + 8 * piece, slot);
+            stage_d8(q0 + 8 * piece, buf, piece);
+        }
+    };
+    long long fq = qbase;                                               // staging frontier (absolute row) ...
+    int fslot = 0;                                                      // ... and its ring slot
+    const long long f0 = ((qb + KCH + halo + 15) >> 4) << 4;
+    for (; fq < f0; fq += 16) {                                         // prologue: 16 rows per step, two pieces, waves take turns
+        const int turn = (int)((fq - qbase) >> 4) & 1;
+        if ((wid >> 1) == turn) {
+            int slot = fslot + 8 * (wid & 1);
+            if (slot >= R) slot -= R;
+            stage_x8(fq + 8 * (wid & 1), slot);
+        }
+        fslot += 16;
+        if (fslot >= R) fslot -= R;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) stage_d8(qb + 8 * (wid + NWAVE * k), 0, wid + NWAVE * k);
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // per-lane part of the transposing-read addresses (see tr_read), for 128-byte rows; + this wave's 64-byte half
+    const int li = lane & 15, grp = lane >> 4, qr = li >> 2, pc = li & 3;
+    const unsigned lane_x = (unsigned)((8 * (grp >> 1) + qr) * XS + (16 * (grp & 1) + 4 * pc) * 2 + 64 * wave_c);
+    const unsigned lane_d = (unsigned)((8 * (grp >> 1) + qr) * DS + (16 * (grp & 1) + 4 * pc) * 2 + 64 * wave_o);
+    int base_slot = (int)(qb - halo - qbase);                           // ring slot of row q0 - halo (0..15 at the start)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    constexpr int NE = (KCH / 16) * 9, AHEAD = 4, RING = 6;             // the register pipeline of the one-wave kernel
+    static_assert(NE % RING == 0, "ring slots must repeat per chunk");
+    uint2 fa[2][2], fb0[RING], fb1[RING];
+    auto issue = [&](int e, unsigned dbuf_l, int bslot) {
+        const int ks = e / 9, t = e % 9;
+        if (t == 0) {
+            fa[ks & 1][0] = tr_read(dbuf_l + (16 * ks) * DS);
+            fa[ks & 1][1] = tr_read(dbuf_l + (16 * ks + 4) * DS);
+        }
+        int slot = bslot + 16 * ks + halo + (t / 3 - 1) * Wrow + (t % 3 - 1);
+        if (slot >= R) slot -= R;
+        const unsigned ad = sX + (unsigned)slot * XS + lane_x;
+        fb0[e % RING] = tr_read(ad);
+        fb1[e % RING] = tr_read(ad + 4 * XS);
+    };
+    auto wait_lgkm = [&](int n) {
+        switch (n) {
+        case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
+        }
+    };
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < AHEAD; ++e) issue(e, sD + lane_d, base_slot);
+    }
+    int it = 0;
+    for (long long q0 = qb; q0 < qe; q0 += KCH, ++it) {
+        const bool more = q0 + KCH < qe;
+        if (more) {                                                     // stage the next chunk while this one computes
+            stage_chunk(fq, fslot, q0 + KCH, (it + 1) & 1);
+            fq += KCH;
+            fslot += KCH;
+            if (fslot >= R) fslot -= R;
+        }
+        const unsigned dbuf = sD + (unsigned)(it & 1) * (KCH * DS) + lane_d;
+        const unsigned dbuf_n = sD + (unsigned)((it + 1) & 1) * (KCH * DS) + lane_d;
+        int bslot_n = base_slot + KCH;
+        if (bslot_n >= R) bslot_n -= R;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            if (i + AHEAD == NE && more) {                              // everybody's share of the next chunk has landed
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            if (active) {
+                if (i + AHEAD < NE) {
+                    issue(i + AHEAD, dbuf, base_slot);
+                    wait_lgkm(2 * AHEAD);
+                } else if (more) {
+                    issue(i + AHEAD - NE, dbuf_n, bslot_n);
+                    wait_lgkm(2 * AHEAD);
+                } else {
+                    wait_lgkm(2 * (NE - 1 - i));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int ks = i / 9;
+                const uint4 av = make_uint4(fa[ks & 1][0].x, fa[ks & 1][0].y, fa[ks & 1][1].x, fa[ks & 1][1].y);
+                const uint4 bv = make_uint4(fb0[i % RING].x, fb0[i % RING].y, fb1[i % RING].x, fb1[i % RING].y);
+                acc[i % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[i % 9], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        base_slot = bslot_n;
+    }
+    if (!active) return;
+    float* const out = gw_part + (size_t)blockIdx.y * ((size_t)Cout * 9 * Cin);
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            out[((size_t)o * 9 + t) * Cin + c0 + lr] = acc[t][r];
+        }
+}
+
 // K splits of the streaming kernel: one wave per workgroup, ~1024 waves on the chip (4 per CU).  Every split writes its own
 // partial dW, which unpack_wgrad re-reads: at the 2048 waves that fill all 8 wave slots per CU the extra partials cost more
 // than the occupancy buys (B = 64 train step on ONE stream, same box: 6.08 ms at 2048, 5.85 at 1536, 5.87 at 1024, 6.11 at
 // 3072; profiles/r03_train_step.txt).  With the dW chains on the side stream they share the CUs with the dX convolutions and
 // fewer, longer waves win: 4.97 / 4.80 / 4.80 / 4.87 / 5.00 ms at 512 / 768 / 1024 / 1536 / 2048, and 376 / 391 / 402 / 397 / 393
 // TFLOP/s at B = 128 (profiles/r03_ab_train_two_streams.txt).  SUBREG_WGRAD_WAVES overrides (measurements).
+// SUBREG_WGRAD_1WAVE=1: the one-wave kernel (A/B runs)
+static bool wgrad_tile4() {
+    static const bool on = [] { const char* e = getenv("SUBREG_WGRAD_1WAVE"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
 static void wgrad_stream_plan(long long Q, int Cin, int Cout, int* splits, int* rows_per_block) {
-    const int tiles = (Cout / 32) * (Cin / 32);
     static const int target = [] { const char* e = getenv("SUBREG_WGRAD_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    // four-wave kernel: 64 x 64-channel tiles, a quarter of the workgroups for the same number of waves
+    const int tiles = wgrad_tile4() ? ((Cout + 63) / 64) * ((Cin + 63) / 64) * 4 : (Cout / 32) * (Cin / 32);
     long long sp = (target + tiles - 1) / tiles;
     long long rpb = ((Q + sp - 1) / sp + 63) / 64 * 64;
     if (rpb < 64) rpb = 64;
@@ -610,7 +782,8 @@ static void wgrad_stream_plan(long long Q, int Cin, int Cout, int* splits, int* 
 
 static bool wgrad_stream_ok(long long Q, int W, int Cin, int Cout) {
     const int ring = (128 + 2 * (W + 3) + 32 + 15) / 16 * 16;
-    return (size_t)(ring + 32) * 64 + 2 * 64 * 64 <= 64 * 1024 && Q * Cin * 2 < (1LL << 32) && Q * Cout * 2 < (1LL << 32);
+    const size_t row = wgrad_tile4() ? 128 : 64, cap = wgrad_tile4() ? 80 * 1024 : 64 * 1024;    // two workgroups per CU either way
+    return (size_t)(ring + 32) * row + 2 * 64 * row <= cap && Q * Cin * 2 < (1LL << 32) && Q * Cout * 2 < (1LL << 32);
 }
 
 // packed fp32 [splits][Cout][taps][Cin_k] -> Conv2d.weight.grad OIHW, summing the K splits (mode 1: first-layer K=32
@@ -920,6 +1093,15 @@ extern "C" int subreg_conv_wgrad(const void* x, const void* dy, float* gw_packed
         int splits, rpb;
         wgrad_stream_plan(Q, Cin, Cout, &splits, &rpb);
         const int ring = (128 + 2 * (W + 3) + 32 + 15) / 16 * 16;
+        if (wgrad_tile4()) {
+            const size_t lds = (size_t)(ring + 32) * 128 + 2 * 64 * 128;
+            static std::atomic<unsigned long long> lds_set{0};
+            if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad3x3_tile_kernel), 80 * 1024, lds_set)) return rc;
+            dim3 grid(((Cout + 63) / 64) * ((Cin + 63) / 64), splits);
+            hipLaunchKernelGGL(conv_wgrad3x3_tile_kernel, grid, dim3(256), lds, s, (const __bf16*)pad_x, (const __bf16*)pad_dy, gw_packed,
+                               Q, W + 2, Cin, Cout, rpb, ring);
+            return launch_status();
+        }
         const size_t lds = (size_t)(ring + 32) * 64 + 2 * 64 * 64;
         dim3 grid((Cout / 32) * (Cin / 32), splits);
         hipLaunchKernelGGL(conv_wgrad3x3_stream_kernel, grid, dim3(64), lds, s, (const __bf16*)pad_x, (const __bf16*)pad_dy, gw_packed,
