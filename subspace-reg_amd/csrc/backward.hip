@@ -346,6 +346,14 @@ __device__ __forceinline__ uint2 tr_read(unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
     return r;
 }
+// the same with a compile-time byte offset in the instruction (saves the v_add of "four rows further")
+template <int OFF>
+__device__ __forceinline__ uint2 tr_read_off(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "16-bit DS offset");
+    uint2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
 
 // One workgroup = NCW waves: output channels [o0, o0+32) x input channels [c0, c0+32*NCW), all TAPS, over a range of padded
 // pixel rows.  Both operands are pixel-major in memory and in LDS; the MFMA wants 8 consecutive K (= pixels) per lane and
@@ -601,10 +609,20 @@ __global__ __launch_bounds__(64, 2) void conv_wgrad3x3_stream_kernel(const __bf1
 // LDS-DMA (8-row pieces, two X + two dY pieces per wave and chunk) - half the bytes per MFMA.  One barrier per 64-pixel chunk,
 // placed where the register pipeline crosses into the next chunk.  Ragged channel counts (160 = 64 + 64 + 32): the waves beyond
 // Cout / Cin stage and synchronise but neither read fragments nor multiply; their half of a row is a duplicate of a valid half.
+#ifndef WGRAD_DIAG
+#define WGRAD_DIAG 0                    // timing experiments only (wrong results): 1 no MFMAs, 2 no fragment reads, 3 no LDS-DMA staging
+#endif
+#ifndef WGRAD_TILE_DEPTH
+#define WGRAD_TILE_DEPTH 1
+#endif
+#ifndef WGRAD_TILE_AHEAD
+#define WGRAD_TILE_AHEAD 4              // fragment elements read ahead of the MFMA that uses them (ring = AHEAD + 2; 36 % ring == 0)
+#endif
 __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_tile_kernel(const __bf16* __restrict__ xq, const __bf16* __restrict__ dyq,
                                                                     float* __restrict__ gw_part, long long Q, int Wrow, int Cin,
                                                                     int Cout, int rows_per_block, int ring_rows) {
     constexpr int KCH = 64, MIRROR = 32, XS = 128, DS = 128, NWAVE = 4;
+    constexpr int DEPTH = WGRAD_TILE_DEPTH, NDBUF = DEPTH + 1;           // chunks staged ahead of the one being multiplied; dY buffers
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -632,12 +650,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_tile_kernel(const __bf16
         long long row = q8 + prow;
         row = row < 0 ? 0 : (row >= Q ? Q - 1 : row);                   // outside the tensor: any finite row (its dY factor is a border zero)
         const unsigned voff = (unsigned)row * (unsigned)(Cin * 2) + xhalf;
+        if (WGRAD_DIAG == 3) return;
         dma16(xbase, voff, sX + (unsigned)slot8 * XS);
         if (slot8 < MIRROR) dma16(xbase, voff, sX + (unsigned)(R + slot8) * XS);
     };
     auto stage_d8 = [&](long long q8, int buf, int piece) {
         const long long row = q8 + prow;
         const unsigned srow = row < qe ? (unsigned)row : 0u;           // beyond the split: row 0 of padded dY, a zero border row
+        if (WGRAD_DIAG == 3) return;
         dma16(dbase, srow * (unsigned)(Cout * 2) + dhalf, sD + (unsigned)buf * (KCH * DS) + piece * 1024);
     };
     // this wave's share of 64 new X rows starting at absolute row fq (ring slot fslot) and of the dY chunk at q0
@@ -653,7 +673,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_tile_kernel(const __bf16
     };
     long long fq = qbase;                                               // staging frontier (absolute row) ...
     int fslot = 0;                                                      // ... and its ring slot
-    const long long f0 = ((qb + KCH + halo + 15) >> 4) << 4;
+    const long long f0 = ((qb + DEPTH * KCH + halo + 15) >> 4) << 4;
     for (; fq < f0; fq += 16) {                                         // prologue: 16 rows per step, two pieces, waves take turns
         const int turn = (int)((fq - qbase) >> 4) & 1;
         if ((wid >> 1) == turn) {
@@ -665,7 +685,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_tile_kernel(const __bf16
         if (fslot >= R) fslot -= R;
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) stage_d8(qb + 8 * (wid + NWAVE * k), 0, wid + NWAVE * k);
+    for (int dch = 0; dch < DEPTH; ++dch)                                // dY chunks 0 .. DEPTH-1 (rows beyond the split read a zero row)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) stage_d8(qb + dch * KCH + 8 * (wid + NWAVE * k), dch, wid + NWAVE * k);
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -678,20 +700,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_tile_kernel(const __bf16
     int base_slot = (int)(qb - halo - qbase);                           // ring slot of row q0 - halo (0..15 at the start)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    constexpr int NE = (KCH / 16) * 9, AHEAD = 4, RING = 6;             // the register pipeline of the one-wave kernel
+    constexpr int NE = (KCH / 16) * 9, AHEAD = WGRAD_TILE_AHEAD, RING = AHEAD + 2;   // the register pipeline of the one-wave kernel
     static_assert(NE % RING == 0, "ring slots must repeat per chunk");
     uint2 fa[2][2], fb0[RING], fb1[RING];
     auto issue = [&](int e, unsigned dbuf_l, int bslot) {
         const int ks = e / 9, t = e % 9;
+        if (WGRAD_DIAG == 2) return;
         if (t == 0) {
-            fa[ks & 1][0] = tr_read(dbuf_l + (16 * ks) * DS);
-            fa[ks & 1][1] = tr_read(dbuf_l + (16 * ks + 4) * DS);
+            const unsigned da = dbuf_l + (16 * ks) * DS;
+            fa[ks & 1][0] = tr_read(da);
+            fa[ks & 1][1] = tr_read_off<4 * DS>(da);
         }
         int slot = bslot + 16 * ks + halo + (t / 3 - 1) * Wrow + (t % 3 - 1);
         if (slot >= R) slot -= R;
         const unsigned ad = sX + (unsigned)slot * XS + lane_x;
         fb0[e % RING] = tr_read(ad);
-        fb1[e % RING] = tr_read(ad + 4 * XS);
+        fb1[e % RING] = tr_read_off<4 * XS>(ad);
     };
     auto wait_lgkm = [&](int n) {
         switch (n) {
@@ -699,7 +723,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_tile_kernel(const __bf16
         case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory"); break;
         }
     };
     if (active) {
@@ -709,39 +736,52 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_tile_kernel(const __bf16
     int it = 0;
     for (long long q0 = qb; q0 < qe; q0 += KCH, ++it) {
         const bool more = q0 + KCH < qe;
-        if (more) {                                                     // stage the next chunk while this one computes
-            stage_chunk(fq, fslot, q0 + KCH, (it + 1) & 1);
+        // stage the chunk DEPTH ahead while this one computes (its DMAs are the youngest: they may stay in flight at the barrier)
+        int n_dma = 0;
+        if (q0 + DEPTH * KCH < qe) {
+            n_dma = 4 + (fslot + 8 * wid < MIRROR || (fslot + 8 * wid >= R && fslot + 8 * wid - R < MIRROR) ? 1 : 0)
+                      + (fslot + 8 * (wid + NWAVE) < MIRROR || (fslot + 8 * (wid + NWAVE) >= R && fslot + 8 * (wid + NWAVE) - R < MIRROR) ? 1 : 0);
+            stage_chunk(fq, fslot, q0 + DEPTH * KCH, (it + DEPTH) % NDBUF);
             fq += KCH;
             fslot += KCH;
             if (fslot >= R) fslot -= R;
         }
-        const unsigned dbuf = sD + (unsigned)(it & 1) * (KCH * DS) + lane_d;
-        const unsigned dbuf_n = sD + (unsigned)((it + 1) & 1) * (KCH * DS) + lane_d;
+        const unsigned dbuf = sD + (unsigned)(it % NDBUF) * (KCH * DS) + lane_d;
+        const unsigned dbuf_n = sD + (unsigned)((it + 1) % NDBUF) * (KCH * DS) + lane_d;
         int bslot_n = base_slot + KCH;
         if (bslot_n >= R) bslot_n -= R;
+        auto next_chunk_landed = [&]() {                                // everybody's share of the NEXT chunk has landed (LDS-DMA completes
+            switch (DEPTH > 1 ? n_dma : 0) {                            // in issue order: the n_dma youngest belong to the chunk after it)
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+            __syncthreads();
+        };
+        if (!active) {                                                  // (one branch per chunk, not one per element)
+            if (more) next_chunk_landed();
+            base_slot = bslot_n;
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            if (i + AHEAD == NE && more) {                              // everybody's share of the next chunk has landed
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+            if (i + AHEAD == NE && more) next_chunk_landed();
+            if (i + AHEAD < NE) {
+                issue(i + AHEAD, dbuf, base_slot);
+                wait_lgkm(2 * AHEAD);
+            } else if (more) {
+                issue(i + AHEAD - NE, dbuf_n, bslot_n);
+                wait_lgkm(2 * AHEAD);
+            } else {
+                wait_lgkm(2 * (NE - 1 - i));
             }
-            if (active) {
-                if (i + AHEAD < NE) {
-                    issue(i + AHEAD, dbuf, base_slot);
-                    wait_lgkm(2 * AHEAD);
-                } else if (more) {
-                    issue(i + AHEAD - NE, dbuf_n, bslot_n);
-                    wait_lgkm(2 * AHEAD);
-                } else {
-                    wait_lgkm(2 * (NE - 1 - i));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const int ks = i / 9;
-                const uint4 av = make_uint4(fa[ks & 1][0].x, fa[ks & 1][0].y, fa[ks & 1][1].x, fa[ks & 1][1].y);
-                const uint4 bv = make_uint4(fb0[i % RING].x, fb0[i % RING].y, fb1[i % RING].x, fb1[i % RING].y);
-                acc[i % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[i % 9], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int ks = i / 9;
+            const uint4 av = make_uint4(fa[ks & 1][0].x, fa[ks & 1][0].y, fa[ks & 1][1].x, fa[ks & 1][1].y);
+            const uint4 bv = make_uint4(fb0[i % RING].x, fb0[i % RING].y, fb1[i % RING].x, fb1[i % RING].y);
+            if (WGRAD_DIAG != 1) acc[i % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[i % 9], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         base_slot = bslot_n;
     }
@@ -781,9 +821,10 @@ static void wgrad_stream_plan(long long Q, int Cin, int Cout, int* splits, int* 
 }
 
 static bool wgrad_stream_ok(long long Q, int W, int Cin, int Cout) {
-    const int ring = (128 + 2 * (W + 3) + 32 + 15) / 16 * 16;
+    const int ahead = wgrad_tile4() ? WGRAD_TILE_DEPTH : 1;
+    const int ring = (64 * (ahead + 1) + 2 * (W + 3) + 32 + 15) / 16 * 16;
     const size_t row = wgrad_tile4() ? 128 : 64, cap = wgrad_tile4() ? 80 * 1024 : 64 * 1024;    // two workgroups per CU either way
-    return (size_t)(ring + 32) * row + 2 * 64 * row <= cap && Q * Cin * 2 < (1LL << 32) && Q * Cout * 2 < (1LL << 32);
+    return (size_t)(ring + 32) * row + (size_t)(ahead + 1) * 64 * row <= cap && Q * Cin * 2 < (1LL << 32) && Q * Cout * 2 < (1LL << 32);
 }
 
 // packed fp32 [splits][Cout][taps][Cin_k] -> Conv2d.weight.grad OIHW, summing the K splits (mode 1: first-layer K=32
@@ -1092,9 +1133,9 @@ extern "C" int subreg_conv_wgrad(const void* x, const void* dy, float* gw_packed
         hipLaunchKernelGGL(pad_copy_kernel, bw_blocks((size_t)Q * Cout / 8), BW_THREADS, 0, s, (const __bf16*)dy, (__bf16*)pad_dy, B, H, W, Cout);
         int splits, rpb;
         wgrad_stream_plan(Q, Cin, Cout, &splits, &rpb);
-        const int ring = (128 + 2 * (W + 3) + 32 + 15) / 16 * 16;
         if (wgrad_tile4()) {
-            const size_t lds = (size_t)(ring + 32) * 128 + 2 * 64 * 128;
+            const int ring = (64 * (WGRAD_TILE_DEPTH + 1) + 2 * (W + 3) + 32 + 15) / 16 * 16;
+            const size_t lds = (size_t)(ring + 32) * 128 + (size_t)(WGRAD_TILE_DEPTH + 1) * 64 * 128;
             static std::atomic<unsigned long long> lds_set{0};
             if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad3x3_tile_kernel), 80 * 1024, lds_set)) return rc;
             dim3 grid(((Cout + 63) / 64) * ((Cin + 63) / 64), splits);
@@ -1102,6 +1143,7 @@ extern "C" int subreg_conv_wgrad(const void* x, const void* dy, float* gw_packed
                                Q, W + 2, Cin, Cout, rpb, ring);
             return launch_status();
         }
+        const int ring = (128 + 2 * (W + 3) + 32 + 15) / 16 * 16;
         const size_t lds = (size_t)(ring + 32) * 64 + 2 * 64 * 64;
         dim3 grid((Cout / 32) * (Cin / 32), splits);
         hipLaunchKernelGGL(conv_wgrad3x3_stream_kernel, grid, dim3(64), lds, s, (const __bf16*)pad_x, (const __bf16*)pad_dy, gw_packed,
