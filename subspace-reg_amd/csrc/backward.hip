@@ -339,6 +339,21 @@ __global__ void pad_copy_kernel(const __bf16* __restrict__ x, __bf16* __restrict
     *reinterpret_cast<uint4*>(y + q * C + c8 * 8) = v;
 }
 
+// one LDS-DMA piece whose 64 lanes read from arbitrary 64-bit addresses (the address lives in a VGPR pair, no scalar base)
+__device__ __forceinline__ void dma16_far(const char* p, unsigned lds_addr) {
+    const unsigned lds_u = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(p), "s"(lds_u)
+        : "memory");
+}
+
 // ds_read_b64_tr_b16: per 16-lane group a 4 (rows = pixels) x 16 (columns = channels) block is delivered transposed:
 // lane i of the group gets column i, element e = row e.  Lane 4*qr+pc supplies the address of row qr, columns 4pc..4pc+3.
 __device__ __forceinline__ uint2 tr_read(unsigned addr) {
@@ -618,9 +633,20 @@ __global__ __launch_bounds__(64, 2) void conv_wgrad3x3_stream_kernel(const __bf1
 #ifndef WGRAD_TILE_AHEAD
 #define WGRAD_TILE_AHEAD 4              // fragment elements read ahead of the MFMA that uses them (ring = AHEAD + 2; 36 % ring == 0)
 #endif
+// DIRECT: X and dY are the COMPACT [B][H][W][C] tensors; the staging lanes map their padded row (image, h + 1, w + 1) to the compact
+// row or, on the one-pixel border, to a line of zeros - the two pad_copy launches per convolution (5 % of the step's kernel time,
+// 2 x the tensor in traffic) are gone.  Two divisions per staged row by multiply-shift with host-made reciprocals (exact for
+// Q < 2^26): ~14 VALU instructions per LDS-DMA, four to six DMAs per wave and 36-MFMA chunk.
+struct WgradGeom {
+    int H, W, HpWp, Wp;                   // image size, padded plane and row lengths
+    unsigned long long m_plane, m_row;    // ceil(2^40 / HpWp), ceil(2^40 / Wp)
+};
+__device__ __attribute__((aligned(16))) const unsigned char wgrad_zero_line[128] = {0};
+
+template <bool DIRECT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_tile_kernel(const __bf16* __restrict__ xq, const __bf16* __restrict__ dyq,
                                                                     float* __restrict__ gw_part, long long Q, int Wrow, int Cin,
-                                                                    int Cout, int rows_per_block, int ring_rows) {
+                                                                    int Cout, int rows_per_block, int ring_rows, const WgradGeom gm) {
     constexpr int KCH = 64, MIRROR = 32, XS = 128, DS = 128, NWAVE = 4;
     constexpr int DEPTH = WGRAD_TILE_DEPTH, NDBUF = DEPTH + 1;           // chunks staged ahead of the one being multiplied; dY buffers
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -646,11 +672,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_tile_kernel(const __bf16
     const char* const xbase = reinterpret_cast<const char*>(xq + cb);
     const char* const dbase = reinterpret_cast<const char*>(dyq + ob);
     const long long qbase = ((qb - halo) >> 4) << 4;                   // floor to a 16-row boundary (may be negative)
+    // DIRECT: byte address of padded row q of a compact [B][H][W][C] tensor (+ this lane's 16 bytes), or the zero line on the border
+    auto compact_src = [&](unsigned q, const char* base, int C, int halfbyte) -> const char* {
+        const unsigned img = (unsigned)(((unsigned long long)q * gm.m_plane) >> 40);
+        const unsigned r = q - img * (unsigned)gm.HpWp;
+        const unsigned hp = (unsigned)(((unsigned long long)r * gm.m_row) >> 40);
+        const unsigned wp = r - hp * (unsigned)gm.Wp;
+        const bool inside = hp - 1u < (unsigned)gm.H && wp - 1u < (unsigned)gm.W;
+        const size_t crow = ((size_t)img * gm.H + (hp - 1u)) * gm.W + (wp - 1u);
+        return inside ? base + crow * (size_t)(C * 2) + halfbyte : reinterpret_cast<const char*>(wgrad_zero_line) + (halfbyte & 63);
+    };
     auto stage_x8 = [&](long long q8, int slot8) {                     // rows q8 .. q8+7 into ring slots slot8 .. slot8+7
         long long row = q8 + prow;
         row = row < 0 ? 0 : (row >= Q ? Q - 1 : row);                   // outside the tensor: any finite row (its dY factor is a border zero)
-        const unsigned voff = (unsigned)row * (unsigned)(Cin * 2) + xhalf;
         if (WGRAD_DIAG == 3) return;
+        if (DIRECT) {
+            const char* src = compact_src((unsigned)row, xbase, Cin, xhalf);
+            dma16_far(src, sX + (unsigned)slot8 * XS);
+            if (slot8 < MIRROR) dma16_far(src, sX + (unsigned)(R + slot8) * XS);
+            return;
+        }
+        const unsigned voff = (unsigned)row * (unsigned)(Cin * 2) + xhalf;
         dma16(xbase, voff, sX + (unsigned)slot8 * XS);
         if (slot8 < MIRROR) dma16(xbase, voff, sX + (unsigned)(R + slot8) * XS);
     };
@@ -658,6 +700,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_tile_kernel(const __bf16
         const long long row = q8 + prow;
         const unsigned srow = row < qe ? (unsigned)row : 0u;           // beyond the split: row 0 of padded dY, a zero border row
         if (WGRAD_DIAG == 3) return;
+        if (DIRECT) {
+            dma16_far(compact_src(srow, dbase, Cout, dhalf), sD + (unsigned)buf * (KCH * DS) + piece * 1024);
+            return;
+        }
         dma16(dbase, srow * (unsigned)(Cout * 2) + dhalf, sD + (unsigned)buf * (KCH * DS) + piece * 1024);
     };
     // this wave's share of 64 new X rows starting at absolute row fq (ring slot fslot) and of the dY chunk at q0
@@ -1126,23 +1172,40 @@ extern "C" int subreg_conv_wgrad(const void* x, const void* dy, float* gw_packed
     const int taps = ksize * ksize;
     const ConvGeom g = make_geom(B, H, W, taps, false);
     const int nsplit = subreg_conv_wgrad_splits(B, H, W, Cin, Cout, ksize, dtype);
-    if (nsplit > 1 && pad_x && pad_dy) {
+    // SUBREG_WGRAD_PADDED=1: the four-wave kernel on zero-bordered copies, as the one-wave kernel needs them (A/B runs)
+    static const bool direct_on = [] { const char* e = getenv("SUBREG_WGRAD_PADDED"); return !(e && e[0] == '1'); }();
+    const long long Qp = (long long)B * (H + 2) * (W + 2);
+    const bool direct = nsplit > 1 && wgrad_tile4() && direct_on && Qp < (1LL << 26);
+    if (nsplit > 1 && (direct || (pad_x && pad_dy))) {
         // streaming bf16 3x3 kernel: per-split partial dW, no zero-fill, no atomics
-        const long long Q = (long long)B * (H + 2) * (W + 2);
-        hipLaunchKernelGGL(pad_copy_kernel, bw_blocks((size_t)Q * Cin / 8), BW_THREADS, 0, s, (const __bf16*)x, (__bf16*)pad_x, B, H, W, Cin);
-        hipLaunchKernelGGL(pad_copy_kernel, bw_blocks((size_t)Q * Cout / 8), BW_THREADS, 0, s, (const __bf16*)dy, (__bf16*)pad_dy, B, H, W, Cout);
+        const long long Q = Qp;
         int splits, rpb;
         wgrad_stream_plan(Q, Cin, Cout, &splits, &rpb);
         if (wgrad_tile4()) {
             const int ring = (64 * (WGRAD_TILE_DEPTH + 1) + 2 * (W + 3) + 32 + 15) / 16 * 16;
             const size_t lds = (size_t)(ring + 32) * 128 + (size_t)(WGRAD_TILE_DEPTH + 1) * 64 * 128;
-            static std::atomic<unsigned long long> lds_set{0};
-            if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad3x3_tile_kernel), 80 * 1024, lds_set)) return rc;
             dim3 grid(((Cout + 63) / 64) * ((Cin + 63) / 64), splits);
-            hipLaunchKernelGGL(conv_wgrad3x3_tile_kernel, grid, dim3(256), lds, s, (const __bf16*)pad_x, (const __bf16*)pad_dy, gw_packed,
-                               Q, W + 2, Cin, Cout, rpb, ring);
+            WgradGeom gm;
+            gm.H = H; gm.W = W; gm.HpWp = (H + 2) * (W + 2); gm.Wp = W + 2;
+            gm.m_plane = ((1ULL << 40) + gm.HpWp - 1) / gm.HpWp;
+            gm.m_row = ((1ULL << 40) + gm.Wp - 1) / gm.Wp;
+            if (direct) {
+                static std::atomic<unsigned long long> lds_set{0};
+                if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad3x3_tile_kernel<true>), 80 * 1024, lds_set)) return rc;
+                hipLaunchKernelGGL(conv_wgrad3x3_tile_kernel<true>, grid, dim3(256), lds, s, (const __bf16*)x, (const __bf16*)dy, gw_packed,
+                                   Q, W + 2, Cin, Cout, rpb, ring, gm);
+                return launch_status();
+            }
+            hipLaunchKernelGGL(pad_copy_kernel, bw_blocks((size_t)Q * Cin / 8), BW_THREADS, 0, s, (const __bf16*)x, (__bf16*)pad_x, B, H, W, Cin);
+            hipLaunchKernelGGL(pad_copy_kernel, bw_blocks((size_t)Q * Cout / 8), BW_THREADS, 0, s, (const __bf16*)dy, (__bf16*)pad_dy, B, H, W, Cout);
+            static std::atomic<unsigned long long> lds_set{0};
+            if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad3x3_tile_kernel<false>), 80 * 1024, lds_set)) return rc;
+            hipLaunchKernelGGL(conv_wgrad3x3_tile_kernel<false>, grid, dim3(256), lds, s, (const __bf16*)pad_x, (const __bf16*)pad_dy, gw_packed,
+                               Q, W + 2, Cin, Cout, rpb, ring, gm);
             return launch_status();
         }
+        hipLaunchKernelGGL(pad_copy_kernel, bw_blocks((size_t)Q * Cin / 8), BW_THREADS, 0, s, (const __bf16*)x, (__bf16*)pad_x, B, H, W, Cin);
+        hipLaunchKernelGGL(pad_copy_kernel, bw_blocks((size_t)Q * Cout / 8), BW_THREADS, 0, s, (const __bf16*)dy, (__bf16*)pad_dy, B, H, W, Cout);
         const int ring = (128 + 2 * (W + 3) + 32 + 15) / 16 * 16;
         const size_t lds = (size_t)(ring + 32) * 64 + 2 * 64 * 64;
         dim3 grid((Cout / 32) * (Cin / 32), splits);

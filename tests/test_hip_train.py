@@ -98,6 +98,21 @@ def test_conv_wgrad_pretrain_batch(shape):
     _cmp("dW (B=64)", grad.cpu().numpy(), dw_ref, 1e-3 * np.abs(dw_ref).max(), 1e-4)
 
 
+@pytest.mark.parametrize("switch", ["SUBREG_WGRAD_PADDED", "SUBREG_WGRAD_1WAVE"])
+def test_conv_wgrad_fallback_kernels(switch):
+    """The dW routes behind the A/B switches - the four-wave tile kernel on zero-bordered copies (SUBREG_WGRAD_PADDED=1) and the
+    one-wave streaming kernel (SUBREG_WGRAD_1WAVE=1) - stay correct: the library reads the switches once per process, so the dW
+    tests above run again in a child process with the switch set."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env[switch] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "test_conv_wgrad_pretrain_batch or (test_conv_wgrad_and_dgrad and bf16)"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("with_act", [False, True])
 def test_bn_backward(dtype, with_act):
