@@ -70,6 +70,11 @@ int env_int(const char* name, int dflt) {
 }
 int fork_bwd_from() { static const int v = env_int("SUBREG_TRAIN_FORK_FROM", 0); return v; }
 int fork_fwd_from() { static const int v = env_int("SUBREG_TRAIN_FORK_FWD_FROM", 0); return v; }
+// Blocks below this index run their shortcut branch (BN backward + 1x1 dW) on the MAIN stream although their 3x3 dW chains fork:
+// in the first two blocks (84x84 / 42x42 maps) the dW chains are longer than the BN-backward -> dX chain and main would wait for them
+// (two gaps of ~100 us at the d(raw) buffer reuse in the trace); the shortcut branch is work main can take over.  The 1x1 convs
+// have a dW scratch of their own (subreg_hip/train.py), so the two streams never share one.
+int down_on_side_from() { static const int v = env_int("SUBREG_TRAIN_DOWN_SIDE_FROM", 2); return v; }
 
 }  // namespace
 
@@ -178,7 +183,8 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
                                   b.down.w ? tb.down.bscale : nullptr, b.down.w ? tb.down.bshift : nullptr, t->dv, B, bh, bw, C,
                                   b.stride == 2, dt, stream));
         // shortcut branch (BN backward -> dr2, dW): needs only dv; all of it on the side stream
-        if (b.down.w && fork) {
+        const bool down_side = fork && i >= down_on_side_from();
+        if (b.down.w && down_side) {
             TRY(f.main_to_side(EV_FORK));
             TRY(bn_backward(d, b.down, tb.down, t->dv, nullptr, t->dr2, t->bn_partial_side, B, bh, bw, f.side));
             TRY(weight_grad(d, t, b.down, tb.down, xin, t->dr2, B, bh, bw, f.side));
@@ -194,7 +200,7 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
         TRY(subreg_conv_fwd_ws(dr, tb.conv2.w_dgrad, t->dt, nullptr, t->zero_shift, nullptr, nullptr, nullptr, nullptr, 0, B, bh, bw,
                                b.conv2.cout, b.conv2.cin, b.conv2.ksize_raw, 0, dt, t->splitk_ws, t->splitk_ws_floats, stream));
         TRY(bn_then_wgrad(b.conv1, tb.conv1, t->dt, tb.conv1.act, xin, bh, bw, &dr));
-        if (b.down.w && !fork) {           // shortcut branch on the main stream (after conv1's chain: they share the dW scratch)
+        if (b.down.w && !down_side) {      // shortcut branch on the main stream
             TRY(bn_backward(d, b.down, tb.down, t->dv, nullptr, t->dr2, t->bn_partial, B, bh, bw, stream));
             TRY(weight_grad(d, t, b.down, tb.down, xin, t->dr2, B, bh, bw, stream));
         }

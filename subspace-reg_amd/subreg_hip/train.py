@@ -32,7 +32,7 @@ class TrainStash:
             return t
 
         h, w, cmax, amax, pmax = H, W, 0, B * H * W * 32, 0
-        gw_need, gw_users, grad_slots = 0, [], []
+        gw_need, gw_down_need, gw_users, grad_slots = 0, 0, [], []
         self.grads = {}                      # state_dict key -> fp32 gradient tensor
         self.dgrad = []                      # (conv name, cout, cin, k, packed tensor)
         for bi, (name, cin, cout, stride, ds, _db) in enumerate(hb.blocks):
@@ -57,8 +57,11 @@ class TrainStash:
                 kin = 32 if ci == 3 else ci
                 kk = 1 if ci == 3 else k
                 nsplit = lib.subreg_conv_wgrad_splits(B, h, w, kin, cout, kk, hb.dtype)
-                gw_need = max(gw_need, nsplit * cout * kk * kk * kin)
-                gw_users.append(tc)
+                if slot == "down":
+                    gw_down_need = max(gw_down_need, nsplit * cout * kk * kk * kin)
+                else:
+                    gw_need = max(gw_need, nsplit * cout * kk * kk * kin)
+                gw_users.append((tc, slot == "down"))
                 grad_slots.append((tc, cname + ".weight", (cout, ci, k, k), bname + ".weight", bname + ".bias", cout))
                 tc.w_dgrad = None
                 if bi > 0 or slot in ("conv2", "conv3"):      # no gradient w.r.t. the images: layer1.0 conv1/shortcut need none
@@ -97,9 +100,11 @@ class TrainStash:
         self.flat_grads._subreg_stash = self     # lets the optimiser recognise gradients that are views of this buffer
         self.conv_weight_offsets = {off: name for name, off, shp in self.grad_views if len(shp) == 4}
         self.opt_packed = None                   # conv-weight versions for which the optimiser already wrote the packed copies
-        gw_shared = buf(gw_need, f32)           # one scratch for every conv's per-split partial dW (used one conv at a time)
-        for tc in gw_users:
-            tc.gw_packed = gw_shared.data_ptr()
+        # scratch for the per-split partial dW: one buffer for the 3x3 convs (their dW chains run one at a time, on one stream) and
+        # one for the 1x1 shortcut convs, whose branch may run on the other stream at the same time (backbone_train.hip)
+        gw_shared, gw_down = buf(gw_need, f32), buf(max(gw_down_need, 1), f32)
+        for tc, is_down in gw_users:
+            tc.gw_packed = (gw_down if is_down else gw_shared).data_ptr()
         self.desc.pad_x = buf(pmax).data_ptr() if hb.dtype == _lib.BF16 else None
         self.desc.pad_dy = buf(pmax).data_ptr() if hb.dtype == _lib.BF16 else None
         self.desc.bn_partial = buf(lib.subreg_bn_bwd_slices(B * H * W) * cmax * 2, torch.float64).data_ptr()
