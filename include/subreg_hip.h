@@ -223,7 +223,6 @@ typedef struct subreg_conv_train { /* per conv; every buffer caller-owned */
     const void* w_dgrad;  /* subreg_pack_conv_weight_dgrad output; NULL when no input gradient is needed */
     float* gw_packed;     /* [splits][cout][taps][cin as the kernel sees it] fp32 scratch; the 3x3 convs may share one buffer, the 1x1
                              shortcut convs another (with side_stream their branch can run while a 3x3 dW chain uses the first) */
-                             shortcut convs another (with side_stream their branch can run while a 3x3 dW chain uses the first) */
     float* grad_w;        /* OIHW fp32: Conv2d.weight.grad */
     float* grad_gamma;    /* [cout] */
     float* grad_beta;     /* [cout] */
