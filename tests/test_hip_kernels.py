@@ -746,6 +746,35 @@ def test_validate_sets_top1_and_top5_with_ties():
         assert int(c1[3:].sum()) == 0 and int(c5[3:].sum()) == 0
 
 
+def test_dropblock_rescale_factor_stays_on_the_device():
+    """DropBlock's `countM / count_ones` (models/resnet_language.py:318-323) without a host read: subreg_random_keep_mask counts
+    the kept elements, subreg_mask_scale turns the counter into the factor, and subreg_bn_apply / subreg_block_tail_bwd read it from
+    the device (mask_scale_dev) - same results as with the host float."""
+    lib = _lib.load()
+    B, H, W, Cc = 3, 6, 5, 64
+    n = B * H * W * Cc
+    keep = torch.empty(n, dtype=torch.uint8, device=_dev())
+    cnt = torch.zeros(1, dtype=torch.int32, device=_dev())
+    _lib.check(lib.subreg_random_keep_mask(_lib.ptr(keep), n, 12345, 0.3, _lib.ptr(cnt), _lib.stream_ptr()))
+    scale_dev = torch.zeros(1, dtype=torch.float32, device=_dev())
+    _lib.check(lib.subreg_mask_scale(_lib.ptr(cnt), n, _lib.ptr(scale_dev), _lib.stream_ptr()))
+    kept = int(keep.sum().item())
+    assert int(cnt.item()) == kept and 0.6 * n < kept < 0.8 * n
+    want = np.float32(n / kept)
+    assert scale_dev.item() == want
+    rs = np.random.RandomState(4)
+    x = torch.from_numpy(rs.standard_normal(n).astype(np.float32)).to(_dev()).to(torch.bfloat16)
+    sc, sh = _t(rs.uniform(0.5, 1.5, Cc).astype(np.float32)), _t(rs.standard_normal(Cc).astype(np.float32))
+    outs = []
+    for dev_scale in (False, True):
+        y = torch.empty(n, dtype=torch.bfloat16, device=_dev())
+        _lib.check(lib.subreg_bn_apply(_lib.ptr(x), _lib.ptr(sc), _lib.ptr(sh), None, None, None, _lib.ptr(keep),
+                                       0.0 if dev_scale else float(want), _lib.ptr(scale_dev) if dev_scale else None, _lib.ptr(y),
+                                       B, H, W, Cc, _lib.CONV_LRELU, _lib.BF16, _lib.stream_ptr()))
+        outs.append(y.float().cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0]).max() > 0
+
+
 @pytest.mark.parametrize("case", [(2, 8, 10, 10, 5, 7), (3, 16, 10, 10, 5, 25), (1, 8, 5, 5, 5, 5), (2, 8, 9, 7, 3, 6), (2, 8, 6, 6, 2, 9),
                                   (1, 8, 10, 10, 5, 0), (4, 64, 10, 10, 5, 400)])
 def test_dropblock_block_mask_on_device(case):
