@@ -30,6 +30,10 @@ namespace subreg {
 #ifndef R64_FUSED_STAGGER
 #define R64_FUSED_STAGGER 1     // conv64_fused_first_kernel: waves 4-7 run conv1 of the next tile AFTER their conv2 chunks (0: all waves first)
 #endif
+#ifndef R64_CUT
+#define R64_CUT 0       // conv64_fused_first_kernel, timing experiments only (WRONG results): leave one component out -
+                        // 1 conv2's MFMAs, 2 conv2's A-fragment reads, 3 conv1, 4 the epilogue, 5 image DMA + patch conversion
+#endif
 #ifndef R64_DIAG
 #define R64_DIAG 0      // 1: per-wave s_memtime stamps of the tile loop's phases into r64_diag (measurement builds only)
 #endif
@@ -680,11 +684,11 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
         int b2 = 0, k2 = 0;
         if (more2) {
             tile_geom(t + 2 * nslot, b2, k2);
-            dma_patch(b2, k2);                                         // lands while this tile computes
+            if (R64_CUT != 5) dma_patch(b2, k2);                       // lands while this tile computes
         }
         // conv1 of the next tile needs nothing from this tile (its own plane pair, its own patch): the two waves of a SIMD (w and
         // w + 4) run it at opposite ends of the tile, so one wave's VALU / LDS-heavy conv1 phase meets its partner's MFMA chunks
-        if (more && (wid < 4 || !R64_FUSED_STAGGER)) conv1_tile(nk, pp ^ 1);
+        if (R64_CUT != 3 && more && (wid < 4 || !R64_FUSED_STAGGER)) conv1_tile(nk, pp ^ 1);
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
             u32x4 ring[RD];
             auto rd = [&](auto jc) {
                 constexpr int j = decltype(jc)::value, tt = j >> 2, s = (j >> 1) & 1, i = j & 1, dy = tt / 3, dx = tt % 3;
-                ring[j % RD] = lds_read16<dy * P * R64_ROWB>(ta[i][dx][s]);
+                if (R64_CUT != 2) ring[j % RD] = lds_read16<dy * P * R64_ROWB>(ta[i][dx][s]);
             };
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             static_for<0, RD - 1>(rd);
@@ -713,8 +717,8 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
                 if constexpr (j + RD - 1 < NRD) rd(std::integral_constant<int, j + RD - 1>{});
                 constexpr int left = NRD - 1 - j;
                 u32x4 f = ring[j % RD];
-                f = lds_wait<(left >= RD - 1 ? RD - 1 : left)>(f);
-                acc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f),
+                if (R64_CUT != 2) f = lds_wait<(left >= RD - 1 ? RD - 1 : left)>(f);
+                if (R64_CUT != 1) acc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f),
                                                                       __builtin_bit_cast(bf16x8, bw[c][j >> 2][(j >> 1) & 1]), acc[j & 1], 0, 0, 0);
             });
         };
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
         const int rows_left = a.H - k_img * a.R, nvalid = (rows_left < a.R ? rows_left : a.R) * W;
         const long long pix0 = ((long long)b * a.H + (long long)k_img * a.R) * W;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < (R64_CUT == 4 ? 0 : 2); ++i) {
             const int jrow0 = wm * 64 + i * 32;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -745,10 +749,10 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (R64_FUSED_STAGGER && more && wid >= 4) conv1_tile(nk, pp ^ 1);
+        if (R64_CUT != 3 && R64_FUSED_STAGGER && more && wid >= 4) conv1_tile(nk, pp ^ 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's patch pieces of tile t + 2 landed (and its stores)
         __syncthreads();                                               // every wave: conv1 read the bf16 patch, every patch piece landed
-        if (more2) convert_patch();
+        if (more2 && R64_CUT != 5) convert_patch();
         __syncthreads();                                               // bf16 patch of t + 2 and the planes of t + 1 are complete
         b = nb; k_img = nk; nb = b2; nk = k2;
     }
