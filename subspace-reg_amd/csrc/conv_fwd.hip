@@ -25,6 +25,8 @@
 //   f32 : v_mfma_f32_32x32x2_f32, bitwise an fmaf chain  (parity mode, 1e-4 gate)
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "conv_index.h"
 #include "subreg_common.h"
 
@@ -37,6 +39,11 @@
 #endif
 #ifndef SUBREG_BF16_MFMA16
 #define SUBREG_BF16_MFMA16 1     // 1: v_mfma_f32_16x16x32_bf16 where mfma_tile() says so, 0: v_mfma_f32_32x32x16_bf16 everywhere
+#endif
+#ifndef SUBREG_STAGING_ROLES
+#define SUBREG_STAGING_ROLES 0   // 1: in 3x3 launches the waves take ONE staging role each (3 weight waves + 1 patch wave of 4): measured
+                                 // 1-17 % SLOWER (profiles/r04_ab_staging_roles.txt): a step is as long as the wave with the most DMAs
+                                 // takes to issue them, and 10 weight pieces over 3 waves is 4 on one of them at every step
 #endif
 #ifndef SUBREG_WAVES_K2
 #define SUBREG_WAVES_K2 1        // 1: grids of <= 256 workgroups (128-row tiles, 3 taps per step) put two waves on every tile
@@ -116,11 +123,24 @@ __device__ __forceinline__ void mma_step<float>(const uint4& a, const uint4& b, 
 // fp32 accumulators to a.part; splitk_reduce_kernel adds them up and runs the epilogue (raw + statistics, or scale / shift / act).
 // For the 10x10 / 5x5 maps at the pretraining batch: 52-100 tiles on 256 CUs, every tile a chain of 30-60 steps that cannot be
 // shorter than one L2 / MALL round trip each (the next step's weights are staged one step ahead).
-template <typename T, int NI, int NJ, int WAVES_M, int WAVES_N, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1, bool SPLITK = false>
+// SWAPC (eval mode, un-pooled, bf16): the MFMA operands are swapped (A = weights, B = activations), so a lane holds ONE pixel and
+// its accumulator registers hold consecutive CHANNELS: the epilogue packs four channels per ds_write_b64 into the store slab
+// (the un-swapped form needs one ds_write_b16 and six VALU instructions per element).  Not for raw mode: its per-channel
+// statistics want the channel in the lane.
+//
+// Staging roles (round 4).  In a 3x3 launch (NG > 1 steps per chunk) the waves of a workgroup have ONE staging role each: the
+// first NWW waves stage weight tiles (the next step's, waited for at the end of every step), the last NPW waves stage the
+// next chunk's patch (waited for only at the chunk's last step).  vmcnt counts a wave's DMAs in issue order, so a wave that
+// issued both kinds could not wait for its weights without also waiting for the patch pieces it had issued a step earlier -
+// an HBM / MALL round trip exposed every step.  The main loop is two loops (convolution chunks, shortcut chunks) with no
+// per-piece phase decisions left in them.
+template <typename T, int NI, int NJ, int WAVES_M, int WAVES_N, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1, bool SPLITK = false,
+          bool SWAPC = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kernel(const ConvArgs a) {
     using K = KT<T>;
     constexpr int NWMN = WAVES_M * WAVES_N, NW = NWMN * WK;
     static_assert(WK == 1 || WK == 2, "one or two waves per output tile");
+    static_assert(!SWAPC || (!POOL && !SPLITK && sizeof(T) == 2), "swapped accumulators: eval-mode un-pooled bf16 tiles only");
     constexpr int TM = WAVES_M * NI * 32, TN = WAVES_N * NJ * 32;
     constexpr int SLOTS = K::SLOTS, ROWB = K::ROWB, ELEM = K::ELEM;
     constexpr int RPP = 1024 / ROWB;                     // rows per 1-KiB DMA piece (16 bf16 / 8 f32)
@@ -177,6 +197,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
         *reinterpret_cast<uint4*>(smem + b * ABUF + AROWS * ROWB + q * 16) = make_uint4(0, 0, 0, 0);
     }
 
+    // Accumulators start at zero - or, with swapped accumulators and the BatchNorm scale folded into the weights (every eval-mode
+    // call of the backbone), at the BN SHIFT of the register's channel: the loads are issued behind the prologue's DMAs, land under
+    // their wait, and the epilogue has no affine step left (no per-channel constants to fetch between its stores).
+    const bool shift_in_acc = SWAPC && !a.scale;                     // kernel-uniform
     acc_t acc[MI][MJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -184,42 +208,38 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
         for (int j = 0; j < MJ; ++j)
 #pragma unroll
             for (int r = 0; r < NR; ++r) acc[i][j][r] = 0.f;
-
-    // ---- staging (LDS-DMA).  Lane l of a piece writes LDS row 16q + l/SLOTS, physical slot l%SLOTS, so it must
+    // ---- staging (LDS-DMA).  Lane l of a piece writes LDS row RPP*q + l/SLOTS, physical slot l%SLOTS, so it must
     //      FETCH logical slot (l%SLOTS) ^ swz(row): the swizzle lives on the source address (rule 21).
+    //      All DMA source addresses are (kernel-argument base pointer) + 32-bit byte offset.
     const int prl = lane / SLOTS, psl = lane % SLOTS;            // row within a piece, physical slot
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of smem
-    // piece group `grp` of a patch = pieces grp*NW .. grp*NW+NW-1, one per wave (the last group re-loads the last
-    // piece on the surplus waves so that every wave issues the same number of DMAs: counted vmcnt waits rely on it)
-    // All DMA source addresses are (kernel-argument base pointer) + 32-bit byte offset: the wave-uniform part of the offset
-    // (patch origin, channel chunk, weight tile) is a handful of 32-bit scalar operations per step.  (Spelled as 64-bit
-    // pointer arithmetic per piece it cost ~130 scalar instructions per step - the "DMA issue" share of the in-kernel stamps.)
     const unsigned xrow0 = (unsigned)a.Cin * ELEM, xrow1 = (unsigned)a.Cin2 * ELEM;
     const unsigned porg0 = (unsigned)plo * xrow0, porg1 = (unsigned)plo * xrow1;       // byte offset of the patch origin in x / x2
-    auto stage_patch_group = [&](bool second, int chunk, int buf, int grp) {
-        const unsigned xrow = second ? xrow1 : xrow0;
-        const unsigned uoff = (second ? porg1 : porg0) + (unsigned)chunk * (32 * ELEM);   // wave-uniform
-        int q = grp * NW + wid;
-        q = q < apieces ? q : apieces - 1;
+    auto swz_off = [&](int row) -> unsigned { return (unsigned)((psl ^ swz_tr<SLOTS, TR>(row)) << 4); };
+    auto rfl = [](unsigned v) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    // piece q (rows RPP*q ..) of the patch whose 32-channel chunk starts at byte `uoff` of `src` (row pitch xrow) into patch buffer buf;
+    // the tail rows of the last piece read any valid source row
+    auto patch_piece = [&](const char* src, unsigned uoff, unsigned xrow, int q, int buf) {
         const int row = q * RPP + prl;
-        const int srow = row < prow ? row : prow - 1;                // tail rows of the last piece: any valid source
-        dma16(second ? a.x2 : a.x, uoff + (unsigned)srow * xrow + ((psl ^ swz_tr<SLOTS, TR>(row)) << 4), lds_base + buf * ABUF + q * 1024);
+        const int srow = row < prow ? row : prow - 1;
+        dma16(src, uoff + (unsigned)srow * xrow + swz_off(row), lds_base + buf * ABUF + q * 1024);
     };
-    const int agroups = (apieces + NW - 1) / NW;                     // piece groups of one patch
-    auto stage_patch = [&](bool second, int chunk, int buf) {
-        for (int grp = 0; grp < agroups; ++grp) stage_patch_group(second, chunk, buf, grp);
+    // the same inside the main loop: the per-lane part of the address is one of two registers made once per chunk (pv: every
+    // piece but the last; pv_last: the last piece with its tail rows clamped), the rest is scalar.  (Written as patch_piece
+    // above, the compiler hoists one clamped row per unrolled piece out of the chunk loop - 24 registers it then spills.)
+    static_assert(RPP % 16 == 0 || sizeof(T) == 4, "bf16: the swizzle of a piece row does not depend on the piece");
+    auto patch_piece_fast = [&](const char* src, unsigned uoff, unsigned xrow, int q, int buf, unsigned pv, unsigned pv_last) {
+        const unsigned so = rfl(uoff + (unsigned)(q * RPP) * xrow);
+        dma16(src, (q == apieces - 1 ? pv_last : pv) + so, lds_base + buf * ABUF + q * 1024);
     };
-    // weight tiles of `ntaps` consecutive taps starting at `tap` into weight buffer `buf`.  The per-lane part of the
-    // source address (output channel row, swizzled slot) does not depend on the step: precomputed once.
-    constexpr int PW = (TN / RPP + NW - 1) / NW;                     // weight pieces per wave per tap
-    unsigned wvoff[PW];
-#pragma unroll
-    for (int k = 0; k < PW; ++k) {
-        const int q = k * NW + wid, row = q * RPP + prl;
+    // per-lane source offset of weight piece q of a (tap, chunk) tile: output channel row, swizzled slot (N tail: those output
+    // columns are never stored)
+    auto wvoff_of = [&](int q) -> unsigned {
+        const int row = q * RPP + prl;
         const int n = n0 + row;
-        const int wn = n < a.Cout ? n : a.Cout - 1;                  // N tail: those output columns are never stored
-        wvoff[k] = (unsigned)wn * ROWB + ((psl ^ swz_tr<SLOTS, TR>(row)) << 4);
-    }
+        const int wn = n < a.Cout ? n : a.Cout - 1;
+        return (unsigned)wn * ROWB + swz_off(row);
+    };
     // ---- step list: phase 0 = the convolution (nch0 chunks x NG tap groups); phase 1 = the fused shortcut GEMM
     //      (nch1 chunks, centre tap only).  Patch of chunk c lives in buffer c&1, weights of step s in buffer s%NWB.
     const int nch0 = a.Cin / 32, nch1 = a.x2 ? a.Cin2 / 32 : 0;
@@ -227,30 +247,57 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     // chunk range of this workgroup: everything, or its share of the K split (no shortcut GEMM in split launches)
     const int c_beg = SPLITK ? (int)((long long)nch0 * blockIdx.y / a.ksplit) : 0;
     const int c_end = SPLITK ? (int)((long long)nch0 * (blockIdx.y + 1) / a.ksplit) : nchunks;
+    const int c_main_end = c_end < nch0 ? c_end : nch0;               // end of the convolution chunks of this workgroup
     constexpr bool STAMPS = SUBREG_DIAG == 3;
     unsigned long long t_begin = 0, t_loop = 0, t_issue = 0, t_wait = 0, t_bar = 0, t_mma = 0, tq = 0, r_begin = 0;
     if (STAMPS) { t_begin = __builtin_amdgcn_s_memtime(); r_begin = __builtin_amdgcn_s_memrealtime(); }
-    // one weight piece (tap-in-step tt, piece kw of this wave) of the step at (chunk sc, tap group stg) into ring slot wb
     const unsigned wtile = (unsigned)a.Cout * ROWB, wtap = (unsigned)nch0 * wtile;     // bytes of one (tap, chunk) tile / of one tap
-    auto stage_w_piece = [&](int sc, int stg, int tt, int kw, int wb) {
-        const int q = kw * NW + wid;
-        if (sc >= c_end || q >= TN / RPP) return 0;
-        const unsigned dst = lds_base + B_BASE + wb * BBUF + tt * BTAP + q * 1024;
-        if (sc < nch0) {                                              // tile (tap, chunk): Cout contiguous rows
-            dma16(a.w, (unsigned)(stg * TPS + tt) * wtap + (unsigned)sc * wtile + wvoff[kw], dst);
-            return 1;
-        }
-        if (tt != 0) return 0;                                        // the shortcut GEMM has a single tap
-        dma16(a.w2, (unsigned)(sc - nch0) * wtile + wvoff[kw], dst);
-        return 1;
-    };
-    // the step after (sc, stg)
-    auto advance = [&](int& sc, int& stg) {
-        if (sc >= nch0 || stg == NG - 1) { ++sc; stg = 0; } else { ++stg; }
-    };
-    stage_patch(false, c_beg, c_beg & 1);
+
+    // staging roles (see the header): with one step per chunk (1x1 launches) every step is a chunk end and all waves do both
+    constexpr bool ROLES = SUBREG_STAGING_ROLES && NG > 1;
+    constexpr int NPW = ROLES ? (NW >= 4 ? NW / 4 : 1) : NW;          // waves that stage patch pieces inside the loop
+    constexpr int NWW = ROLES ? NW - NPW : NW;                        // waves that stage weight pieces
+    const bool has_w = !ROLES || wid < NWW, has_p = !ROLES || wid >= NWW;          // wave-uniform
+    const int ww = has_w ? wid : 0, pw = ROLES ? (has_p ? wid - NWW : 0) : wid;
+    constexpr int WPT = TN / RPP;                                      // weight pieces per tap
+    constexpr int PWW = (WPT + NWW - 1) / NWW;                         // ... per weight wave (the last one only on some waves)
+    const bool w_last_ok = (PWW - 1) * NWW + ww < WPT;
+    unsigned wvoff[PWW];
 #pragma unroll
-    for (int k = 0; k < TPS * PW; ++k) stage_w_piece(c_beg, 0, k / PW, k % PW, 0);
+    for (int k = 0; k < PWW; ++k) wvoff[k] = wvoff_of(k * NWW + ww);
+    // weight tiles of `ntaps` consecutive taps (byte offset soff of the first, tapstride between them) into weight buffer wb
+    auto stage_weights = [&](const char* wsrc, unsigned soff, unsigned tapstride, int ntaps, int wb) {
+#pragma unroll
+        for (int tt = 0; tt < TPS; ++tt) {
+            if (tt >= ntaps) continue;
+#pragma unroll
+            for (int k = 0; k < PWW; ++k) {
+                if (k == PWW - 1 && !w_last_ok) continue;
+                // (the scalar part goes through readfirstlane as ONE value: split into a per-step and a per-chunk term the
+                // compiler hoists wvoff + per-step term out of the chunk loop, one register per unrolled piece)
+                dma16(wsrc, wvoff[k] + rfl(soff + (unsigned)tt * tapstride),
+                      lds_base + B_BASE + wb * BBUF + tt * BTAP + (k * NWW + ww) * 1024);
+            }
+        }
+    };
+    // prologue: the first chunk's patch and the first step's weights, spread over all waves (every wave issues the same number of
+    // patch DMAs: the surplus waves of the last round re-load the last piece)
+    {
+        const int rounds = (apieces + NW - 1) / NW;
+        for (int r = 0; r < rounds; ++r) {
+            int q = r * NW + wid;
+            q = q < apieces ? q : apieces - 1;
+            patch_piece(a.x, porg0 + (unsigned)c_beg * (32 * ELEM), xrow0, q, c_beg & 1);
+        }
+#pragma unroll
+        for (int k = 0; k < (TPS * WPT + NW - 1) / NW; ++k) {
+            const int idx = k * NW + wid;
+            if (idx < TPS * WPT) {
+                const int tt = idx / WPT, q = idx % WPT;
+                dma16(a.w, wvoff_of(q) + (unsigned)tt * wtap + (unsigned)c_beg * wtile, lds_base + B_BASE + tt * BTAP + q * 1024);
+            }
+        }
+    }
     // per-lane LDS addresses of this lane's A rows for every tap (k-step 0; k-step s is addr ^ 16*LG*s): logical slot
     // LG*s + lh of the row, physical slot = logical ^ swz.  Kept as 16-bit halves (every patch buffer is < 64 KiB):
     // the 16x16 MFMA shape needs MI = 4 row addresses per tap and the accumulators leave no room for 36 registers.
@@ -284,150 +331,206 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     static_assert(TR % 16 == 0, "swizzle period");
     // (computed HERE, between issuing the prologue's DMAs and waiting for them: ~1000 cycles of integer divisions that would
     // otherwise precede the first global access of a short-K workgroup)
+    // (after the tap addresses: loaded earlier, 80-160 accumulator registers are live across that register-hungry computation)
+    if constexpr (SWAPC) {
+        if (shift_in_acc && wave_k == 0) {                           // (WK = 2: the pair's sums are added at the end - one shift only)
+#pragma unroll
+            for (int j = 0; j < MJ; ++j)
+#pragma unroll
+                for (int q = 0; q < NR / 4; ++q) {
+                    int n = n0 + wave_n * (NJ * 32) + j * TR + 8 * q + 4 * lh;
+                    n = n < a.Cout ? n : a.Cout - 4;
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = sh[e];
+                }
+        }
+    }
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's DMA landed ...
     __syncthreads();                                                  // ... everyone's did; zero rows visible
-    // Patch of chunk c+1 is prefetched during chunk c, PA piece groups per step (none in the chunk's last step when
-    // there are several).  LDS-DMA completes in issue order; a step issues [weights of step+1][patch groups] and its
-    // end-of-step wait is `vmcnt(N)` with N = the patch groups, the youngest DMAs, which may stay in flight (0 at a chunk end).
-    constexpr int PSTEPS = NG > 1 ? NG - 1 : 1;                       // steps of a chunk that carry patch groups
-    constexpr int PA = (AROWS / RPP + NW * PSTEPS - 1) / (NW * PSTEPS);
+    // one MFMA of this kernel: C[pixel][channel] tiles, or (SWAPC) C[channel][pixel] with the operands swapped
+    auto mma_ab = [&](const uint4& xa, const uint4& wb, acc_t& c) {
+        if constexpr (SWAPC) mma_step<T>(wb, xa, c); else mma_step<T>(xa, wb, c);
+    };
+    // ---- the k-steps of one step: TPS taps x KSTEPS (a shortcut step: the centre tap only) on patch buffer offset aoff, weight
+    //      buffer offset boff.  Where the register budget allows two fragment sets (small wave tiles, which also run at low
+    //      occupancy), software-pipeline: the LDS reads of k-step kk+1 are issued between the MFMAs of k-step kk.  The 64x160
+    //      wave tile (160 accumulator registers) cannot afford it: per k-step the A fragments, then the B fragments streamed
+    //      column tile by column tile through a 3-deep register ring, each read issued two tiles (2*MI MFMAs) ahead of its use.
+    //      The order is pinned with sched_group_barriers: left alone, the scheduler sinks every read next to its use and waits
+    //      lgkmcnt(0) on it (one exposed LDS latency per MI MFMAs).
+    constexpr int NK = TPS * KSTEPS;
+    constexpr int KX = 16 * LG;                               // address XOR per k-step
+    constexpr bool SWP = NI * NJ * 16 + 2 * (MI + MJ) * 4 + 40 <= 200;
+    static_assert(WK == 1 || !SWP, "the k-step split is implemented on the ring-pipelined path");
+    auto mma_block = [&](auto ph1_tag, int aoff, int boff, int tg, int step) {
+        constexpr bool PH1 = decltype(ph1_tag)::value;
+        constexpr int NKE = PH1 ? KSTEPS : NK;                // k-steps of this step
+        auto a_tap = [&](int kk) -> int { return PH1 ? CENTER : tg * TPS + kk / KSTEPS; };
+        auto load_b1 = [&](int kk, int j) -> uint4 {
+            const int tt = PH1 ? 0 : kk / KSTEPS, s = kk % KSTEPS;
+            return *reinterpret_cast<const uint4*>(smem + boff + tt * BTAP + j * (TR * ROWB) + (baddr0 ^ (KX * s)));
+        };
+        if constexpr (SUBREG_DIAG == 2) {
+        } else if constexpr (SWP) {
+            constexpr int NRD = MI + MJ, NMM = MI * MJ * (sizeof(T) == 2 ? 1 : 4), PER = NMM / NRD > 0 ? NMM / NRD : 1;
+            uint4 fa[2][MI], fb[2][MJ];
+            auto load_a = [&](int kk, uint4(&xa)[MI]) {
+                const int s = kk % KSTEPS;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) xa[i] = *reinterpret_cast<const uint4*>(smem + aoff + (aaddr(i, a_tap(kk)) ^ (KX * s)));
+            };
+            load_a(0, fa[0]);
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) fb[0][j] = load_b1(0, j);
+#pragma unroll
+            for (int kk = 0; kk < NKE; ++kk) {
+                if (kk + 1 < NKE) {
+                    load_a(kk + 1, fa[(kk + 1) & 1]);
+#pragma unroll
+                    for (int j = 0; j < MJ; ++j) fb[(kk + 1) & 1][j] = load_b1(kk + 1, j);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MJ; ++j) mma_ab(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
+                if (kk + 1 < NKE) {                                   // interleave: PER MFMAs, 1 ds_read, ...
+#pragma unroll
+                    for (int n = 0; n < NRD; ++n) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+            }
+        } else {
+            constexpr int MPG = MI * (sizeof(T) == 2 ? 1 : 4);    // MFMAs per column tile
+#pragma unroll
+            for (int kk = 0; kk < NKE; ++kk) {
+                if (WK > 1 && ((step * NK + kk) % WK) != wave_k) continue;    // the partner wave's k-step
+                const int s = kk % KSTEPS;
+                uint4 fa[MI], fb[3];
+                auto rd_a = [&](int i) { fa[i] = *reinterpret_cast<const uint4*>(smem + aoff + (aaddr(i, a_tap(kk)) ^ (KX * s))); };
+                rd_a(0);
+                fb[0] = load_b1(kk, 0);
+#pragma unroll
+                for (int i = 1; i < MI; ++i) rd_a(i);
+                if (MJ > 1) fb[1] = load_b1(kk, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, MI + (MJ > 1 ? 2 : 1), 0);
+#pragma unroll
+                for (int j = 0; j < MJ; ++j) {
+                    if (j + 2 < MJ) {
+                        fb[(j + 2) % 3] = load_b1(kk, j + 2);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) mma_ab(fa[i], fb[j % 3], acc[i][j]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
+                }
+            }
+        }
+    };
+    // Patch of chunk c+1 is prefetched during chunk c, PA pieces per patch wave and step (none in the chunk's last step when
+    // there are several, so that the chunk-end wait finds them landed).
+    constexpr int PSTEPS = NG > 1 ? NG - 1 : 1;                       // steps of a chunk that carry patch pieces
+    constexpr int PA = (AROWS / RPP + NPW * PSTEPS - 1) / (NPW * PSTEPS);
     int step = 0;
     if (STAMPS) t_loop = __builtin_amdgcn_s_memtime();
-    for (int c = c_beg; c < c_end; ++c) {
-        const bool ph1 = c >= nch0;
+    int c = c_beg;
+    // ---- phase 0: the convolution chunks
+    for (; c < c_main_end; ++c) {
         const bool more = c + 1 < c_end;
         const bool nsecond = c + 1 >= nch0;                           // the next chunk belongs to the shortcut GEMM
-        const int nck = nsecond ? c + 1 - nch0 : c + 1;
+        const char* const psrc = nsecond ? a.x2 : a.x;
+        const unsigned pxrow = nsecond ? xrow1 : xrow0;
+        const unsigned puoff = nsecond ? porg1 + (unsigned)(c + 1 - nch0) * (32 * ELEM) : porg0 + (unsigned)(c + 1) * (32 * ELEM);
+        const int np = more ? apieces : 0;                            // patch pieces to stage during this chunk
+        unsigned pv = 0, pv_last = 0;                                 // per-lane parts of the patch source addresses (patch waves)
+        if (has_p) {
+            int prl_o = prl;
+            asm volatile("" : "+v"(prl_o));                           // (opaque: keeps the two values out of the loop-invariant set)
+            const int lim = prow - 1 - (apieces - 1) * RPP;           // last valid row of the last piece
+            if constexpr (sizeof(T) == 2) {
+                pv = (unsigned)prl_o * pxrow + swz_off(prl_o);
+                pv_last = (unsigned)(prl_o < lim ? prl_o : lim) * pxrow + swz_off(prl_o);
+            }
+        }
         const int nbuf = (c + 1) & 1;                                 // patch buffer of the next chunk
         const int aoff = (c & 1) * ABUF;
 #pragma unroll
         for (int tg = 0; tg < NG; ++tg) {
-            if (ph1 && tg != 0) continue;
-            const bool last_grp = ph1 || tg == NG - 1;
-            // DMA work of this step: the next step's weight pieces, then PA patch groups of the next chunk.  Issued in one
-            // burst right after the barrier; the DMAs of the four waves queue up behind each other in the CU's one address
-            // path (~75 stalled cycles each, in-kernel stamps).
             if (STAMPS) tq = __builtin_amdgcn_s_memtime();
-            int wc = c, wtg = tg;                                     // the step whose weights this step stages
-            advance(wc, wtg);
             const int wb = (step + 1) % NWB;
             int n_patch = 0;
             if (SUBREG_DIAG != 1) {
-#pragma unroll
-                for (int k = 0; k < TPS * PW; ++k) stage_w_piece(wc, wtg, k / PW, k % PW, wb);
-                if (!ph1) {
+                if (has_w) {                                          // the next step's weights
+                    if (tg < NG - 1) {
+                        stage_weights(a.w, (unsigned)((tg + 1) * TPS) * wtap + (unsigned)c * wtile, wtap, TPS, wb);
+                    } else if (c + 1 < c_main_end) {
+                        stage_weights(a.w, (unsigned)(c + 1) * wtile, wtap, TPS, wb);
+                    } else if (more) {
+                        stage_weights(a.w2, (unsigned)(c + 1 - nch0) * wtile, 0, 1, wb);
+                    }
+                }
+                if (has_p && (NG == 1 || tg < PSTEPS)) {              // PA pieces of the next chunk's patch
 #pragma unroll
                     for (int k = 0; k < PA; ++k) {
-                        const int grp = tg * PA + k;
-                        if (more && (NG == 1 || tg < PSTEPS) && grp < agroups) {
-                            stage_patch_group(nsecond, nck, nbuf, grp);
+                        const int q = (tg * PA + k) * NPW + pw;
+                        if (q < np) {
                             ++n_patch;
+                            if constexpr (sizeof(T) == 2) patch_piece_fast(psrc, puoff, pxrow, q, nbuf, pv, pv_last);
+                            else patch_piece(psrc, puoff, pxrow, q, nbuf);
                         }
                     }
-                } else if (more) {                                    // a shortcut step consumes a whole patch: stage all of the next
-                    for (int grp = 0; grp < agroups; ++grp) stage_patch_group(nsecond, nck, nbuf, grp);
                 }
             }
             if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_issue += n - tq; tq = n; }
-            const int boff = (step % NWB) * BBUF;
-            // k-steps of this step (TPS taps x KSTEPS).  Where the register budget allows two fragment sets (small
-            // wave tiles, which also run at low occupancy), software-pipeline: the LDS reads of k-step kk+1 are issued
-            // between the MFMAs of k-step kk.  The 64x160 wave tile (160 accumulator registers) cannot afford it.
-            constexpr int NK = TPS * KSTEPS;
-            constexpr int KX = 16 * LG;                               // address XOR per k-step
-            constexpr bool SWP = NI * NJ * 16 + 2 * (MI + MJ) * 4 + 40 <= 200;
-            static_assert(WK == 1 || !SWP, "the k-step split is implemented on the ring-pipelined path");
-            auto load_a = [&](int kk, uint4(&xa)[MI]) {
-                const int tt = kk / KSTEPS, s = kk % KSTEPS;
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int ad = ph1 ? aaddr(i, CENTER) : aaddr(i, tg * TPS + tt);
-                    xa[i] = *reinterpret_cast<const uint4*>(smem + aoff + (ad ^ (KX * s)));
-                }
-            };
-            auto load_b1 = [&](int kk, int j) -> uint4 {
-                const int tt = kk / KSTEPS, s = kk % KSTEPS;
-                return *reinterpret_cast<const uint4*>(smem + boff + tt * BTAP + j * (TR * ROWB) + (baddr0 ^ (KX * s)));
-            };
-            if constexpr (SUBREG_DIAG == 2) {
-            } else if constexpr (SWP) {
-                constexpr int NRD = MI + MJ, NMM = MI * MJ * (sizeof(T) == 2 ? 1 : 4), PER = NMM / NRD > 0 ? NMM / NRD : 1;
-                uint4 fa[2][MI], fb[2][MJ];
-                load_a(0, fa[0]);
-#pragma unroll
-                for (int j = 0; j < MJ; ++j) fb[0][j] = load_b1(0, j);
-#pragma unroll
-                for (int kk = 0; kk < NK; ++kk) {
-                    if (ph1 && kk >= KSTEPS) continue;                 // the shortcut GEMM has a single tap
-                    const bool more_k = kk + 1 < NK && !(ph1 && kk + 1 >= KSTEPS);
-                    if (more_k) {
-                        load_a(kk + 1, fa[(kk + 1) & 1]);
-#pragma unroll
-                        for (int j = 0; j < MJ; ++j) fb[(kk + 1) & 1][j] = load_b1(kk + 1, j);
-                    }
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-#pragma unroll
-                        for (int j = 0; j < MJ; ++j) mma_step<T>(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
-                    if (kk + 1 < NK) {                                    // interleave: PER MFMAs, 1 ds_read, ...
-#pragma unroll
-                        for (int n = 0; n < NRD; ++n) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        }
-                    }
-                }
-            } else {
-                // big wave tiles: no room for a second fragment set.  Per k-step: the A fragments, then the B fragments
-                // streamed column tile by column tile through a 3-deep register ring, each read issued two tiles (2*MI
-                // MFMAs) ahead of its use.  The order is pinned with sched_group_barriers: left alone, the scheduler
-                // sinks every read next to its use and waits lgkmcnt(0) on it (one exposed LDS latency per MI MFMAs).
-                constexpr int MPG = MI * (sizeof(T) == 2 ? 1 : 4);    // MFMAs per column tile
-#pragma unroll
-                for (int kk = 0; kk < NK; ++kk) {
-                    if (ph1 && kk >= KSTEPS) continue;
-                    if (WK > 1 && ((step * NK + kk) % WK) != wave_k) continue;    // the partner wave's k-step
-                    const int tt = kk / KSTEPS, s = kk % KSTEPS;
-                    uint4 fa[MI], fb[3];
-                    auto rd_a = [&](int i) {
-                        const int ad = ph1 ? aaddr(i, CENTER) : aaddr(i, tg * TPS + tt);
-                        fa[i] = *reinterpret_cast<const uint4*>(smem + aoff + (ad ^ (KX * s)));
-                    };
-                    rd_a(0);
-                    fb[0] = load_b1(kk, 0);
-#pragma unroll
-                    for (int i = 1; i < MI; ++i) rd_a(i);
-                    if (MJ > 1) fb[1] = load_b1(kk, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x100, MI + (MJ > 1 ? 2 : 1), 0);
-#pragma unroll
-                    for (int j = 0; j < MJ; ++j) {
-                        if (j + 2 < MJ) {
-                            fb[(j + 2) % 3] = load_b1(kk, j + 2);
-                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        }
-#pragma unroll
-                        for (int i = 0; i < MI; ++i) mma_step<T>(fa[i], fb[j % 3], acc[i][j]);
-                        __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
-                    }
-                }
-            }
+            mma_block(std::false_type{}, aoff, (step % NWB) * BBUF, tg, step);
             ++step;
             if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_mma += n - tq; tq = n; }
-            // end of step: next step's weights landed (and, at a chunk boundary, the whole next patch); this wave's
-            // LDS reads are complete (their results fed the MFMAs); then the workgroup barrier
-            {
-                const int keep = last_grp ? 0 : n_patch;
-                switch (keep) {
-                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            // end of step: the weight waves' DMAs (next step's weights) landed; at a chunk end the patch waves' too; this
+            // wave's LDS reads are complete (their results fed the MFMAs); then the workgroup barrier
+            if constexpr (ROLES) {
+                if (has_w || tg == NG - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                // every wave issued [weights of the next step][n_patch patch pieces]: DMAs complete in issue order, so vmcnt(PA)
+                // leaves exactly a full set of patch pieces - the youngest - in flight; a partial set (once per chunk) is waited for
+                if (NG > 1 && tg < NG - 1 && n_patch == PA) {
+                    static_assert(NG == 1 || PA <= 6, "vmcnt immediates below");
+                    if constexpr (PA == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    if constexpr (PA == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    if constexpr (PA == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    if constexpr (PA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    if constexpr (PA == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                    if constexpr (PA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
             }
+            if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_wait += n - tq; tq = n; }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_bar += n - tq; tq = n; }
+        }
+    }
+    // ---- phase 1: the shortcut GEMM's chunks, one step each (centre tap); every step consumes a whole patch, which all waves stage
+    if constexpr (!SPLITK) {
+        for (; c < c_end; ++c) {
+            const bool more = c + 1 < c_end;
+            const int aoff = (c & 1) * ABUF;
+            if (STAMPS) tq = __builtin_amdgcn_s_memtime();
+            if (SUBREG_DIAG != 1 && more) {
+                if (has_w) stage_weights(a.w2, (unsigned)(c + 1 - nch0) * wtile, 0, 1, (step + 1) % NWB);
+                const unsigned puoff = porg1 + (unsigned)(c + 1 - nch0) * (32 * ELEM);
+                for (int q = wid; q < apieces; q += NW) patch_piece(a.x2, puoff, xrow1, q, (c + 1) & 1);
+            }
+            if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_issue += n - tq; tq = n; }
+            mma_block(std::true_type{}, aoff, (step % NWB) * BBUF, 0, step);
+            ++step;
+            if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_mma += n - tq; tq = n; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_wait += n - tq; tq = n; }
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -493,13 +596,111 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
         epi_stamp.t0 = n;
     }
     // ------------------------------------------------------------------ epilogue
-    // C layout of a TR x TR tile: column = lane % TR; register r holds row (r&3) + 8*(r>>2) + 4*(lane / TR)
-    // (32x32: 16 registers, 16x16: 4).  Registers 4q..4q+3 are 4 consecutive rows = one 2x2 pooling window.
     T* const y = reinterpret_cast<T*>(a.y);
     const T* const res = reinterpret_cast<const T*>(a.res);
     const bool full = m0 + TM <= g.M && n0 + TN <= a.Cout;            // no ragged edge in this tile
     constexpr int TPB = 32 / TR;                                      // MFMA tiles per 32-row slab
     constexpr bool SLAB_FITS = NWMN * 32 * (NJ * 32 * ELEM + 16) <= 2 * ABUF + NWB * BBUF;   // slabs reuse the staging LDS
+    if constexpr (SWAPC) {
+        // Swapped accumulators: lane = pixel (row lr of MFMA tile i), registers 4q..4q+3 of tile (i, j) = the four consecutive
+        // channels j*TR + 8q + 4*lh + {0..3}.  Full tiles go through a [row][channel] LDS slab (+16 B row pad) with one
+        // ds_write_b64 per four channels and leave as whole 16-byte vectors, consecutive lanes on consecutive addresses of a
+        // pixel row; ragged tiles / a residual operand take 8-byte stores straight from the registers.
+        constexpr int TNW = NJ * 32, RS = TNW * ELEM + 16, VPR = TNW * ELEM / 16, NV = 32 * VPR, NQ = NR / 4;
+        const bool slab_ok = SLAB_FITS && full && !res;
+        char* const slab = smem + wmn * (32 * RS);    // all waves are past the last step's barrier
+        const float slope = a.act ? 0.1f : 1.f;       // LeakyReLU(0.1) as max(v, slope * v); slope 1 = no activation
+        auto lrelu_pack = [&](float (&v)[4]) -> uint2 {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // (fmaxf would add a canonicalising v_max per element: the compiler does not see that a packed fma result is no sNaN)
+                const float t = v[e] * slope;
+                asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(v[e]), "v"(t));
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+            return __builtin_bit_cast(uint2, o);
+        };
+        // channels cb..cb+3 of tile registers 4q..4q+3: scale / shift (unless the shift is already in the accumulators: INACC),
+        // residual, activation
+        // (per-lane bases + compile-time offsets: spelled with the lane term inside the index the compiler keeps one address
+        // register per store and spills)
+        const float* const shb = s_shift + wave_n * TNW + 4 * lh;
+        const float* const scb = s_scale + wave_n * TNW + 4 * lh;
+        char* const wbase = slab + lr * RS + 4 * lh * ELEM;
+        auto finish4 = [&](auto inacc_tag, const acc_t& cfr, int q, int cc, const uint2* rp) -> uint2 {   // cc = cb - 4*lh (compile-time)
+            constexpr bool INACC = decltype(inacc_tag)::value;
+            float v[4];
+            if constexpr (INACC) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = cfr[4 * q + e];
+            } else {
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(shb + cc);
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(scb + cc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = cfr[4 * q + e] * sc[e] + sh[e];
+            }
+            if (rp) {
+                const uint2 rv = *rp;
+                const __bf16* rb = reinterpret_cast<const __bf16*>(&rv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)rb[e];
+            }
+            return lrelu_pack(v);
+        };
+        auto slab_epilogue = [&](auto inacc_tag) {
+#pragma unroll
+            for (int ib = 0; ib < NI; ++ib) {
+#pragma unroll
+                for (int ii = 0; ii < TPB; ++ii)
+#pragma unroll
+                    for (int j = 0; j < MJ; ++j)
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            const int cc = j * TR + 8 * q;                       // channel (less 4*lh) within this wave's TNW columns
+                            *reinterpret_cast<uint2*>(wbase + ii * TR * RS + cc * ELEM) = finish4(inacc_tag, acc[ib * TPB + ii][j], q, cc, nullptr);
+                        }
+                const int mrow0 = m0 + (wave_m * NI + ib) * 32;
+                char* const ybase = a.y + ((size_t)mrow0 * a.Cout + n0 + wave_n * TNW) * ELEM;
+#pragma unroll
+                for (int v0 = 0; v0 < NV; v0 += 64) {
+                    const int v = v0 + lane;
+                    if (NV % 64 == 0 || v < NV) {
+                        const int row = v / VPR, c16 = v % VPR;
+                        const uint4 val = *reinterpret_cast<const uint4*>(slab + row * RS + c16 * 16);
+                        *reinterpret_cast<uint4*>(ybase + (size_t)row * a.Cout * ELEM + c16 * 16) = val;
+                    }
+                }
+            }
+        };
+        auto direct_epilogue = [&](auto inacc_tag) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + (wave_m * MI + i) * TR + lr;
+#pragma unroll
+                for (int j = 0; j < MJ; ++j)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int cc = j * TR + 8 * q;
+                        const int n = n0 + wave_n * TNW + cc + 4 * lh;
+                        if (m < g.M && n < a.Cout) {
+                            const size_t o = (size_t)m * a.Cout + n;
+                            *reinterpret_cast<uint2*>(y + o) =
+                                finish4(inacc_tag, acc[i][j], q, cc, res ? reinterpret_cast<const uint2*>(res + o) : nullptr);
+                        }
+                    }
+            }
+        };
+        if (slab_ok) {
+            if (shift_in_acc) slab_epilogue(std::true_type{}); else slab_epilogue(std::false_type{});
+        } else {
+            if (shift_in_acc) direct_epilogue(std::true_type{}); else direct_epilogue(std::false_type{});
+        }
+        return;
+    }
+    // C layout of a TR x TR tile: column = lane % TR; register r holds row (r&3) + 8*(r>>2) + 4*(lane / TR)
+    // (32x32: 16 registers, 16x16: 4).  Registers 4q..4q+3 are 4 consecutive rows = one 2x2 pooling window.
     const bool raw_slab = !POOL && SLAB_FITS && full;                 // raw tile written by the slab path below
     if (a.raw) {
 #pragma unroll
@@ -714,18 +915,34 @@ static int worst_patch_rows(const ConvGeom& g, int TM) {
     return worst;
 }
 
-template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1, bool SPLITK = false>
-static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
+template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK, bool SPLITK, bool SWAPC>
+static int launch_kernel(const ConvArgs& a, hipStream_t stream) {
     using K = KT<T>;
     constexpr int TM = WM * NI * 32, TN = WN * NJ * 32;
     constexpr int ABUF = (AROWS + 1) * K::ROWB, BBUF = TPS * TN * K::ROWB;
     const size_t lds = 2 * (size_t)ABUF + 2 * (size_t)BBUF + 2 * TN * sizeof(float);   // patch x2, weights x2, shift/scale
-    auto kern = conv_fwd_kernel<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AROWS, MINW, WK, SPLITK>;
+    auto kern = conv_fwd_kernel<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AROWS, MINW, WK, SPLITK, SWAPC>;
     static std::atomic<unsigned long long> lds_set{0};   // per instantiation
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set)) return rc;
     dim3 grid(((a.g.M + TM - 1) / TM) * ((a.Cout + TN - 1) / TN), SPLITK ? a.ksplit : 1);   // x: the kernel decodes (m-tile, n-tile) itself
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * WK * 64), lds, stream, a);
     return launch_status();
+}
+
+// measurement switch: SUBREG_NO_SWAPC=1 in the environment keeps the un-swapped accumulator layout everywhere (A/B runs)
+static bool swapc_enabled() {
+    static const bool on = [] { const char* e = getenv("SUBREG_NO_SWAPC"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
+template <typename T, int NI, int NJ, int WM, int WN, int TAPS, int TPS, bool POOL, int AROWS, int MINW, int WK = 1, bool SPLITK = false>
+static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
+    // eval-mode un-pooled bf16 tiles run with swapped accumulators (channels in the registers: packed epilogue); raw mode
+    // (per-channel statistics in the epilogue), pooled tiles (window max over four registers) and K splits keep the pixel-major form
+    if constexpr (!POOL && !SPLITK && sizeof(T) == 2) {
+        if (!a.raw && swapc_enabled()) return launch_kernel<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AROWS, MINW, WK, SPLITK, true>(a, stream);
+    }
+    return launch_kernel<T, NI, NJ, WM, WN, TAPS, TPS, POOL, AROWS, MINW, WK, SPLITK, false>(a, stream);
 }
 
 // AR_S / AR_L: small and large LDS patch capacities (rows); the small one allows more workgroups per CU
@@ -936,7 +1153,7 @@ static int conv_fwd_impl(const void* x, const void* w, void* y, const float* sca
             // 128-row tiles.  If they all fit one per CU (<= 256 workgroups) stage 3 taps per step (84 KB LDS, covers the
             // LDS-DMA latency at that occupancy); otherwise 1 tap per step and 3 workgroups per CU.
             if (((b.g.M + 127) / 128) * nt > 256) {
-                const int rc = launch_shape<__bf16, 1, 5, 4, 1, 1, 192, 224, 2>(b, pool, st);    // 224: 42x42 maps, still 3 per CU
+                const int rc = launch_shape<__bf16, 1, 5, 4, 1, 1, 192, 224, 3>(b, pool, st);    // 224: 42x42 maps, still 3 per CU
                 return rc != SUBREG_EUNSUPPORTED ? rc : launch_shape<__bf16, 1, 5, 4, 1, 1, 432, 432, 2>(b, pool, st);
             }
 #if SUBREG_WAVES_K2
