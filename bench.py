@@ -162,6 +162,167 @@ def cpu_baseline(args, n_base):
     return out
 
 
+def measure_forward_ms(net, dev, batches, iters=6):
+    """Eval-mode backbone forward time (ms, HIP events on the launch stream, random 84x84 images) at each batch size in `batches`."""
+    hb = net.hip_backbone()
+    out = {}
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    for n in sorted(set(int(b) for b in batches)):
+        x = torch.randn(n, 3, 84, 84, device=dev, generator=g)
+        for _ in range(2):
+            hb.forward(x, check_params=False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            hb.forward(x, check_params=False)
+        e1.record()
+        torch.cuda.synchronize()
+        out[n] = e0.elapsed_time(e1) / iters
+    return out
+
+
+def sweep_model(args, net, dev, session_seconds):
+    """Inputs of the level-2 sweep model measured on THIS GPU: the eval-mode forward at the per-rank batches
+    a seed shared by g ranks produces (ceil(125 (s + 2) / g) images per epoch of session s, ceil(base / g) for the base
+    evaluation), and the per-epoch cost that does not shard (classifier step + validation, from the timed sessions: session
+    seconds minus forward time).  The feature all-gather itself cannot be measured on one GPU: 30 us per call is assumed
+    (1.8 MB at most over 7 xGMI links x ~153 GB/s is ~2-12 us + launch) and stated."""
+    from subreg_hip import sweep
+    E, nb = args.epochs, args.base_batch
+    groups = sorted({len(rk) for w in (2, 4, 8) for rnd in sweep.plan_sweep(range(args.sweep_seeds or 10), w) for _sd, rk in rnd} | {1})
+    need = set()
+    for g in groups:
+        need |= {-(-(125 * (s + 2)) // g) for s in range(8)} | {-(-nb // g)}
+    t = measure_forward_ms(net, dev, need)
+    fixed_ms = None
+    if session_seconds:
+        # per-epoch cost beside the forward, from the timed region: (session time - forwards) / epochs, averaged over sessions
+        fx = [(1e3 * session_seconds[s] - E * t[125 * (s + 2)] - t[nb]) / E for s in sorted(session_seconds)]
+        fixed_ms = max(0.0, float(np.mean(fx)))
+    gather_ms = 0.030
+    seed_ms = {}
+    for g in groups:
+        seed_ms[g] = sum(E * (t[-(-(125 * (s + 2)) // g)] + (fixed_ms or 0.1) + (gather_ms if g > 1 else 0.0)) + t[-(-nb // g)] for s in range(8))
+    out = {"forward_ms_at_batch": {str(k): round(v, 4) for k, v in sorted(t.items())}, "fixed_ms_per_epoch": fixed_ms,
+           "assumed_allgather_ms": gather_ms, "seed_run_ms_by_group_size": {str(g): round(v, 1) for g, v in seed_ms.items()},
+           "dp_efficiency_by_group_size": {str(g): round((seed_ms[1] / seed_ms[g] - 1.0) / (g - 1), 4) for g in groups if g > 1}}
+    for w in (2, 4, 8):
+        out["speedup_at_%d_gpus" % w] = round(sweep.sweep_speedup_measured(args.sweep_seeds or 10, w, seed_ms), 3)
+    return out
+
+
+def route_a(args, net, opt, meta, dev, n_epochs=8):
+    """Throughput of drop-in route A: the reference's UNCHANGED loop statements (language_eval.py:242-326)
+    over the drop-in modules - nn.Module forward through the HIP backbone, torch autograd for CE + regloss + LangPuller,
+    torch.optim.SGD, one forward per query set - at the shape of the LAST session (125 support images, 8 query sets of 125,
+    100 classifier rows).  The fused loop (IncrementalRunner, the headline) runs the same epoch as one batched forward + three
+    launches; both are reported as fine-tune epochs per second."""
+    from subreg_hip.resnet_language import LangPuller
+    with torch.no_grad():
+        net.classifier.weight = torch.nn.Parameter(net.classifier.weight.detach()[:60].clone())
+    base_weight, base_bias = net._get_base_weights()
+    for _ in range(8):
+        net.augment_base_classifier_(5)
+    support_xs = meta[7][0][0]
+    support_ys = torch.randint(60, 100, (125,), device=dev)
+    queries = [(meta[s][2][0], torch.randint(60, 100, (125,), device=dev)) for s in range(8)]
+    puller = LangPuller(opt, ["b"] * 60, ["n"] * 5)
+    for name, prm in net.named_parameters():                          # freeze_backbone_weights (eval/util.py:62-69)
+        prm.requires_grad = name.startswith("classifier")
+    optimizer = torch.optim.SGD(net.parameters(), lr=opt.learning_rate, momentum=opt.momentum, weight_decay=opt.weight_decay)
+    criterion = torch.nn.CrossEntropyLoss()
+    net.eval()
+
+    def epoch():
+        output = net(support_xs)
+        loss = criterion(output, support_ys)
+        loss = loss + net.regloss(opt.lmbd_reg_transform_w, base_weight, base_bias)
+        pullers = puller.get_projected_weight(base_weight, net.classifier.weight[60:, :])
+        loss = loss + puller.loss1(opt.label_pull, pullers, net.classifier.weight[60:, :])
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        lv = loss.item()                                               # the reference reads the loss every epoch (:296)
+        accs = []
+        with torch.no_grad():
+            for qx, qy in queries:                                     # validate(): one forward per query set (:18-43)
+                out = net(qx)
+                accs.append((out.argmax(1) == qy).float().sum().item())
+        return lv, accs
+    for _ in range(2):
+        epoch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_epochs):
+        epoch()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n_epochs
+    with torch.no_grad():
+        net.classifier.weight = torch.nn.Parameter(net.classifier.weight.detach()[:60].clone())
+    return {"epochs_per_s": 1.0 / dt, "ms_per_epoch": dt * 1e3, "images_per_epoch": 1125,
+            "shape": "session 8 of 8: 125 support + 8 x 125 query images, 9 backbone forwards, torch autograd + SGD on classifier.weight [100, 640]"}
+
+
+def pretrain_leg(args):
+    """BASELINE.json configs[2]: the train_supervised.py step (train-mode forward with stash, full backward, SGD on all 26.29 M
+    parameters; train_supervised.py:205-268) at the reference's batch 64 and at 128, bf16, synthetic 84x84 images.
+    Algorithmic work 24.339 GFLOP per image."""
+    from subreg_hip import synthetic as syn
+    from subreg_hip.resnet_language import create_model
+    from subreg_hip.train import SGD
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = {"workload": "train_supervised.py step, ResNet18, 60 classes, SGD(0.05, 0.9, 5e-4), synthetic 84x84 (BASELINE.json configs[2])",
+           "flop_per_image": 24.339e9, "dtype": args.dtype, "batches": {}}
+    for B in (64, 128):
+        net = create_model("resnet18", 60, SimpleNamespace(no_dropblock=True, linear_bias=False, hip_dtype=args.dtype))
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in syn.make_state_dict(1, randomize_bn=False).items()})
+        net = net.to(dev).train()
+        sgd = SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+        crit = torch.nn.CrossEntropyLoss()
+        x = torch.randn(B, 3, 84, 84, device=dev)
+        y = torch.randint(0, 60, (B,), device=dev)
+
+        def step():
+            loss = crit(net(x), y)
+            sgd.zero_grad()
+            loss.backward()
+            sgd.step()
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        n = 20
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        tf = B * 24.339e9 / dt / 1e12
+        out["batches"][str(B)] = {"ms_per_step": dt * 1e3, "images_per_s": B / dt,
+                                  "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                                               "frac": tf / PEAK_TFLOPS[args.dtype]}}
+        del net, sgd, x, y
+    return out
+
+
+def leg_in_child(args, flag, key, deadline):
+    """An extra leg in a child process (started, never exec'ed, from this GPU-holding process), killed by PID at the deadline."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), flag, "--dtype", args.dtype]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    try:
+        so, se = proc.communicate(timeout=deadline)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        return {"error": "%s leg did not finish within %d s" % (key, deadline)}
+    for ln in so.splitlines():
+        if ln.startswith("{") and ('"%s"' % key) in ln:
+            return json.loads(ln)[key]
+    return {"error": "%s child exited with code %s: %s" % (key, proc.returncode, se[-400:])}
+
+
 def self_launch(args, argv):
     """`python bench.py --gpus N` with no launcher: start N ranks as a child `torch.distributed.run` job and relay its output.
     This parent never initialises the GPU (no torch.cuda call happens before this point), and nothing is exec'ed from a
@@ -236,7 +397,7 @@ def run_sweep(args, rank, world, dev, host_only):
                 meta, base = make_run_inputs(seed, dev, args.base_batch)
                 shard = sweep.RowShard(group) if group is not None else None
                 torch.cuda.synchronize()
-                t_run = time.perf_counter()
+                t_run = time.perf_counter()                     # (runs-only clock: starts behind the group broadcast and the set-up)
                 r = IncrementalRunner(net, meta, base, opt, None, None, None, args.epochs_per_sync or args.epochs, False,
                                       verbose=False, row_shard=shard).start()
                 for idx in range(r.iter_num):
@@ -258,8 +419,11 @@ def run_sweep(args, rank, world, dev, host_only):
     # init on the host, 10 BN warm-up batches) and inputs is kept as `seconds_with_setup`.
     dt_run = dt if host_only else sweep.max_over_ranks(busy, dev)
     seen = sorted(x for r in sweep.gather_results(done) for x in r)
-    return {"workload": "%d seeds x 8 sessions (BASELINE.json configs[3])" % args.sweep_seeds, "value": args.sweep_seeds * 8 / dt_run,
-            "unit": "episodes/s", "seconds": dt_run, "seconds_with_setup": dt, "scaling": "strong", "seeds_done": seen,
+    # `value` is on the WALL clock of the whole leg (barrier to barrier: per-seed set-up, the group broadcasts and the runs), the
+    # same basis at every rank count, so that value(N) / value(1) compares like with like; the runs-only figure is beside it
+    return {"workload": "%d seeds x 8 sessions (BASELINE.json configs[3])" % args.sweep_seeds, "value": args.sweep_seeds * 8 / dt,
+            "unit": "episodes/s", "seconds": dt, "value_runs_only": args.sweep_seeds * 8 / dt_run, "seconds_runs_only": dt_run,
+            "scaling": "strong", "seeds_done": seen,
             "plan": [[[sd, len(rk)] for sd, rk in rnd] for rnd in plan],
             "n_ranks_seen": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
             "model_speedup_over_1_gpu": sweep.sweep_speedup(args.sweep_seeds, world)}
@@ -299,6 +463,8 @@ def main():
                     help="also run the S-seed x 8-session sweep (configs[3]) after the timed region; 0 = skip")
     ap.add_argument("--sweep-deadline", type=int, default=900, help="seconds after which the sweep leg is abandoned")
     ap.add_argument("--sweep-only", action="store_true", help="(internal) run only the one-rank sweep leg and print {\"sweep\": ...}")
+    ap.add_argument("--pretrain-only", action="store_true", help="(internal) run only the pretraining-step leg and print {\"pretrain\": ...}")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the pretraining-step, route-A and sweep-model legs")
     ap.add_argument("--reuse-features", action="store_true",
                     help="NOT the headline: opt-in frozen-feature reuse (reported in DESIGN.md only)")
     ap.add_argument("--selftest-one-gpu", action="store_true",
@@ -344,6 +510,10 @@ def main():
         assert world == 1
         print(json.dumps({"sweep": run_sweep(args, 0, 1, dev, False)}), flush=True)
         return
+    if args.pretrain_only:
+        assert world == 1
+        print(json.dumps({"pretrain": pretrain_leg(args)}), flush=True)
+        return
     from subreg_hip.incremental import IncrementalRunner
     seed = rank + 1                                           # one seed per GPU, like the SLURM array
     net, opt = make_net(args, seed, dev)
@@ -369,11 +539,15 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     runners = []
+    session_mix, session_sec = [0] * 8, {}
     for i in range(args.steps):
         if i % 8 == 0:
             r = new_runner(True)
             runners.append(r)
-        r.run_session(i % 8)
+        ts = time.perf_counter()
+        r.run_session(i % 8)                                  # (returns with the session's results on the host: synchronised)
+        session_sec.setdefault(i % 8, []).append(time.perf_counter() - ts)
+        session_mix[i % 8] += 1
     torch.cuda.synchronize()
     sweep.barrier()
     torch.cuda.synchronize()
@@ -387,6 +561,11 @@ def main():
     tpath = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(tpath):
         traffic = (json.load(open(tpath)).get(args.dtype) or {}).get("bytes_per_image")   # HBM bytes per image forwarded
+    # `value` = K episodes / time, as the contract says; step i is session i mod 8, so a K that is not a multiple of 8 over-weights
+    # the cheap early sessions (session s forwards 125 (s + 2) images per epoch).  The session-balanced figure beside it is
+    # images/s over the mean image count of the 8 sessions of a run (incl. each run's initial base evaluation): it does not move
+    # with K, and equals `value` when K is a multiple of 8.
+    mean_imgs = float(np.mean([images_per_episode(s_, args.epochs, args.base_batch) for s_ in range(8)])) + args.base_batch / 8.0
     out = {
         "metric": "incremental episodes/sec, ResNet18 miniImageNet 5w5s", "value": args.steps * world / dt,
         "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -394,14 +573,17 @@ def main():
         "dtype": args.dtype, "data": "synthetic" if not args.selftest_one_gpu else "synthetic (SELF-TEST: all ranks share one GPU; not a measurement)",
         "config": {"workload": "8-session FSCIL, subspace regularizer, -M (BASELINE.json configs[1]); one seed per GPU",
                    "epochs_per_episode": args.epochs, "images_per_gpu": imgs, "base_batch": args.base_batch,
+                   "session_mix": session_mix, "images_per_episode_session_balanced": mean_imgs,
                    "feature_reuse": bool(args.reuse_features), "backbone": "ResNet18 (RFS ResNet-12 family, 8.1219 GFLOP/img)",
                    "n_ranks_seen": dist.get_world_size() if world > 1 else 1},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                      "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": traffic,
                      "kernel": "conv_fwd_kernel family over %d backbone forwards (%.1f ms each)" % (n_fwd, fwd_ms / max(n_fwd, 1))},
         "images_per_s": imgs * world / dt,
+        "episodes_per_s_balanced": imgs * world / dt / mean_imgs,   # session-balanced: invariant in --steps
         "epochs_per_s": args.steps * world * args.epochs / dt,     # fine-tune epochs (forward + step + validation) per second, SURVEY.md 8d
     }
+    session_seconds = {s_: float(np.mean(v)) for s_, v in session_sec.items()}
     del runners, r
     if rank == 0:                                              # the headline is on record before any extra leg starts
         print("[bench.py headline, extra legs follow] " + json.dumps(out), file=sys.stderr, flush=True)
@@ -409,6 +591,19 @@ def main():
     #      one rank  -> it runs in a CHILD process (its own HIP context) that is killed at the deadline; a crash or hang there
     #                   is reported under "sweep", the parent prints the line regardless;
     #      N ranks   -> it needs this process group, so it runs here under a deadline thread that prints the line without it.
+    if world == 1 and not args.no_extra_legs:
+        # route A (the reference's unchanged loop statements over the drop-in modules) and the measured inputs of the sweep model:
+        # in this process (they need the backbone), each wrapped - nothing here can cost the line
+        try:
+            out["route_a"] = route_a(args, net, opt, meta, dev)
+            if 7 in session_seconds:
+                out["route_a"]["fused_loop_epochs_per_s_same_shape"] = args.epochs / (session_seconds[7] - 0.0)
+        except Exception as exc:                                   # noqa: BLE001
+            out["route_a"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        try:
+            out["sweep_model"] = sweep_model(args, net, dev, session_seconds if len(session_seconds) == 8 else None)
+        except Exception as exc:                                   # noqa: BLE001
+            out["sweep_model"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if args.sweep_seeds > 0 and world == 1:
         del net, meta, base
         import gc
@@ -416,6 +611,8 @@ def main():
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         out["sweep"] = sweep_in_child(args)
+        if "sweep_model" in out and "speedup_at_8_gpus" in out["sweep_model"] and isinstance(out["sweep"], dict):
+            out["sweep"]["model_speedup_at_8_gpus_measured_inputs"] = out["sweep_model"]["speedup_at_8_gpus"]
     elif args.sweep_seeds > 0:
         import threading
 
@@ -432,6 +629,12 @@ def main():
         except Exception as exc:                                   # noqa: BLE001 - reported in the line, never silently dropped
             out["sweep"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         timer.cancel()
+    if rank == 0 and world == 1 and not args.no_extra_legs:
+        # BASELINE.json configs[2] (pretraining step) in a child process of its own, like the one-rank sweep leg
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["pretrain"] = leg_in_child(args, "--pretrain-only", "pretrain", 300)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -125,3 +125,12 @@ def sweep_speedup(n_seeds, world, dp_efficiency=0.9):
     for rnd in plan_sweep(range(n_seeds), world):
         t += max(1.0 / (1.0 + (len(ranks) - 1) * dp_efficiency) for _seed, ranks in rnd)
     return n_seeds / t
+
+
+def sweep_speedup_measured(n_seeds, world, seed_ms_by_group_size):
+    """Speed-up over one GPU of `plan_sweep` from MEASURED seed-run times: seed_ms_by_group_size[g] = time of one seed's 8-session
+    run when g ranks share it (bench.py::sweep_model builds it from forwards timed at the per-rank batch sizes)."""
+    t = 0.0
+    for rnd in plan_sweep(range(n_seeds), world):
+        t += max(float(seed_ms_by_group_size[len(ranks)]) for _seed, ranks in rnd)
+    return n_seeds * float(seed_ms_by_group_size[1]) / t

@@ -263,6 +263,48 @@ def test_train_step_against_reference_autograd(hw, dtype):
              g[key + ".after_step.layer1.0.conv1.weight"], 1e-3, 1e-3)    # lr 0.05 x the kink-event gradient perturbation
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_train_step_351_base_classes_against_oracle(dtype):
+    """BASELINE.json configs[4], pretraining leg: the train_supervised.py step with tieredImageNet's 351 base classes
+    (train_supervised.py:94) - train-mode forward, CE over 351 logits, full backward.  The reference cannot run tieredImageNet
+    (train_supervised.py:74 passes unknown kwargs to its dataset), so parity is against oracle/torch_ref.py::train_step_grads
+    (pinned at 60 classes by the reference's own autograd golden, tests/test_oracle_golden.py) with a 351-row classifier."""
+    from oracle import torch_ref
+    from subreg_hip.resnet_language import create_model
+    from test_hip_loop import make_opt
+    NC, B, hw = 351, 6, 32
+    sd = syn.make_state_dict(81, n_cls=NC)
+    net = create_model("resnet18", NC, make_opt(hip_dtype=dtype))
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    net = net.cuda()
+    net.mask_source = MaskSource(84)
+    x = syn.make_images(82, B, hw)
+    labels = np.random.RandomState(83).randint(0, NC, B).astype(np.int64)
+    labels[0], labels[1] = 0, NC - 1                                 # first and last classifier row
+    net.train()
+    logits = net(torch.from_numpy(x).cuda())
+    assert logits.shape == (B, NC)
+    loss = torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(labels).cuda())
+    loss.backward()
+    f32 = dtype == "f32"
+    loss_o, go = torch_ref.train_step_grads(sd, x, labels, MaskSource(84), bf16=not f32)
+    _cmp("loss", loss.item(), loss_o, 2e-4 if f32 else 2e-2, 2e-4 if f32 else 5e-3)
+    grads = {n: p.grad.detach().cpu().numpy() for n, p in net.named_parameters()}
+    assert grads["classifier.weight"].shape == (NC, 640)
+    for name, got in grads.items():
+        a, b = got.astype(np.float64).ravel(), go[name].astype(np.float64).ravel()
+        l2 = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+        if f32:
+            assert l2 < 1.5e-2, ("l2", name, l2)                     # (the LeakyReLU-kink note of the 60-class test applies)
+        else:
+            cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-30))
+            weight_like = ".conv" in name or "downsample.0" in name or name.startswith("classifier")
+            assert cos > (0.91 if weight_like else 0.87) and l2 < (0.45 if weight_like else 0.55), ("bf16 oracle", name, cos, l2)
+    if f32:
+        _cmp("grad classifier", grads["classifier.weight"], go["classifier.weight"],
+             1e-3 * float(np.abs(go["classifier.weight"]).max()), 2e-3)
+
+
 def test_softmax_ce_kernel_matches_torch_and_reference_accuracy():
     """nn.CrossEntropyLoss() (mean) + eval/util.py:26-40 top-1/top-5 in one launch, and its autograd."""
     from subreg_hip import functional as HF

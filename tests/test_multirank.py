@@ -207,3 +207,19 @@ def test_row_sharded_sweep_path_two_ranks_on_device():
     assert "single-process run: True" in p.stdout
     done, total = [int(x) for x in p.stdout.split("rank 0:")[1].split(")")[0].replace("of", " ").split()]
     assert 0 < done < total                                    # rank 0 really forwarded only its share of the images
+
+
+@pytest.mark.gpu
+def test_pretrain_gradient_sync_two_ranks_on_device():
+    """BASELINE.json configs[4], 'data-parallel RCCL allreduce': pretrain.GradientSync with TWO processes on the device
+    (tools/dp_pretrain_check.py) - uneven shards 4 + 3 of a global batch, loss pre-scaled by n_local / n_global, the staged
+    backward with one asynchronous SUM all-reduce per stage, fused SGD - must equal the single-process emulation of what
+    nn.DataParallel does (train_supervised.py:141-142) up to the measured run-to-run noise of the float atomics.  One GPU per
+    box: both ranks share cuda:0 over gloo; with one GPU per rank the same code all-reduces over RCCL."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(repo, "tools", "dp_pretrain_check.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "EQUIVALENT" in p.stdout and "MISMATCH" not in p.stdout
