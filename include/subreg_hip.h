@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUBREG_ABI_VERSION 9
+#define SUBREG_ABI_VERSION 10
 
 #define SUBREG_OK 0
 #define SUBREG_EINVAL (-1)       /* bad argument (null pointer, shape not supported by contract) */
@@ -165,6 +165,10 @@ typedef struct subreg_backbone_desc {
 } subreg_backbone_desc;
 
 long long subreg_backbone_ws_bytes(const subreg_backbone_desc* d, int B, int H, int W);
+/* 1 if subreg_backbone_forward of (B, H, W) images in this mode reads the im2col buffer `col` (it must then be non-NULL), 0 if
+ * layer 1 reads the fp32 image itself.  The one predicate the library and its callers share: it needs both the shape support of
+ * subreg_layer1_direct_supported and a first block of the layer1.0 form (ResNet.forward, models/resnet_language.py:170-192). */
+int subreg_backbone_needs_col(const subreg_backbone_desc* d, int B, int H, int W, int train);
 long long subreg_backbone_stats_floats(const subreg_backbone_desc* d, int B, int H, int W);
 /* (re)pack every conv weight: the raw copy, and the copy with the eval-mode BN scale folded in; writes shift[].
  * Call after the weights or the BN statistics changed. */
@@ -210,6 +214,11 @@ int subreg_avgpool_bwd(const float* dfeat, void* dx, int B, int H, int W, int C,
 int subreg_sgd_momentum_multi(float* const* params, float* const* momentum_bufs, const float* grad_base,
                               const long long* grad_offsets, const long long* ends, int n, long long total, float lr,
                               float momentum, float weight_decay, int first_step, void* stream);
+/* torch.optim.Adam step (train_supervised.py:128-131 with --adam: Adam(lr, weight_decay 5e-4), betas (0.9, 0.999), eps 1e-8;
+ * eval/util.py:92-97 builds the same for the incremental loop): L2 weight decay added to the gradient, bias corrections
+ * 1 - beta^step (step >= 1, counted by the caller); exp_avg / exp_avg_sq are the caller's state tensors, zero before step 1 */
+int subreg_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
+                float beta2, float eps, float weight_decay, int step, void* stream);
 int subreg_sgd_momentum(float* param, const float* grad, float* momentum_buf, long long n, float lr, float momentum,
                         float weight_decay, int first_step, void* stream);
 

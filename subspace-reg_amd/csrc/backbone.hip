@@ -46,6 +46,17 @@ int conv_train(const subreg_backbone_desc* d, const subreg_conv_desc& c, const v
 
 extern "C" int subreg_abi_version(void) { return SUBREG_ABI_VERSION; }
 
+// Does a forward of this backbone read the first layer's im2col buffer (desc.col)?  ONE predicate for the library and its callers:
+// 0 only for eval-mode forwards whose layer 1 reads the fp32 NCHW image itself (conv_first.hip + the image-fed kernels of
+// conv64_resident.hip), which needs the (B, H, W, dtype) support of subreg_layer1_direct_supported AND a first block of the
+// layer1.0 shape (stride 2, a 1x1 downsample branch, 64 output channels).
+extern "C" int subreg_backbone_needs_col(const subreg_backbone_desc* d, int B, int H, int W, int train) {
+    if (!d || d->n_blocks < 1 || !d->blocks) return 1;
+    const bool direct = !train && d->blocks[0].stride == 2 && d->blocks[0].down.w && d->blocks[0].conv1.cout == 64 &&
+                        subreg_layer1_direct_supported(B, H, W, d->dtype);
+    return direct ? 0 : 1;
+}
+
 extern "C" const char* subreg_strerror(int code) {
     switch (code) {
         case SUBREG_OK: return "ok";
@@ -120,8 +131,7 @@ extern "C" int subreg_backbone_forward(const subreg_backbone_desc* d, const floa
     const int dt = d->dtype;
     // eval mode, bf16, 84x84-class images: layer 1 reads the fp32 image itself (conv_first.hip; conv3's shortcut inside
     // conv64_resident.hip) - no im2col buffer is written or read.  Otherwise conv1 and the shortcut are K = 32 GEMMs over it.
-    const bool direct = !train && d->blocks[0].stride == 2 && d->blocks[0].down.w && d->blocks[0].conv1.cout == 64 &&
-                        subreg_layer1_direct_supported(B, H, W, dt);
+    const bool direct = !subreg_backbone_needs_col(d, B, H, W, train ? 1 : 0);
     SUBREG_CHECK_ARG(direct || d->col);
 
     if (!direct) TRY(subreg_pack_input(x_nchw, d->col, B, H, W, dt, stream));

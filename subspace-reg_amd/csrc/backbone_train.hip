@@ -163,6 +163,9 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
         *draw_out = drb[k];
         return SUBREG_OK;
     };
+    // The blocks, as a callable: whatever it returns, the side stream is joined before this call does (the header's promise;
+    // an error return between a fork and its join would otherwise leave side-stream work nobody waits for)
+    auto run_blocks = [&]() -> int {
     for (int i = last_block; i >= first_block; --i) {
         const int gi = (nb - 1 - i) & 1;
         const subreg_block_desc& b = d->blocks[i];
@@ -183,6 +186,10 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
                                   b.down.w ? tb.down.bscale : nullptr, b.down.w ? tb.down.bshift : nullptr, t->dv, B, bh, bw, C,
                                   b.stride == 2, dt, stream));
         // shortcut branch (BN backward -> dr2, dW): needs only dv; all of it on the side stream
+        // INVARIANT the two-stream schedule rests on: the shortcut convolution is 1x1, and the 1x1 path of subreg_conv_wgrad never
+        // touches the dW scratch (t->pad_x / t->pad_dy) that the 3x3 dW chains of the OTHER stream are using at the same time; its
+        // own dW scratch (gw of `down`) is a separate buffer (train.py).  A 3x3 shortcut would race: refused here.
+        SUBREG_CHECK_ARG(!b.down.w || b.down.ksize_raw == 1);
         const bool down_side = fork && i >= down_on_side_from();
         if (b.down.w && down_side) {
             TRY(f.main_to_side(EV_FORK));
@@ -218,8 +225,12 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
                                 bw, b.conv1.cout, b.conv1.cin, b.conv1.ksize_raw, 0, dt, stream));
         }
     }
+    return SUBREG_OK;
+    };
+    const int rc = run_blocks();
     // join: every gradient of these blocks is complete in main-stream order when this call's work is
-    return join();
+    const int rj = join();
+    return rc != SUBREG_OK ? rc : rj;
 }
 
 extern "C" int subreg_event_create(void** event) {

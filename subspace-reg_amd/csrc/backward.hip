@@ -12,6 +12,8 @@
 #include "conv_index.h"
 #include <stdlib.h>
 
+#include <math.h>
+
 #include "subreg_common.h"
 
 namespace subreg {
@@ -1059,6 +1061,20 @@ __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restri
     p[i] -= lr * b;
 }
 
+// torch.optim.Adam (amsgrad off, L2 weight decay added to the gradient: train_supervised.py:128-131 builds Adam(lr, weight_decay=5e-4)):
+// g' = g + wd p; m = b1 m + (1 - b1) g'; v = b2 v + (1 - b2) g'^2; p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                            float lr, float b1, float b2, float eps, float wd, float step_size, float inv_sqrt_bc2) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float d = g[i] + wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * d;
+    const float vi = b2 * v[i] + (1.f - b2) * d * d;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+}
+
 // n tensors in one launch: thread i finds its tensor by binary search in the prefix sums
 __global__ void sgd_momentum_multi_kernel(float* const* __restrict__ params, float* const* __restrict__ bufs,
                                           const float* __restrict__ gbase, const long long* __restrict__ goff,
@@ -1350,6 +1366,16 @@ extern "C" int subreg_sgd_momentum_multi(float* const* params, float* const* mom
     SUBREG_CHECK_ARG(params && momentum_bufs && grad_base && grad_offsets && ends && n > 0 && total > 0);
     hipLaunchKernelGGL(sgd_momentum_multi_kernel, bw_blocks((size_t)total), BW_THREADS, 0, (hipStream_t)stream, params, momentum_bufs,
                        grad_base, grad_offsets, ends, n, lr, momentum, weight_decay, first_step);
+    return launch_status();
+}
+
+extern "C" int subreg_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int step, void* stream) {
+    SUBREG_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1);
+    // bias corrections on the host in double, as torch does (1 - beta^t)
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, bw_blocks((size_t)n), BW_THREADS, 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (size_t)n,
+                       lr, beta1, beta2, eps, weight_decay, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)));
     return launch_status();
 }
 

@@ -40,6 +40,9 @@
 #ifndef SUBREG_BF16_MFMA16
 #define SUBREG_BF16_MFMA16 1     // 1: v_mfma_f32_16x16x32_bf16 where mfma_tile() says so, 0: v_mfma_f32_32x32x16_bf16 everywhere
 #endif
+#ifndef SUBREG_EARLY_READS
+#define SUBREG_EARLY_READS 1     // 1: a step's first fragment reads are issued before its DMAs (see EARLY in the kernel)
+#endif
 #ifndef SUBREG_STAGING_ROLES
 #define SUBREG_STAGING_ROLES 0   // 1: in 3x3 launches the waves take ONE staging role each (3 weight waves + 1 patch wave of 4): measured
                                  // 1-17 % SLOWER (profiles/r04_ab_staging_roles.txt): a step is as long as the wave with the most DMAs
@@ -258,7 +261,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     constexpr int NPW = ROLES ? (NW >= 4 ? NW / 4 : 1) : NW;          // waves that stage patch pieces inside the loop
     constexpr int NWW = ROLES ? NW - NPW : NW;                        // waves that stage weight pieces
     const bool has_w = !ROLES || wid < NWW, has_p = !ROLES || wid >= NWW;          // wave-uniform
-    const int ww = has_w ? wid : 0, pw = ROLES ? (has_p ? wid - NWW : 0) : wid;
+    // (without roles the in-loop patch pieces are dealt from the LAST wave down: the weight pieces are dealt from the first wave up,
+    // TN / RPP = 10 of them over 4 waves is 3, 3, 2, 2, so a partial round of patch pieces lands on the waves with fewer weight DMAs)
+    const int ww = has_w ? wid : 0, pw = ROLES ? (has_p ? wid - NWW : 0) : NW - 1 - wid;
     constexpr int WPT = TN / RPP;                                      // weight pieces per tap
     constexpr int PWW = (WPT + NWW - 1) / NWW;                         // ... per weight wave (the last one only on some waves)
     const bool w_last_ok = (PWW - 1) * NWW + ww < WPT;
@@ -366,6 +371,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     constexpr int KX = 16 * LG;                               // address XOR per k-step
     constexpr bool SWP = NI * NJ * 16 + 2 * (MI + MJ) * 4 + 40 <= 200;
     static_assert(WK == 1 || !SWP, "the k-step split is implemented on the ring-pipelined path");
+    // EARLY: the step's first LDS reads (k-step 0: the A fragments and the first two B fragments) are issued BEFORE the step's DMAs,
+    // right behind the barrier that made them readable - their latency then runs under the DMA issue instead of in front of the
+    // step's first MFMA.  (Ring-pipelined path, one wave per tile.)
+    // Measured (profiles/r04_ab_early_reads.txt): -1...-3 % on the 32x32x16 / 256-row tiles, +1 % on the 16x16x32 / 128-row tiles
+    // (three workgroups per CU: another wave's MFMAs already cover that latency) - so only where TR == 32.
+    constexpr bool EARLY = SUBREG_EARLY_READS && !SWP && WK == 1 && TR == 32 && SUBREG_DIAG != 2;
+    uint4 e_fa[MI], e_fb[2];
+    auto early_reads = [&](auto ph1_tag, int aoff, int boff, int tg) {
+        constexpr bool PH1 = decltype(ph1_tag)::value;
+        const int tap = PH1 ? CENTER : tg * TPS;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) e_fa[i] = *reinterpret_cast<const uint4*>(smem + aoff + aaddr(i, tap));
+        e_fb[0] = *reinterpret_cast<const uint4*>(smem + boff + baddr0);
+        if (MJ > 1) e_fb[1] = *reinterpret_cast<const uint4*>(smem + boff + (TR * ROWB) + baddr0);
+    };
     auto mma_block = [&](auto ph1_tag, int aoff, int boff, int tg, int step) {
         constexpr bool PH1 = decltype(ph1_tag)::value;
         constexpr int NKE = PH1 ? KSTEPS : NK;                // k-steps of this step
@@ -413,12 +433,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
                 const int s = kk % KSTEPS;
                 uint4 fa[MI], fb[3];
                 auto rd_a = [&](int i) { fa[i] = *reinterpret_cast<const uint4*>(smem + aoff + (aaddr(i, a_tap(kk)) ^ (KX * s))); };
-                rd_a(0);
-                fb[0] = load_b1(kk, 0);
+                if (EARLY && kk == 0) {
 #pragma unroll
-                for (int i = 1; i < MI; ++i) rd_a(i);
-                if (MJ > 1) fb[1] = load_b1(kk, 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, MI + (MJ > 1 ? 2 : 1), 0);
+                    for (int i = 0; i < MI; ++i) fa[i] = e_fa[i];
+                    fb[0] = e_fb[0];
+                    if (MJ > 1) fb[1] = e_fb[1];
+                } else {
+                    rd_a(0);
+                    fb[0] = load_b1(kk, 0);
+#pragma unroll
+                    for (int i = 1; i < MI; ++i) rd_a(i);
+                    if (MJ > 1) fb[1] = load_b1(kk, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, MI + (MJ > 1 ? 2 : 1), 0);
+                }
 #pragma unroll
                 for (int j = 0; j < MJ; ++j) {
                     if (j + 2 < MJ) {
@@ -464,6 +491,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
             if (STAMPS) tq = __builtin_amdgcn_s_memtime();
             const int wb = (step + 1) % NWB;
             int n_patch = 0;
+            if constexpr (EARLY) early_reads(std::false_type{}, aoff, (step % NWB) * BBUF, tg);
             if (SUBREG_DIAG != 1) {
                 if (has_w) {                                          // the next step's weights
                     if (tg < NG - 1) {
@@ -521,6 +549,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
             const bool more = c + 1 < c_end;
             const int aoff = (c & 1) * ABUF;
             if (STAMPS) tq = __builtin_amdgcn_s_memtime();
+            if constexpr (EARLY) early_reads(std::true_type{}, aoff, (step % NWB) * BBUF, 0);
             if (SUBREG_DIAG != 1 && more) {
                 if (has_w) stage_weights(a.w2, (unsigned)(c + 1 - nch0) * wtile, 0, 1, (step + 1) % NWB);
                 const unsigned puoff = porg1 + (unsigned)(c + 1 - nch0) * (32 * ELEM);

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SUBREG_LIB") or os.path.join(_HERE, "libsubreg_hip.so
 F32, BF16 = 0, 1
 CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
 FWD_TRAIN = 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_QUERY_SETS = 32                          # SUBREG_MAX_QUERY_SETS
 
 c_void_p, c_int, c_float, c_longlong = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -109,6 +109,7 @@ SIGNATURES = {
     "subreg_block_tail_bwd": (_I, [_P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "subreg_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_sgd_momentum": (_I, [_P, _P, _P, _L, _F, _F, _F, _I, _P]),
+    "subreg_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
     "subreg_backbone_forward_stash": (_I, [C.POINTER(BackboneDesc), C.POINTER(TrainDesc), _P, _I, _I, _I, _P, _P]),
     "subreg_conv_splitk_floats": (_L, [_I, _I, _I, _I, _I, _I, _I]),
     "subreg_event_create": (_I, [C.POINTER(c_void_p)]),
@@ -124,6 +125,7 @@ SIGNATURES = {
     "subreg_dropblock_mask": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "subreg_avgpool": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_backbone_ws_bytes": (_L, [C.POINTER(BackboneDesc), _I, _I, _I]),
+    "subreg_backbone_needs_col": (_I, [C.POINTER(BackboneDesc), _I, _I, _I, _I]),
     "subreg_backbone_stats_floats": (_L, [C.POINTER(BackboneDesc), _I, _I, _I]),
     "subreg_backbone_fold": (_I, [C.POINTER(BackboneDesc), _P]),
     "subreg_backbone_pack_raw": (_I, [C.POINTER(BackboneDesc), _P]),

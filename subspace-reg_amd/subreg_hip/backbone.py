@@ -132,8 +132,8 @@ class HipBackbone:
     def _col_elems(self, B, H, W, need_col):
         """Elements of the first layer's im2col buffer this forward needs: none when layer 1 reads the fp32 image itself
         (eval mode, bf16, 84x84-class images: csrc/conv_first.hip + the image-fed shortcut of csrc/conv64_resident.hip)."""
-        if not need_col and self.lib.subreg_layer1_direct_supported(B, H, W, self.dtype):
-            return 0
+        if not need_col and not self.lib.subreg_backbone_needs_col(C.byref(self._desc), B, H, W, 0):
+            return 0            # (the library's own predicate: shape support AND a first block of the layer1.0 form)
         return B * H * W * 32
 
     def _ensure_workspace(self, B, H, W, need_col=True):

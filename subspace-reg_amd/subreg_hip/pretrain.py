@@ -20,7 +20,7 @@ import torch
 
 from . import checkpoint as ck
 from . import functional as HF
-from .train import SGD
+from .train import SGD, Adam
 
 
 class AverageMeter(object):
@@ -218,9 +218,10 @@ def validate(val_loader, model, criterion, opt, log=print):
 def fit(model, opt, train_loader, val_loader=None, lang_puller=None, rank=0, world=1, group=None, log=print):
     """train_supervised.py:122-202 without the tensorboard logger: optimizer, LR schedule, epochs, periodic and final
     checkpoints (rank 0 writes).  Returns the per-epoch history."""
-    if getattr(opt, "adam", False):
-        raise NotImplementedError("the HIP train step implements SGD(momentum, weight_decay) (train_supervised.py:133-136)")
-    optimizer = SGD(model.parameters(), lr=opt.learning_rate, momentum=opt.momentum, weight_decay=opt.weight_decay)
+    if getattr(opt, "adam", False):                                                              # :128-131
+        optimizer = Adam(model.parameters(), lr=opt.learning_rate, weight_decay=0.0005)
+    else:                                                                                        # :133-136
+        optimizer = SGD(model.parameters(), lr=opt.learning_rate, momentum=opt.momentum, weight_decay=opt.weight_decay)
     sync = None
     if world > 1:
         from . import sweep

@@ -223,6 +223,14 @@ class BackboneTrainFn(torch.autograd.Function):
             if p.requires_grad and p.grad is not None:
                 g = p.grad
                 old[n] = g.clone() if lo_ptr <= g.data_ptr() < hi_ptr else g
+        if old and not getattr(hb, "_warned_accumulate", False):
+            # correct, but off the fast path: the sums below are fresh tensors, not views of the flat buffer, so SGD.step() takes
+            # its per-tensor path (no fused update + re-pack launch) for this step - say so once
+            import warnings
+            hb._warned_accumulate = True
+            warnings.warn("subreg_hip: backward() found existing .grad tensors and accumulates into copies (gradient accumulation / "
+                          "zero_grad(set_to_none=False)); the fused SGD step needs zero_grad() with set_to_none=True before every "
+                          "backward and is bypassed for this step", RuntimeWarning, stacklevel=2)
         if old and hook is not None:
             raise RuntimeError("subreg_hip: gradient accumulation over several backward passes is not supported together with the "
                                "data-parallel stage hook (the flat gradient buffer is being all-reduced in place): call "
@@ -351,3 +359,36 @@ class SGD:
                                                      _lib.ptr(cache["offs"]), _lib.ptr(cache["ends"]), len(items), cache["total"],
                                                      self.lr, self.momentum, self.weight_decay, int(first), _lib.stream_ptr()),
                        "sgd_momentum_multi")
+
+
+class Adam:
+    """torch.optim.Adam(lr, weight_decay) semantics (train_supervised.py:128-131, `--adam`) on the HIP kernel: one launch per
+    parameter tensor (the option is outside every script's path; the conv weights' packed copies are rebuilt by the next
+    train-mode forward, as after any update the fused SGD step did not make)."""
+
+    def __init__(self, params, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        self.weight_decay, self.betas, self.eps = weight_decay, betas, eps
+        self.param_groups = [{"params": self.params, "lr": lr}]      # adjust_learning_rate (util.py:45-51) writes param_groups[i]['lr']
+        self.state = [None] * len(self.params)                       # (exp_avg, exp_avg_sq, step)
+
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def step(self):
+        lib = _lib.load()
+        for i, p in enumerate(self.params):
+            if p.grad is None:
+                continue
+            if self.state[i] is None:
+                self.state[i] = [torch.zeros_like(p.data), torch.zeros_like(p.data), 0]
+            st = self.state[i]
+            st[2] += 1
+            g = p.grad.contiguous().float()
+            _lib.check(lib.subreg_adam(_lib.ptr(p.data), _lib.ptr(g), _lib.ptr(st[0]), _lib.ptr(st[1]), p.numel(), self.lr,
+                                       self.betas[0], self.betas[1], self.eps, self.weight_decay, st[2], _lib.stream_ptr()), "adam")

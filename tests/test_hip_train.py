@@ -571,3 +571,25 @@ def test_bf16_backward_from_its_own_forward_stash(hw):
         worst = max(worst, (name, l2), key=lambda t: t[1])
         assert l2 < 5e-2, ("bf16 backward vs the oracle on the same stash", name, l2)
     print("worst tensor:", worst)
+
+
+def test_adam_step_matches_torch_optim_adam():
+    """train_supervised.py:128-131 (`--adam`): Adam(lr, weight_decay 5e-4) - the HIP update against torch.optim.Adam on CPU over
+    four steps (bias corrections, L2 decay added to the gradient), tensors of the sizes a backbone has."""
+    from subreg_hip.train import Adam
+    rs = np.random.RandomState(5)
+    shapes = [(64, 3, 3, 3), (160,), (351, 640), (320, 160, 1, 1)]
+    ref = [torch.nn.Parameter(torch.from_numpy((rs.standard_normal(sh) * 0.1).astype(np.float32))) for sh in shapes]
+    dut = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref]
+    o_ref = torch.optim.Adam(ref, lr=1e-3, weight_decay=0.0005)
+    o_dut = Adam(dut, lr=1e-3, weight_decay=0.0005)
+    for step in range(4):
+        for pr, pd in zip(ref, dut):
+            g = (rs.standard_normal(tuple(pr.shape)) * (0.5 if step % 2 else 5e-4)).astype(np.float32)   # large and tiny gradients
+            pr.grad = torch.from_numpy(g)
+            pd.grad = torch.from_numpy(g).cuda()
+        o_ref.step()
+        o_dut.step()
+    torch.cuda.synchronize()
+    for k, (pr, pd) in enumerate(zip(ref, dut)):
+        _cmp("adam tensor %d" % k, pd.detach().cpu().numpy(), pr.detach().numpy(), 2e-7, 2e-6)

@@ -2,8 +2,10 @@
 """Achieved HBM bandwidth of the element-wise / BatchNorm / packing kernels (the part of the path whose roofline is HBM, not
 MFMA), through the C ABI, at the shapes the pretraining step (B = 64, train_supervised.py:205-268) and an evaluation forward
 use them on.  One line per (kernel call, layer shape): time from HIP events on the launch stream, ALGORITHMIC bytes (every
-operand read once, every result written once) and the fraction of the streaming rates measured on the same box by
-tools/probes/stream_bw.hip (read 6.3, write 4.7, copy 4.8 TB/s; spec 8).
+operand read once, every result written once) and the fraction of the HBM SPEC rate (8 TB/s, MI355X_MICROARCH.md); the box's own
+streaming rates (tools/probes/stream_bw.hip: read ~6.3, write ~4.7, copy ~4.8 TB/s) are the practical ceiling of a read + write
+pass.  A row whose tensors fit the 256 MiB Infinity Cache between two launches of the timing loop is marked `L3`: its bytes
+never reach HBM, so its rate is NOT an HBM figure (such rows can read above the copy rate).
 
   python tools/bench_elementwise.py [--batch 64] [--iters 30]
 """
@@ -22,7 +24,8 @@ from subreg_hip import _lib  # noqa: E402
 # (layer, H = W of the block's input, C, pooled)
 BLOCKS = [("layer1.0", 84, 64, True), ("layer2.0", 42, 160, True), ("layer3.0", 21, 320, True), ("layer3.1", 10, 320, False),
           ("layer4.0", 10, 640, True), ("layer4.1", 5, 640, False)]
-MIX = 4.8     # TB/s a read + write stream sustains (stream_bw copy)
+SPEC = 8.0    # TB/s, HBM3E spec (the roofline's peak); a read + write stream sustains ~4.8 on these boxes (stream_bw copy)
+L3_BYTES = 256 * 2 ** 20
 
 
 def main():
@@ -53,7 +56,8 @@ def main():
         k = tot.setdefault(kind, [0.0, 0.0])
         k[0] += us
         k[1] += nbytes
-        print("%-34s %-9s %8.1f us  %8.1f MB  %5.2f TB/s  %3.0f%% of %.1f" % (kind, name, us, nbytes * 1e-6, tbs, 100 * tbs / MIX, MIX))
+        print("%-34s %-9s %8.1f us  %8.1f MB  %5.2f TB/s  %3.0f%% of %.0f (spec)%s" %
+              (kind, name, us, nbytes * 1e-6, tbs, 100 * tbs / SPEC, SPEC, "  L3" if nbytes < L3_BYTES else ""))
 
     print("batch %d, bf16; bytes are algorithmic (operands read once, results written once)" % B)
     for name, H, Cc, pool in BLOCKS:

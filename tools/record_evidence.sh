@@ -4,7 +4,8 @@
 # Then copy what should be judged into profiles/ as <tag>_* (see profiles/README.md).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/evidence
+FINAL=$R/gpurun_out/evidence
+O=$R/gpurun_out/evidence.tmp.$$          # written here, moved into place only when the run got to its end: a failed run keeps the old evidence
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 G="grep -v amdgpu.ids"
@@ -32,6 +33,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/ev_write -
 ff=$(find /tmp/ev_fetch -name "*counter_collection.csv" | head -1); fw=$(find /tmp/ev_write -name "*counter_collection.csv" | head -1)
 (cd $R && python3 tools/traffic_summary.py "$ff" "$fw" 256 bf16 > $O/traffic_layers.txt 2>&1; cp profiles/traffic.json $O/traffic.json)
 # --- HBM-bound kernels: streaming rates of the box, then the element-wise / BN kernels against them
+[ -x $R/tools/probes/stream_bw ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 $R/tools/probes/stream_bw.hip -o $R/tools/probes/stream_bw
 $R/tools/probes/stream_bw 1024 > $O/stream_bw.txt 2>&1
 python3 $R/tools/bench_elementwise.py 2>&1 | $G > $O/hbm_kernels.txt
 # --- pretraining step
@@ -57,4 +59,5 @@ bash $R/tools/pmc_layers.sh > $O/pmc_raw.txt 2>&1
 python3 $R/tools/dp_pretrain_check.py 2>&1 | grep -v "amdgpu.ids\|Gloo\|socket.cpp" > $O/dp_pretrain_check.txt
 python3 $R/tools/dp_check.py 2>&1 | grep -v "amdgpu.ids\|Gloo\|socket.cpp" > $O/dp_check.txt
 python3 $R/tools/rccl_smoke.py 2>&1 | grep -v "amdgpu.ids" > $O/rccl_single_rank_smoke.txt
+rm -rf $FINAL && mv $O $FINAL
 echo evidence done
