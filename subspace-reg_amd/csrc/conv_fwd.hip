@@ -1007,6 +1007,10 @@ static int launch_shape(const ConvArgs& a, bool pool, hipStream_t s) {
 // (e.g. 548 tiles of 256 rows = 2 rounds lose to 1094 tiles of 128 rows = 2 x 0.62); on 42x42 maps the halo (2 x 43 rows
 // per tile) makes the small tile as slow or slower (pooled: 1.2x), so those keep 256 rows whenever they fill the chip.
 static bool wide_takes_256_rows(int M, int Cout, int W) {
+    // measurement switch: SUBREG_FORCE_TILE=128 / 256 forces one tiling for every Cout % 160 == 0 launch (A/B runs of the rule below)
+    static const int forced = [] { const char* e = getenv("SUBREG_FORCE_TILE"); return e ? atoi(e) : 0; }();
+    if (forced == 128) return false;
+    if (forced == 256) return true;
     const long long nt = Cout / 160, t256 = (long long)((M + 255) / 256) * nt, t128 = (long long)((M + 127) / 128) * nt;
     if (W > 21) return t256 >= 384;
     return (double)((t256 + 511) / 512) <= 0.62 * (double)((t128 + 767) / 768);

@@ -54,7 +54,13 @@ template <> struct ElemTraits<__bf16> {
 // Issued from inline asm ON PURPOSE: for the builtin form hipcc (ROCm 7.2) inserts `s_waitcnt vmcnt(0)` in front of
 // the next ds_read of ANY LDS address, which drains the prefetch every step; asm DMAs are invisible to that pass, so
 // the counted `s_waitcnt vmcnt(N)` + `s_barrier` at the end of each step are the only (hand-placed) waits on them.
-// M0 (the DMA's LDS base) is compiler-reserved: save / set / restore inside the one statement.
+// M0 (the DMA's LDS base) is set inside the statement and declared clobbered.  Rounds 1-3 saved and restored it around every DMA
+// (four scalar instructions per piece); hipcc (ROCm 7.2) never uses M0 in any kernel of this library - every mention of m0 in the
+// generated ISA is inside these statements (tools/kernel_resources.sh has the one-line check) - and with the clobber it knows the
+// register does not survive, so it would re-materialise a value of its own.  SUBREG_DMA_KEEP_M0=1 restores the old form.
+#ifndef SUBREG_DMA_KEEP_M0
+#define SUBREG_DMA_KEEP_M0 0
+#endif
 __device__ __forceinline__ void dma16(const char* base_in, unsigned voff, unsigned lds_addr) {
     // the base is wave-uniform by construction; say so where the compiler's uniformity analysis cannot see it
     const unsigned long long bu = (unsigned long long)(size_t)base_in;
@@ -62,6 +68,7 @@ __device__ __forceinline__ void dma16(const char* base_in, unsigned voff, unsign
     const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bu >> 32));
     const char* base = (const char*)(size_t)(((unsigned long long)bhi << 32) | blo);
     const unsigned lds_u = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);   // wave-uniform too (M0 is a scalar register)
+#if SUBREG_DMA_KEEP_M0
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -72,6 +79,15 @@ __device__ __forceinline__ void dma16(const char* base_in, unsigned voff, unsign
         : "=&s"(keep)
         : "v"(voff), "s"(base), "s"(lds_u)
         : "memory");
+#else
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(voff), "s"(base), "s"(lds_u)
+        : "memory", "m0");
+#endif
 }
 
 __device__ __forceinline__ float lrelu(float v) { return v >= 0.f ? v : v * 0.1f; }   // nn.LeakyReLU(0.1)

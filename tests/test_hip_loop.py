@@ -382,3 +382,50 @@ def test_fused_loop_351_base_classes_against_oracle(dtype, scale):
         ab, an = want["acc_base"][-1], want["novel_acc"][-1]
         w1, w2 = (NB, 5 * ns) if follow else (200, NB + 5 * ns - 60)
         assert abs(want["weighted_avg"][-1] - round((w1 * want["base_vals"][-1] + w2 * want["novel_vals"][-1]) / (w1 + w2), 2)) < 1e-9, (ab, an)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fused_loop_351_base_classes_hw84_against_cached_oracle(dtype):
+    """BASELINE.json configs[4], incremental leg at the reference's image size: 351 base classes, +M, 2 sessions x 3 epochs at
+    84x84 (476-601 images per forward through the production kernels incl. the fused layer 1).  Expected values: the build's NumPy
+    oracle, computed once in the build container (tools/make_oracle_fixture.py, ~11 minutes) and committed as
+    tests/golden/oracle_loop351_hw84.npz - NOT a reference golden (the reference cannot run tieredImageNet,
+    eval_incremental.py:82-83); the oracle itself is pinned by the reference-generated 60-class goldens."""
+    from subreg_hip.incremental import few_shot_finetune_incremental_test
+    from subreg_hip.resnet_language import create_model
+    g = np.load(os.path.join(GOLDEN, "oracle_loop351_hw84.npz"))
+    c = {k[5:]: g[k].item() for k in g.files if k.startswith("case.")}
+    NB, seed, signal, hw, ns, n_epochs = int(c["NB"]), int(c["seed"]), float(c["signal"]), int(c["hw"]), int(c["ns"]), int(c["n_epochs"])
+    opt = make_opt(set_seed=seed, neval_episodes=ns, memory_replay=1, hip_dtype=dtype, max_novel_epochs=n_epochs,
+                   dataset="tieredImageNet", avg_weights_follow_n_base=True)
+    sd = syn.make_state_dict(int(c["sd_seed"]), n_cls=NB)
+    sessions = syn.make_sessions(seed, ns, hw, class_signal=signal, first_novel=NB)
+    bx, by = syn.make_base_batch(seed, int(c["n_base_batch"]), hw, n_base=NB, class_signal=signal)
+    sx, sy = syn.make_base_support(seed, hw, n_base=NB, class_signal=signal)
+    inits = syn.make_novel_inits(seed, ns)
+    picks = [np.array([1]), np.array([3])][:ns]
+    net = create_model("resnet18", NB, opt, dataset="tieredImageNet")
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    net = net.cuda()
+    net.mask_source = MaskSource(int(c["mask_seed"]))
+    names_base = ["b%d" % i for i in range(NB)]
+    base_loader = _Loader([(torch.from_numpy(bx), torch.from_numpy(by), torch.arange(len(by)))], names_base)
+    meta = _Loader([(torch.from_numpy(s["support_xs"])[None], torch.from_numpy(s["support_ys"])[None],
+                     torch.from_numpy(s["query_xs"])[None], torch.from_numpy(s["query_ys"])[None]) for s in sessions],
+                   ["n%d" % i for i in range(NB + 100)])
+    bsl = _Loader([(torch.from_numpy(sx)[None], torch.from_numpy(sy)[None], torch.zeros(1, 1, 3, hw, hw),
+                    torch.zeros(1, 1, dtype=torch.long))], names_base)
+    few_shot_finetune_incremental_test(net, {}, None, meta, base_loader, opt, base_support_loader=bsl, novel_inits=inits,
+                                       memory_picks=picks, verbose=False)
+    run = net.last_run
+    f32 = dtype == "f32"
+    assert run["classifier_weight"].shape == (NB + 5 * ns, 640)
+    for s in range(ns):
+        assert run["epochs"][s] == int(g["epochs"][s]) == n_epochs
+        _cmp("loss s%d" % s, run["loss"][s], g["loss.%d" % s], 2e-4 if f32 else 5e-2, 2e-4 if f32 else 2e-2)
+        _cmp("val acc s%d" % s, run["test_acc"][s], g["test_acc.%d" % s], 1e-6 if f32 else 200.0 / 125 + 1e-6, 0)
+        _cmp("val top-5 s%d" % s, run["test_acc_top5"][s], g["test_acc_top5.%d" % s], 1e-4 if f32 else 500.0 / 125 + 1e-4, 0)
+    _cmp("final classifier", run["classifier_weight"], g["classifier_weight"], 1e-4 if f32 else 5e-3, 1e-4 if f32 else 5e-3)
+    if f32:
+        _cmp("weighted avg", run["weighted_avg"], g["weighted_avg"], 1e-6, 0)
+        _cmp("acc base", run["acc_base"], g["acc_base"], 1e-6, 0)
