@@ -1018,8 +1018,16 @@ static bool wide_takes_256_rows(int M, int Cout, int W) {
 
 // rows of stats partials the raw mode writes for a given problem = m-tiles x waves along M of the configuration that
 // subreg_conv_fwd picks for it (the caller sizes the buffer and calls subreg_bn_train_finalize with this)
+// f32 (parity mode): 256-row tiles of four waves - one wave on EVERY SIMD of the CU (rounds 1-3 ran 128-row tiles of two waves at one
+// workgroup per CU: half the SIMDs idle) - wherever the un-pooled 3x3 patch of such a tile fits the larger patch buffer
+// (256 + 2 (W + 1) <= 432 rows); raw mode sizes its statistics rows from the same predicate
+static bool f32_takes_256_rows(int W) {
+    static const bool on = [] { const char* e = getenv("SUBREG_F32_TILE128"); return !(e && e[0] == '1'); }();   // A/B switch
+    return on && 256 + 2 * (W + 1) <= 432;
+}
+
 static int stats_rows_for(int dtype, int M, int Cout, int W) {
-    if (dtype != SUBREG_BF16) return ((M + 127) / 128) * 2;          // f32: 128-row tiles, 2 waves along M
+    if (dtype != SUBREG_BF16) return f32_takes_256_rows(W) ? ((M + 255) / 256) * 4 : ((M + 127) / 128) * 2;   // f32: 4 or 2 waves along M
     const int tm = (Cout % 160 == 0 && !wide_takes_256_rows(M, Cout, W)) ? 128 : 256;
     return ((M + tm - 1) / tm) * 4;
 }
@@ -1197,6 +1205,10 @@ static int conv_fwd_impl(const void* x, const void* w, void* y, const float* sca
         };
         if (!wide_takes_256_rows(a.g.M, Cout, W)) return tiles128(a, s);
         return tiles256(a, s);
+    }
+    if (f32_takes_256_rows(W)) {
+        const int rc = wide ? launch_shape<float, 2, 5, 4, 1, 1, 344, 432, 1>(a, pool, s) : launch_shape<float, 2, 2, 4, 1, 1, 344, 432, 1>(a, pool, s);
+        if (rc != SUBREG_EUNSUPPORTED || raw) return rc;             // (a pooled tile's patch can be larger: the 128-row tiles below take it)
     }
     return wide ? launch_shape<float, 2, 5, 2, 1, 1, 304, 408, 1>(a, pool, s) : launch_shape<float, 2, 2, 2, 1, 1, 304, 408, 1>(a, pool, s);
 }
