@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUBREG_ABI_VERSION 10
+#define SUBREG_ABI_VERSION 11
 
 #define SUBREG_OK 0
 #define SUBREG_EINVAL (-1)       /* bad argument (null pointer, shape not supported by contract) */
@@ -103,6 +103,10 @@ int subreg_layer1_direct_supported(int B, int H, int W, int dtype);
 int subreg_bn_fold(const float* weight, const float* bias, const float* running_mean, const float* running_var,
                    float* scale, float* shift, int C, float eps, void* stream);
 /* train: reduce the partials -> batch scale/shift; running stats updated in place (momentum, unbiased var) */
+/* eval-mode BatchNorm of a forward that keeps a stash (subreg_train_desc.eval_mode): scale = w / sqrt(rv + eps), shift = b - rm * scale,
+ * save_mean = rm, save_invstd = 1 / sqrt(rv + eps) (nn.BatchNorm2d in eval mode, models/resnet_language.py:250-255) */
+int subreg_bn_eval_stash(const float* weight, const float* bias, const float* running_mean, const float* running_var, float eps,
+                         int C, float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
 int subreg_bn_train_finalize(const float* stats_partial, int rows, int C, long long count, const float* weight,
                              const float* bias, float* running_mean, float* running_var, float momentum, float eps,
                              float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
@@ -200,6 +204,10 @@ int subreg_bn_bwd_slices(long long npix);
 int subreg_bn_bwd(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
                   const float* gamma, double* partial, float* dgamma, float* dbeta, void* dx, long long npix, int C, int dtype,
                   void* stream);
+/* the same for an eval-mode BatchNorm (mean / invstd = the running statistics, constants): dx = gamma * invstd * dy * lrelu'(act) */
+int subreg_bn_bwd_eval(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
+                  const float* gamma, double* partial, float* dgamma, float* dbeta, void* dx, long long npix, int C, int dtype,
+                  void* stream);
 /* backward of  out = keep*mask_scale * [pool2](lrelu(raw3*scale3+shift3 + residual*res_scale+res_shift))  w.r.t. the
  * pre-activation sum (MaxPool2d: first maximum of the window; BasicBlock.forward :288-299) */
 int subreg_block_tail_bwd(const void* grad_out, const unsigned char* keep_mask, float mask_scale,
@@ -267,6 +275,10 @@ typedef struct subreg_train_desc {
     float* stats_side;       /* like subreg_backbone_desc.stats, for the shortcut conv's batch statistics in the forward */
     float* splitk_ws;        /* optional workspace of subreg_conv_fwd_ws for the step's 3x3 convolutions (forward and dX) */
     long long splitk_ws_floats; /* >= max over them of subreg_conv_splitk_floats */
+    int eval_mode;           /* 1: the forward normalises with the RUNNING statistics (and updates nothing), the backward is that of an
+                              * eval-mode BatchNorm - whole-network fine-tuning with the model in eval mode, i.e. the epochs 2 ..
+                              * freeze_backbone_at - 1 of eval/language_eval.py:242-295 (validate() leaves the model in eval mode, :19);
+                              * the blocks' keep_mask must be NULL (no dropout / DropBlock in eval mode).  0: train mode */
 } subreg_train_desc;
 
 /* hipEvent_t (timing disabled) for subreg_train_desc.events; destroy when the descriptor is retired */

@@ -115,9 +115,11 @@ class _GradBf16(torch.autograd.Function):
         return _round_bf16_t(g)
 
 
-def train_step_grads(sd, x, labels, masks, bf16=True, n_blocks=(1, 1, 2, 2), no_dropblock=True):
+def train_step_grads(sd, x, labels, masks, bf16=True, n_blocks=(1, 1, 2, 2), no_dropblock=True, eval_mode=False):
     """One train-mode forward + backward of the backbone + linear classifier on CPU.  sd: state_dict (numpy), x [B,3,H,W],
-    labels [B], masks: a MaskSource (consumed in the reference's order).  Returns (loss, {parameter name: gradient})."""
+    labels [B], masks: a MaskSource (consumed in the reference's order).  Returns (loss, {parameter name: gradient}).
+    eval_mode: the model in eval mode with every parameter still requiring grad - BatchNorm normalises with its running
+    statistics, no dropout / DropBlock (eval/language_eval.py:242-295 before freeze_backbone_at, after the first validate())."""
     from .resnet_ref import DROP_RATE, dropblock_gamma
     assert no_dropblock, "block_size 1 only (every script of the reference passes --no_dropblock)"
     store = _StoreBf16.apply if bf16 else (lambda t: t)
@@ -130,6 +132,9 @@ def train_step_grads(sd, x, labels, masks, bf16=True, n_blocks=(1, 1, 2, 2), no_
         return w + (_round_bf16_t(w) - w).detach() if bf16 else w
 
     def bn(t, p):
+        if eval_mode:
+            return F.batch_norm(t, torch.from_numpy(np.asarray(sd[p + ".running_mean"])), torch.from_numpy(np.asarray(sd[p + ".running_var"])),
+                                P[p + ".weight"], P[p + ".bias"], False, 0.1, BN_EPS)
         return F.batch_norm(t, None, None, P[p + ".weight"], P[p + ".bias"], True, 0.1, BN_EPS)
 
     a = store(torch.as_tensor(x, dtype=torch.float32))
@@ -143,6 +148,9 @@ def train_step_grads(sd, x, labels, masks, bf16=True, n_blocks=(1, 1, 2, 2), no_
         if s["stride"] > 1:
             out = F.max_pool2d(out, s["stride"])
         B, C, H, W = out.shape
+        if eval_mode:
+            a = store(out)
+            continue
         if s["drop_block"]:                         # DropBlock with block_size 1 (:311-325): drop with probability gamma
             gamma = dropblock_gamma(1, H, 1)
             keep = 1.0 - masks.bernoulli((B, C, H, W), gamma)

@@ -14,9 +14,12 @@ namespace {
 
 // raw conv + batch statistics; scale/shift of this batch, mean/invstd saved for the backward
 int conv_stash(const subreg_backbone_desc* d, const subreg_conv_desc& c, const subreg_conv_train& tc, const void* x, int B, int H,
-               int W, float* stats, float* ws, long long ws_floats, void* stream) {
+               int W, float* stats, float* ws, long long ws_floats, void* stream, bool eval_mode = false) {
     TRY(subreg_conv_fwd_ws(x, c.w, tc.raw, nullptr, nullptr, nullptr, stats, nullptr, nullptr, 0, B, H, W, c.cin, c.cout, c.ksize,
                            SUBREG_CONV_RAW_STATS, d->dtype, ws, ws_floats, stream));
+    if (eval_mode)      // eval-mode BatchNorm (running statistics; nothing is updated): the batch statistics just computed are not used
+        return subreg_bn_eval_stash(c.bn_weight, c.bn_bias, c.running_mean, c.running_var, d->bn_eps, c.cout, tc.bscale, tc.bshift,
+                                    tc.mean, tc.invstd, stream);
     const int rows = subreg_conv_stats_rows(d->dtype, B, H, W, c.cout);
     return subreg_bn_train_finalize(stats, rows, c.cout, (long long)B * H * W, c.bn_weight, c.bn_bias, c.running_mean,
                                     c.running_var, d->bn_momentum, d->bn_eps, tc.bscale, tc.bshift, tc.mean, tc.invstd, stream);
@@ -24,9 +27,9 @@ int conv_stash(const subreg_backbone_desc* d, const subreg_conv_desc& c, const s
 
 // BN backward (+ fused LeakyReLU' of `act`): d(raw conv output) into `draw`, d gamma / d beta
 int bn_backward(const subreg_backbone_desc* d, const subreg_conv_desc& c, const subreg_conv_train& tc, const void* dy, const void* act,
-                void* draw, double* partial, int B, int H, int W, void* stream) {
-    return subreg_bn_bwd(dy, act, tc.raw, tc.mean, tc.invstd, c.bn_weight, partial, tc.grad_gamma, tc.grad_beta, draw,
-                         (long long)B * H * W, c.cout, d->dtype, stream);
+                void* draw, double* partial, int B, int H, int W, void* stream, bool eval_mode = false) {
+    return (eval_mode ? subreg_bn_bwd_eval : subreg_bn_bwd)(dy, act, tc.raw, tc.mean, tc.invstd, c.bn_weight, partial, tc.grad_gamma,
+                                                           tc.grad_beta, draw, (long long)B * H * W, c.cout, d->dtype, stream);
 }
 
 // the weight gradient of the conv that produced `raw`, from d(raw) and the conv's input
@@ -83,6 +86,7 @@ extern "C" int subreg_backbone_forward_stash(const subreg_backbone_desc* d, cons
     SUBREG_CHECK_ARG(d && t && d->blocks && t->blocks && d->n_blocks > 0 && x_nchw && feat && B > 0 && H > 0 && W > 0);
     SUBREG_CHECK_ARG(d->col && d->stats);
     const int dt = d->dtype;
+    const bool ev = t->eval_mode != 0;     // eval-mode BatchNorm (running statistics), no dropout masks: the caller leaves keep_mask NULL
     Fork f(t, stream);
     if (!t->stats_side) f.on = false, f.side = f.main;
     TRY(subreg_pack_input(x_nchw, d->col, B, H, W, dt, stream));
@@ -99,17 +103,17 @@ extern "C" int subreg_backbone_forward_stash(const subreg_backbone_desc* d, cons
         if (b.down.w) {                    // the 1x1 shortcut conv + its statistics: beside conv1..conv3 on the side stream
             SUBREG_CHECK_ARG(tb.down.raw != nullptr);
             if (fork) TRY(f.main_to_side(EV_FORK));
-            TRY(conv_stash(d, b.down, tb.down, cur, B, h, w, fork ? t->stats_side : d->stats, nullptr, 0, fork ? f.side : f.main));
+            TRY(conv_stash(d, b.down, tb.down, cur, B, h, w, fork ? t->stats_side : d->stats, nullptr, 0, fork ? f.side : f.main, ev));
             if (fork) TRY(f.mark_side(EV_DOWN));
             res = tb.down.raw; rsc = tb.down.bscale; rsh = tb.down.bshift;
         }
-        TRY(conv_stash(d, b.conv1, tb.conv1, cur, B, h, w, d->stats, t->splitk_ws, t->splitk_ws_floats, stream));
+        TRY(conv_stash(d, b.conv1, tb.conv1, cur, B, h, w, d->stats, t->splitk_ws, t->splitk_ws_floats, stream, ev));
         TRY(subreg_bn_apply(tb.conv1.raw, tb.conv1.bscale, tb.conv1.bshift, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, tb.conv1.act, B, h,
                             w, b.conv1.cout, SUBREG_CONV_LRELU, dt, stream));
-        TRY(conv_stash(d, b.conv2, tb.conv2, tb.conv1.act, B, h, w, d->stats, t->splitk_ws, t->splitk_ws_floats, stream));
+        TRY(conv_stash(d, b.conv2, tb.conv2, tb.conv1.act, B, h, w, d->stats, t->splitk_ws, t->splitk_ws_floats, stream, ev));
         TRY(subreg_bn_apply(tb.conv2.raw, tb.conv2.bscale, tb.conv2.bshift, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, tb.conv2.act, B, h,
                             w, b.conv2.cout, SUBREG_CONV_LRELU, dt, stream));
-        TRY(conv_stash(d, b.conv3, tb.conv3, tb.conv2.act, B, h, w, d->stats, t->splitk_ws, t->splitk_ws_floats, stream));
+        TRY(conv_stash(d, b.conv3, tb.conv3, tb.conv2.act, B, h, w, d->stats, t->splitk_ws, t->splitk_ws_floats, stream, ev));
         if (b.down.w && fork) TRY(f.main_waits(EV_DOWN));
         TRY(subreg_bn_apply(tb.conv3.raw, tb.conv3.bscale, tb.conv3.bshift, res, rsc, rsh, b.keep_mask, b.mask_scale, b.mask_scale_dev, tb.out, B, h, w,
                             b.conv3.cout, SUBREG_CONV_LRELU | pflag, dt, stream));
@@ -151,7 +155,7 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
                              const void* conv_input, int bh, int bw, const void** draw_out) -> int {
         const int k = use++ & 1;
         if (busy[k]) { TRY(f.main_waits(EV_DONE0 + k)); busy[k] = false; }
-        TRY(bn_backward(d, c, tc, dy, act, drb[k], t->bn_partial, B, bh, bw, stream));
+        TRY(bn_backward(d, c, tc, dy, act, drb[k], t->bn_partial, B, bh, bw, stream, t->eval_mode != 0));
         if (fork) {
             TRY(f.main_to_side(EV_READY0 + k));
             TRY(weight_grad(d, t, c, tc, conv_input, drb[k], B, bh, bw, f.side));
@@ -193,7 +197,7 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
         const bool down_side = fork && i >= down_on_side_from();
         if (b.down.w && down_side) {
             TRY(f.main_to_side(EV_FORK));
-            TRY(bn_backward(d, b.down, tb.down, t->dv, nullptr, t->dr2, t->bn_partial_side, B, bh, bw, f.side));
+            TRY(bn_backward(d, b.down, tb.down, t->dv, nullptr, t->dr2, t->bn_partial_side, B, bh, bw, f.side, t->eval_mode != 0));
             TRY(weight_grad(d, t, b.down, tb.down, xin, t->dr2, B, bh, bw, f.side));
             TRY(f.mark_side(EV_DOWN));
             down_busy = true;
@@ -208,7 +212,7 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
                                b.conv2.cout, b.conv2.cin, b.conv2.ksize_raw, 0, dt, t->splitk_ws, t->splitk_ws_floats, stream));
         TRY(bn_then_wgrad(b.conv1, tb.conv1, t->dt, tb.conv1.act, xin, bh, bw, &dr));
         if (b.down.w && !down_side) {      // shortcut branch on the main stream
-            TRY(bn_backward(d, b.down, tb.down, t->dv, nullptr, t->dr2, t->bn_partial, B, bh, bw, stream));
+            TRY(bn_backward(d, b.down, tb.down, t->dv, nullptr, t->dr2, t->bn_partial, B, bh, bw, stream, t->eval_mode != 0));
             TRY(weight_grad(d, t, b.down, tb.down, xin, t->dr2, B, bh, bw, stream));
         }
         // the shortcut branch's results (dr2) and its reads of dv: main continues after them

@@ -1130,9 +1130,28 @@ extern "C" int subreg_block_tail_bwd(const void* grad_out, const unsigned char* 
 // (at most 512 slices, whatever the problem: see the slice plan in subreg_bn_bwd)
 extern "C" int subreg_bn_bwd_slices(long long npix) { (void)npix; return 512 + 1; }
 
+// eval_mode: the statistics are constants (running mean / variance), so d(x) = gamma * invstd * g: the two batch-statistics terms of
+// the train-mode formula carry a factor 1 / N, and passing 1 / N = 0 to the finalize pass drops exactly them (k2 = k3 = 0); d(gamma)
+// and d(beta) are the same sums over x_hat = (raw - mean) * invstd in both modes
+static int bn_bwd_impl(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
+                       const float* gamma, double* partial, float* dgamma, float* dbeta, void* dx, long long npix, int C,
+                       int dtype, bool eval_mode, void* stream);
+
 extern "C" int subreg_bn_bwd(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
                              const float* gamma, double* partial, float* dgamma, float* dbeta, void* dx, long long npix, int C,
                              int dtype, void* stream) {
+    return bn_bwd_impl(dy, act, raw, mean, invstd, gamma, partial, dgamma, dbeta, dx, npix, C, dtype, false, stream);
+}
+
+extern "C" int subreg_bn_bwd_eval(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
+                                  const float* gamma, double* partial, float* dgamma, float* dbeta, void* dx, long long npix, int C,
+                                  int dtype, void* stream) {
+    return bn_bwd_impl(dy, act, raw, mean, invstd, gamma, partial, dgamma, dbeta, dx, npix, C, dtype, true, stream);
+}
+
+static int bn_bwd_impl(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
+                       const float* gamma, double* partial, float* dgamma, float* dbeta, void* dx, long long npix, int C,
+                       int dtype, bool eval_mode, void* stream) {
     SUBREG_CHECK_ARG(dy && raw && mean && invstd && gamma && partial && dgamma && dbeta && dx && npix > 0 && C > 0);
     hipStream_t s = (hipStream_t)stream;
     // at most 512 slices (two per CU): the finalize pass walks every slice of a channel, and at 1764 slices (64 x 84 x 84
@@ -1151,8 +1170,8 @@ extern "C" int subreg_bn_bwd(const void* dy, const void* act, const void* raw, c
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, slices, 256, lds, s, (const float*)dy, (const float*)act, (const float*)raw, mean, invstd, partial, npix, C, (int)pps),
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, slices, 256, lds, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, partial, npix, C, (int)pps));
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, (C + 7) / 8, 256, 0, s, partial, slices, C, mean, invstd, gamma, 1.0 / (double)npix,
-                       dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, (C + 7) / 8, 256, 0, s, partial, slices, C, mean, invstd, gamma,
+                       eval_mode ? 0.0 : 1.0 / (double)npix, dgamma, dbeta, coef);
     long long ppb = (npix + 4095) / 4096;                   // apply pass: ~4096 blocks, whole unrolled rounds of the pixel lanes
     ppb = (ppb + 4 * lanes_ - 1) / (4 * lanes_) * (4 * lanes_);
     const int agrid = (int)((npix + ppb - 1) / ppb);

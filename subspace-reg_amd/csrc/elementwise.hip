@@ -131,6 +131,21 @@ __global__ void bn_fold_kernel(const float* __restrict__ weight, const float* __
     shift[c] = bias[c] - rm[c] * s;
 }
 
+// eval-mode BatchNorm of a forward that keeps a stash for the backward (whole-network fine-tuning before freeze_backbone_at,
+// eval/language_eval.py:243-249 with the model in eval mode from the first validate() on): scale / shift from the RUNNING
+// statistics, which also take the place of the batch mean / invstd the backward normalises with
+__global__ void bn_eval_stash_kernel(const float* __restrict__ weight, const float* __restrict__ bias,
+                                     const float* __restrict__ rm, const float* __restrict__ rv, float* __restrict__ scale,
+                                     float* __restrict__ shift, float* __restrict__ mean, float* __restrict__ invstd, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.f / sqrtf(rv[c] + eps), s = weight[c] * is;
+    scale[c] = s;
+    shift[c] = bias[c] - rm[c] * s;
+    mean[c] = rm[c];
+    invstd[c] = is;
+}
+
 // ---------------------------------------------------------------- BN train-mode statistics
 // partial [rows][C][2] (sum, sumsq) -> batch mean / biased var -> scale/shift for this batch, and the
 // running-stat update (momentum, unbiased variance) in place.  One 256-thread block per channel; per-thread
@@ -467,6 +482,14 @@ extern "C" int subreg_bn_fold(const float* weight, const float* bias, const floa
     SUBREG_CHECK_ARG(weight && bias && running_mean && running_var && scale && shift && C > 0);
     hipLaunchKernelGGL(bn_fold_kernel, ew_blocks(C), EW_THREADS, 0, (hipStream_t)stream, weight, bias, running_mean,
                        running_var, scale, shift, C, eps);
+    return launch_status();
+}
+
+extern "C" int subreg_bn_eval_stash(const float* weight, const float* bias, const float* running_mean, const float* running_var,
+                                    float eps, int C, float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
+    SUBREG_CHECK_ARG(weight && bias && running_mean && running_var && scale && shift && save_mean && save_invstd && C > 0);
+    hipLaunchKernelGGL(bn_eval_stash_kernel, ew_blocks(C), EW_THREADS, 0, (hipStream_t)stream, weight, bias, running_mean, running_var,
+                       scale, shift, save_mean, save_invstd, C, eps);
     return launch_status();
 }
 

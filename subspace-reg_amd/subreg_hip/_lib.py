@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SUBREG_LIB") or os.path.join(_HERE, "libsubreg_hip.so
 F32, BF16 = 0, 1
 CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
 FWD_TRAIN = 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_QUERY_SETS = 32                          # SUBREG_MAX_QUERY_SETS
 
 c_void_p, c_int, c_float, c_longlong = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -53,7 +53,7 @@ class TrainDesc(C.Structure):
                 ("dr2", c_void_p), ("bn_partial", c_void_p), ("pad_x", c_void_p), ("pad_dy", c_void_p),
                 ("zero_shift", c_void_p), ("grad_out_dump", C.POINTER(c_void_p)),
                 ("side_stream", c_void_p), ("events", c_void_p * 6), ("dr_alt", c_void_p), ("bn_partial_side", c_void_p),
-                ("stats_side", c_void_p), ("splitk_ws", c_void_p), ("splitk_ws_floats", c_longlong)]
+                ("stats_side", c_void_p), ("splitk_ws", c_void_p), ("splitk_ws_floats", c_longlong), ("eval_mode", c_int)]
 
 
 class LoopState(C.Structure):
@@ -106,6 +106,8 @@ SIGNATURES = {
     "subreg_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_bn_bwd_slices": (_I, [_L]),
     "subreg_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "subreg_bn_bwd_eval": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "subreg_bn_eval_stash": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P]),
     "subreg_block_tail_bwd": (_I, [_P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "subreg_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_sgd_momentum": (_I, [_P, _P, _P, _L, _F, _F, _F, _I, _P]),

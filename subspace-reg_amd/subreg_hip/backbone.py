@@ -202,6 +202,14 @@ class HipBackbone:
         self._desc.col = self._desc.stats = None
 
     # ------------------------------------------------------------------ train-mode masks
+    def _clear_masks(self):
+        """No dropout / DropBlock (an eval-mode forward that keeps a stash): every block's keep mask off."""
+        self._keep = []
+        for bi in range(len(self.blocks)):
+            self._blk[bi].keep_mask = None
+            self._blk[bi].mask_scale = 1.0
+            self._blk[bi].mask_scale_dev = None
+
     def _prepare_masks(self, B, H, W, masks):
         """Keep masks of every block output (dropout :299 / DropBlock :311-325), uploaded as NHWC u8."""
         self._keep = []

@@ -88,10 +88,17 @@ class IncrementalRunner:
         # classifier with bias (eval_incremental.py:96-103: whatever the checkpoint holds): handled by the fused step; the one
         # combination the reference itself cannot run is refused where the reference fails (run_session)
         self.novel_bias_inits = novel_bias_inits
-        if int(getattr(opt, "freeze_backbone_at", 1)) != 1:
-            # language_eval.py:247-249 trains the backbone with SGD until epoch == freeze_backbone_at; every script passes 1
-            raise NotImplementedError("freeze_backbone_at=%r: the fused loop keeps the backbone frozen from epoch 1 "
-                                      "(eval/util.py:62-69 with the scripts' value)" % (opt.freeze_backbone_at,))
+        # freeze_backbone_at = K (language_eval.py:243, eval/util.py:62-69): the backbone's parameters stop requiring grad at the
+        # start of epoch K of whichever session gets there first.  Every script passes 1 (frozen before the first forward: the
+        # fused loop below).  K > 1: the epochs before K fine-tune the WHOLE network (run_session::pre-freeze epochs); at K the
+        # backbone freezes for good and the fused loop takes over.
+        self.freeze_at = int(getattr(opt, "freeze_backbone_at", 1))
+        if self.freeze_at < 1:
+            raise ValueError("freeze_backbone_at must be >= 1 (the reference's loop counts epochs from 1)")
+        self.backbone_frozen = self.freeze_at == 1
+        if not self.backbone_frozen and row_shard is not None and row_shard.size > 1:
+            raise NotImplementedError("freeze_backbone_at > 1 together with a row-sharded seed (the helpers would need the gradient "
+                                      "all-reduce of pretrain.GradientSync inside the session loop)")
         self.lib = _lib.load()
         self.net, self.opt = net, opt
         self.meta_valloader, self.base_val_loader, self.base_support_loader = meta_valloader, base_val_loader, base_support_loader
@@ -304,17 +311,70 @@ class IncrementalRunner:
                                                query_x[j].shape[0], N, D, _lib.ptr(ses.state), _lib.ptr(ses.correct), j,
                                                n_sets, int(j == n_sets - 1), s()), "validate")
 
-        # ---- epoch 1: TRAIN-mode support (+memory) forward (BN batch stats, running-stat update, masks), :252-258
-        self._forward(sx, train=True, out=feats[:Bs])
-        if Bm:
-            self._forward(mem_x, train=True, out=feats[Bs:Bs + Bm])
-        torch._foreach_add_([m.num_batches_tracked for m in net._bns], 1 + (1 if Bm else 0))     # one launch, not one per BatchNorm
-        net.eval()                                                             # validate() flips the mode for good, :19
-        hb.refresh()                                                           # BN running statistics moved: fold once
-        self._forward_eval(all_x[Bs + Bm:], out=feats[Bs + Bm:])
-        for i in range(len(hb.nbt)):
-            hb.nbt[i] += n_sets - 1
-        step_and_validate()
+        def validate_only():
+            assert n_sets <= _lib.MAX_QUERY_SETS
+            _lib.check(lib.subreg_validate_sets(_lib.ptr(feats[q_off[0]:]), _lib.ptr(query_labels), _lib.ptr(W), bias_p, set_rows,
+                                                n_sets, N, D, _lib.ptr(ses.state), _lib.ptr(ses.correct), _lib.ptr(ses.correct5),
+                                                n_sets, 1, s()), "validate_sets")
+
+        trainable = [] if self.backbone_frozen else [p_ for n_, p_ in net.named_parameters()
+                                                       if not n_.startswith("classifier") and p_.requires_grad]
+        if trainable and self.freeze_at > 1:
+            # ---- pre-freeze epochs 1 .. K-1 (language_eval.py:242-295 with a trainable backbone): the support forward keeps a stash
+            #      (train mode in epoch 1, eval mode afterwards: validate() leaves the model there, :19); the fused step computes the
+            #      loss, d(logits) and the classifier's own SGD update as in every other epoch; d(features) = d(logits) @ W (the W
+            #      the forward used) goes back through the backbone's HIP backward, and every backbone parameter takes the same
+            #      SGD(lr, momentum, weight_decay) step (get_optim builds ONE optimiser over net.parameters() per session, :231);
+            #      the query sets are then forwarded through the UPDATED backbone.  The regularizers do not reach the backbone.
+            from .train import SGD as _BackboneSGD
+            if getattr(opt, "adam", False):
+                raise NotImplementedError("freeze_backbone_at > 1 with --adam (the backbone's optimiser here is SGD)")
+            if Bm:
+                raise NotImplementedError("a backbone that is still trainable in a session with replay memory (two train-mode "
+                                          "forwards per step share one stash)")
+            opt_bb = _BackboneSGD(trainable, lr=opt.learning_rate, momentum=opt.momentum, weight_decay=opt.weight_decay)
+            dfeat = torch.empty(Bs, D, dtype=torch.float32, device=dev)
+            while True:
+                st = ses.state.cpu()
+                epoch_next = int(st[0]) + 1
+                if bool(st[1]) or epoch_next >= self.freeze_at:
+                    break
+                with torch.enable_grad():
+                    feat = net.features(sx)                                    # BackboneTrainFn: train mode in epoch 1, eval after
+                feats[:Bs].copy_(feat.detach())
+                self.images_forwarded += Bs
+                w_used = W.clone()
+                _lib.check(lib.subreg_finetune_step(C.byref(d), s()), "finetune_step")
+                _lib.check(lib.subreg_linear_bwd(_lib.ptr(ses.dlogits), _lib.ptr(feats), _lib.ptr(w_used), None, None, _lib.ptr(dfeat),
+                                                 Bs, N, D, s()), "linear_bwd")
+                feat.backward(dfeat)
+                opt_bb.step()
+                opt_bb.zero_grad()
+                net.eval()                                                     # validate() flips the mode for good, :19
+                hb.refresh(force=True)                                         # weights (and in epoch 1 the running statistics) moved
+                self._forward_eval(all_x[Bs + Bm:], out=feats[Bs + Bm:])
+                for i in range(len(hb.nbt)):
+                    hb.nbt[i] += n_sets - 1
+                validate_only()
+            st = ses.state.cpu()
+            if not bool(st[1]):                                                # the loop reached epoch K: freeze (eval/util.py:62-69)
+                for n_, p_ in net.named_parameters():
+                    p_.requires_grad = n_.startswith("classifier")
+                self.backbone_frozen = True
+                self.p("Freezing the backbone.")
+                hb.refresh(force=True)
+        else:
+            # ---- epoch 1: TRAIN-mode support (+memory) forward (BN batch stats, running-stat update, masks), :252-258
+            self._forward(sx, train=True, out=feats[:Bs])
+            if Bm:
+                self._forward(mem_x, train=True, out=feats[Bs:Bs + Bm])
+            torch._foreach_add_([m.num_batches_tracked for m in net._bns], 1 + (1 if Bm else 0))     # one launch, not one per BatchNorm
+            net.eval()                                                             # validate() flips the mode for good, :19
+            hb.refresh()                                                           # BN running statistics moved: fold once
+            self._forward_eval(all_x[Bs + Bm:], out=feats[Bs + Bm:])
+            for i in range(len(hb.nbt)):
+                hb.nbt[i] += n_sets - 1
+            step_and_validate()
         # ---- epochs >= 2: eval mode, one batched forward per epoch.  The forward is identical every epoch (frozen
         #      backbone, constant inputs): after one eager pass its launch sequence is captured into a hipGraph and
         #      replayed - every epoch still executes all 22 convolutions, only the host-side launches are saved.

@@ -208,14 +208,16 @@ class ResNet(nn.Module):
         hb = self.hip_backbone()
         if torch.is_grad_enabled() and any(p.requires_grad for n, p in self.named_parameters()
                                            if not n.startswith("classifier")):
-            # pretraining path (train_supervised.py:229-244): forward with a stash, backward on the HIP kernels
-            if not self.training or return_stages:
-                raise NotImplementedError("backbone gradients are built for train-mode forwards (model.train(), "
-                                          "train_supervised.py:207); freeze the backbone for eval-mode fine-tuning")
+            # pretraining path (train_supervised.py:229-244) and whole-network fine-tuning before freeze_backbone_at
+            # (eval/language_eval.py:242-295): forward with a stash, backward on the HIP kernels.  In eval mode (the fine-tuning
+            # loop after its first validate()) BatchNorm uses and keeps its running statistics and there is no dropout
+            if return_stages:
+                raise NotImplementedError("is_feat=True with a grad-requiring backbone: stage outputs are not kept for the backward")
             from .train import BackboneTrainFn
             names, params = zip(*[(n, p) for n, p in self.named_parameters() if not n.startswith("classifier")])
-            feat = BackboneTrainFn.apply(x, hb, self.mask_source, names, *params)
-            torch._foreach_add_([m.num_batches_tracked for m in self._bns], 1)      # one launch, not one per BatchNorm
+            feat = BackboneTrainFn.apply(x, hb, self.mask_source if self.training else "eval", names, *params)
+            if self.training:
+                torch._foreach_add_([m.num_batches_tracked for m in self._bns], 1)      # one launch, not one per BatchNorm
             return feat
         hb = self.hip_backbone()
         out = hb.forward(x.float(), train=self.training, masks=self.mask_source, return_stages=return_stages)

@@ -178,20 +178,28 @@ def conv_weight_versions(hb):
 
 
 class BackboneTrainFn(torch.autograd.Function):
-    """feat = backbone(x) in train mode; backward -> gradients of every backbone parameter (`names` order)."""
+    """feat = backbone(x) with a stash; backward -> gradients of every backbone parameter (`names` order).  masks is a MaskSource /
+    None for a TRAIN-mode forward (batch statistics, running-stat update, dropout / DropBlock), or the string "eval" for an
+    eval-mode forward (running statistics, no masks: whole-network fine-tuning before freeze_backbone_at with the model in eval
+    mode, eval/language_eval.py:242-295 after the first validate())."""
 
     @staticmethod
     def forward(ctx, x, hb, masks, names, *params):
         B, _, H, W = x.shape
         x = x.contiguous().float()
-        for i in range(len(hb.nbt)):
+        eval_mode = isinstance(masks, str) and masks == "eval"
+        for i in range(len(hb.nbt)):             # BasicBlock's own forward counter (resnet_language.py:269: every call, either mode)
             hb.nbt[i] += 1
         stash = getattr(hb, "_train_stash", None)
         if stash is None or stash.shape != (B, H, W):
             stash = TrainStash(hb, B, H, W)
         hb._train_stash = stash
         hb._ensure_workspace(B, H, W)
-        hb._prepare_masks(B, H, W, masks)
+        stash.desc.eval_mode = 1 if eval_mode else 0
+        if eval_mode:
+            hb._clear_masks()
+        else:
+            hb._prepare_masks(B, H, W, masks)
         # weights moved since the last step: every conv's raw forward copy and dX copy in ONE launch (the eval-mode folded
         # copies are not needed here and are rebuilt by the next eval-mode forward) - unless the optimiser's fused step
         # (SGD.step -> subreg_sgd_pack_train) already wrote them for exactly these weights

@@ -107,7 +107,7 @@ def build_case(g, dtype, embed_dir=None):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw84_M", "hw32_sem", "hw32_map", "hw84_noM_s8", "hw84_noM_disc",
-                                 "hw84_stop", "hw84_sem", "hw84_map", "hw32_adam", "hw32_bias"])
+                                 "hw84_stop", "hw84_sem", "hw84_map", "hw32_adam", "hw32_bias", "hw32_freeze3"])
 def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
     """hw84_noM_s8 is the bench-scale case (BASELINE.json configs[1]: 8 sessions, -M, 84x84, 1000-image base batch) with 6
     epochs per session, so the per-epoch hipGraph is captured and replayed and up to 1125 images go through one launch
@@ -118,7 +118,9 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
     bf16 gate on them is ONE query image.  hw84_sem / hw84_map: the semantic subspace regularizer and the linear-mapping target
     (scripts/continual/slurm_semantic_subspace_reg.sh, slurm_linear_mapping.sh) on the same kind of episodes at 84x84, 30 epochs,
     with the reference's own word vectors.  hw32_adam: `--adam` (eval/util.py:92-97, torch.optim.Adam instead of SGD), +M, 3 sessions.
-    hw32_bias: a classifier WITH bias (backbone pretrained without --no_linear_bias), +M, 3 sessions, no --lmbd_reg_novel."""
+    hw32_bias: a classifier WITH bias (backbone pretrained without --no_linear_bias), +M, 3 sessions, no --lmbd_reg_novel.
+    hw32_freeze3: freeze_backbone_at = 3 (language_eval.py:243, eval/util.py:62-69): epochs 1-2 of the first session fine-tune
+    the WHOLE network (train mode, then eval mode), the backbone freezes at epoch 3; the golden pins what the backbone became."""
     from subreg_hip.incremental import few_shot_finetune_incremental_test
     g = np.load(os.path.join(GOLDEN, "loop_%s.npz" % tag))
     net, opt, meta, base_loader, bsl, inits, picks = build_case(g, dtype, str(tmp_path / "word_embeds"))
@@ -191,6 +193,25 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
         # (a stop rule that fires an epoch or two apart under bf16 moves the base accuracy with it: three images there)
         _cmp("base acc per session", run["acc_base"], want_b,
              1e-6 if f32 else (300.0 if data_dependent_stop else 200.0) / int(g["n_base_batch"]) + 1e-6, 0)
+    if "final.requires_grad" in g.files:
+        # the backbone was fine-tuned before the freeze: its parameters must have moved exactly as far, and be frozen now
+        assert [int(p.requires_grad) for n, p in net.named_parameters() if not n.startswith("classifier")] == list(g["final.requires_grad"])
+        assert net.classifier.weight.requires_grad
+        sd0, sdn = syn.make_state_dict(int(g["sd_seed"])), net.state_dict()
+        for k in g.files:
+            if not k.startswith("final_delta_norm."):
+                continue
+            name = k[len("final_delta_norm."):]
+            got = sdn[name].detach().cpu().numpy()
+            moved = float(np.linalg.norm((got - sd0[name]).astype(np.float64)))
+            want_moved = float(g[k])
+            assert want_moved > 0
+            assert abs(moved - want_moved) <= (2e-3 if f32 else 0.25) * want_moved, (name, moved, want_moved)
+            want = g["final." + name]
+            # f32: element-wise on the update itself (the weights moved by ~1e-5 per element: compare the DIFFERENCE to the start)
+            d_got, d_want = (got[:want.shape[0]] - sd0[name][:want.shape[0]]).astype(np.float64), (want - sd0[name][:want.shape[0]]).astype(np.float64)
+            l2 = float(np.linalg.norm(d_got - d_want) / max(np.linalg.norm(d_want), 1e-30))
+            assert l2 < (1e-2 if f32 else 0.5), ("backbone update", name, l2)
     if f32:
         _cmp("novel avg", novel_avg, g["novel_avg"], 1e-5, 1e-6)
         _cmp("base avg", base_avg, g["base_avg"], 1e-5, 1e-6)

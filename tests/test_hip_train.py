@@ -593,3 +593,39 @@ def test_adam_step_matches_torch_optim_adam():
     torch.cuda.synchronize()
     for k, (pr, pd) in enumerate(zip(ref, dut)):
         _cmp("adam tensor %d" % k, pd.detach().cpu().numpy(), pr.detach().numpy(), 2e-7, 2e-6)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_eval_mode_backbone_gradients_against_oracle(dtype):
+    """Whole-network fine-tuning with the model in EVAL mode (eval/language_eval.py:242-295 before `freeze_backbone_at`, after the
+    first validate() put the model into eval mode): BatchNorm normalises with its running statistics (and does not update them),
+    there is no dropout, every parameter still gets a gradient.  Against torch autograd on CPU (oracle/torch_ref.py, eval_mode)."""
+    from oracle import torch_ref
+    net = _train_net(dtype)
+    sd = syn.make_state_dict(71)
+    B, hw = 5, 32
+    x = syn.make_images(91, B, hw)
+    labels = np.random.RandomState(92).randint(0, 60, B).astype(np.int64)
+    net.eval()
+    rm0 = net.state_dict()["layer2.0.bn2.running_mean"].clone()
+    logits = net(torch.from_numpy(x).cuda())
+    loss = torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(labels).cuda())
+    loss.backward()
+    f32 = dtype == "f32"
+    loss_o, go = torch_ref.train_step_grads(sd, x, labels, None, bf16=not f32, eval_mode=True)
+    _cmp("loss", loss.item(), loss_o, 2e-4 if f32 else 2e-2, 2e-4 if f32 else 5e-3)
+    assert torch.equal(net.state_dict()["layer2.0.bn2.running_mean"], rm0)                  # eval mode: statistics untouched
+    assert int(net.state_dict()["layer1.0.bn1.num_batches_tracked"]) == 0
+    for name, p in net.named_parameters():
+        a, b = p.grad.detach().cpu().numpy().astype(np.float64).ravel(), go[name].astype(np.float64).ravel()
+        l2 = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+        if f32:
+            assert l2 < 1.5e-2, ("l2", name, l2)
+        else:
+            cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-30))
+            weight_like = ".conv" in name or "downsample.0" in name or name.startswith("classifier")
+            assert cos > (0.91 if weight_like else 0.87) and l2 < (0.45 if weight_like else 0.55), ("bf16 oracle", name, cos, l2)
+    # the eval-mode forward with a stash gives the features the plain eval-mode forward gives
+    with torch.no_grad():
+        ref_logits = net(torch.from_numpy(x).cuda())
+    _cmp("logits", logits.detach().cpu().numpy(), ref_logits.cpu().numpy(), 1e-4 if f32 else 5e-2, 1e-4 if f32 else 2e-2)

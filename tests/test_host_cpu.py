@@ -61,7 +61,7 @@ def test_struct_layouts_match_c():
     assert ctypes.sizeof(_lib.StepDesc) == 272
     # offsetof(subreg_train_desc, side_stream / dr_alt / stats_side), sizeof
     assert (_lib.TrainDesc.side_stream.offset, _lib.TrainDesc.dr_alt.offset, _lib.TrainDesc.stats_side.offset) == (96, 152, 168)
-    assert ctypes.sizeof(_lib.TrainDesc) == 192 and _lib.TrainDesc.splitk_ws.offset == 176
+    assert ctypes.sizeof(_lib.TrainDesc) == 200 and _lib.TrainDesc.splitk_ws.offset == 176 and _lib.TrainDesc.eval_mode.offset == 192
 
 
 def test_conv_tiling_index_emulation():

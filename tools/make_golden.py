@@ -469,6 +469,14 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False
     for k in ("layer1.0.bn1", "layer4.1.bn3"):
         m = dict(net.named_modules())[k]
         out[k + ".running_mean"], out[k + ".running_var"] = t2n(m.running_mean), t2n(m.running_var)
+    if int(opt.freeze_backbone_at) != 1:         # the backbone was fine-tuned before the freeze: pin what it became
+        sdf = net.state_dict()
+        for k in ("layer1.0.conv1.weight", "layer2.0.bn2.weight", "layer2.0.bn2.bias", "layer3.1.conv2.weight", "layer4.0.downsample.0.weight",
+                  "layer4.1.conv3.weight", "layer4.1.bn3.bias"):
+            full = t2n(sdf[k])
+            out["final." + k] = full if full.size <= 50000 else full[:2]          # (large tensors: the first two output channels ...)
+            out["final_delta_norm." + k] = np.array(np.linalg.norm((full - np.asarray(sd[k])).astype(np.float64)))   # ... and how far all of it moved
+        out["final.requires_grad"] = np.array([int(p.requires_grad) for n, p in net.named_parameters() if not n.startswith("classifier")])
     np.savez_compressed(os.path.join(GOLD, "loop_%s.npz" % tag), **out)
     print("loop_%s.npz" % tag, {k: v for k, v in out.items() if k.endswith("epochs")})
 
@@ -592,6 +600,10 @@ def main():
     if "adam" in what:
         # --adam (eval/util.py:92-97: torch.optim.Adam(lr, weight_decay=0.0005) instead of SGD), +M, three sessions
         gen_loop("hw32_adam", 32, 3, True, 40, seed=13, max_novel_epochs=5, adam=True)
+    if "freeze" in what:
+        # freeze_backbone_at = 3 (language_eval.py:243-249, eval/util.py:62-69): epochs 1-2 of the first session fine-tune the WHOLE
+        # network (epoch 1 in train mode, epoch 2 in eval mode: validate() leaves the model there), the backbone freezes at epoch 3
+        gen_loop("hw32_freeze3", 32, 2, False, 40, seed=15, max_novel_epochs=6, freeze_backbone_at=3)
     if "bias" in what:
         # classifier WITH bias (a backbone pretrained without --no_linear_bias; eval_incremental.py:96-103 reads it off the
         # checkpoint), +M, three sessions.  --lmbd_reg_novel must be absent: with a bias the reference's reglossnovel
