@@ -40,6 +40,9 @@
 #ifndef SUBREG_BF16_MFMA16
 #define SUBREG_BF16_MFMA16 1     // 1: v_mfma_f32_16x16x32_bf16 where mfma_tile() says so, 0: v_mfma_f32_32x32x16_bf16 everywhere
 #endif
+#ifndef SUBREG_B_RING
+#define SUBREG_B_RING 3          // depth of the B-fragment register ring of the big wave tiles (reads run SUBREG_B_RING - 1 column tiles ahead)
+#endif
 #ifndef SUBREG_EARLY_READS
 #define SUBREG_EARLY_READS 1     // 1: a step's first fragment reads are issued before its DMAs (see EARLY in the kernel)
 #endif
@@ -431,29 +434,34 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
             for (int kk = 0; kk < NKE; ++kk) {
                 if (WK > 1 && ((step * NK + kk) % WK) != wave_k) continue;    // the partner wave's k-step
                 const int s = kk % KSTEPS;
-                uint4 fa[MI], fb[3];
+                constexpr int RD = SUBREG_B_RING;                 // B-fragment ring: each read is issued RD - 1 column tiles ahead of its use
+                uint4 fa[MI], fb[RD];
                 auto rd_a = [&](int i) { fa[i] = *reinterpret_cast<const uint4*>(smem + aoff + (aaddr(i, a_tap(kk)) ^ (KX * s))); };
                 if (EARLY && kk == 0) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i) fa[i] = e_fa[i];
                     fb[0] = e_fb[0];
                     if (MJ > 1) fb[1] = e_fb[1];
+#pragma unroll
+                    for (int j = 2; j < RD - 1 && j < MJ; ++j) fb[j] = load_b1(kk, j);
+                    if (RD > 3) __builtin_amdgcn_sched_group_barrier(0x100, RD - 3, 0);
                 } else {
                     rd_a(0);
                     fb[0] = load_b1(kk, 0);
 #pragma unroll
                     for (int i = 1; i < MI; ++i) rd_a(i);
-                    if (MJ > 1) fb[1] = load_b1(kk, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x100, MI + (MJ > 1 ? 2 : 1), 0);
+#pragma unroll
+                    for (int j = 1; j < RD - 1 && j < MJ; ++j) fb[j] = load_b1(kk, j);
+                    __builtin_amdgcn_sched_group_barrier(0x100, MI + (MJ < RD - 1 ? MJ : RD - 1), 0);
                 }
 #pragma unroll
                 for (int j = 0; j < MJ; ++j) {
-                    if (j + 2 < MJ) {
-                        fb[(j + 2) % 3] = load_b1(kk, j + 2);
+                    if (j + RD - 1 < MJ) {
+                        fb[(j + RD - 1) % RD] = load_b1(kk, j + RD - 1);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) mma_ab(fa[i], fb[j % 3], acc[i][j]);
+                    for (int i = 0; i < MI; ++i) mma_ab(fa[i], fb[j % RD], acc[i][j]);
                     __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
                 }
             }
