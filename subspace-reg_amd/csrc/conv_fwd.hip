@@ -236,7 +236,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     static_assert(RPP % 16 == 0 || sizeof(T) == 4, "bf16: the swizzle of a piece row does not depend on the piece");
     auto patch_piece_fast = [&](const char* src, unsigned uoff, unsigned xrow, int q, int buf, unsigned pv, unsigned pv_last) {
         const unsigned so = rfl(uoff + (unsigned)(q * RPP) * xrow);
-        dma16(src, (q == apieces - 1 ? pv_last : pv) + so, lds_base + buf * ABUF + q * 1024);
+        if constexpr (MINW >= 3) {
+            // three waves per SIMD (168 registers): the two per-lane values are re-made per piece (4 VALU instructions) instead of
+            // being held through the chunk - held, the kernel spills five dwords to scratch
+            int prl_o = lane / SLOTS;
+            asm volatile("" : "+v"(prl_o));
+            const int lim = q == apieces - 1 ? prow - 1 - (apieces - 1) * RPP : RPP;
+            dma16(src, (unsigned)(prl_o < lim ? prl_o : lim) * xrow + swz_off(prl_o) + so, lds_base + buf * ABUF + q * 1024);
+        } else {
+            dma16(src, (q == apieces - 1 ? pv_last : pv) + so, lds_base + buf * ABUF + q * 1024);
+        }
     };
     // per-lane source offset of weight piece q of a (tap, chunk) tile: output channel row, swizzled slot (N tail: those output
     // columns are never stored)
@@ -483,7 +492,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
         const unsigned puoff = nsecond ? porg1 + (unsigned)(c + 1 - nch0) * (32 * ELEM) : porg0 + (unsigned)(c + 1) * (32 * ELEM);
         const int np = more ? apieces : 0;                            // patch pieces to stage during this chunk
         unsigned pv = 0, pv_last = 0;                                 // per-lane parts of the patch source addresses (patch waves)
-        if (has_p) {
+        if (has_p && MINW < 3) {
             int prl_o = prl;
             asm volatile("" : "+v"(prl_o));                           // (opaque: keeps the two values out of the loop-invariant set)
             const int lim = prow - 1 - (apieces - 1) * RPP;           // last valid row of the last piece

@@ -13,7 +13,7 @@ G="grep -v amdgpu.ids"
 #     (SUBREG_EVAL_LANES=1): with two lanes kernels of both lanes overlap and per-kernel durations are inflated; with one lane
 #     sum(kernel time of the forward kernels) / images reproduces roofline.frac of ITS OWN bench line (bench_lanes1.json)
 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
-SUBREG_EVAL_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_bench -o b -- python3 $R/bench.py --no-cpu-baseline --sweep-seeds 0 > $O/bench_lanes1.json 2> /dev/null
+SUBREG_EVAL_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_bench -o b -- python3 $R/bench.py --no-cpu-baseline --sweep-seeds 0 --no-extra-legs > $O/bench_lanes1.json 2> /dev/null
 f=$(find /tmp/ev_bench -name "*kernel_stats.csv" | head -1); cut -c1-140 "$f" > $O/kernel_stats.csv
 f=$(find /tmp/ev_bench -name "*kernel_trace.csv" | head -1); python3 $R/tools/prof_summary.py "$f" --top 25 --conv > $O/kernel_summary.txt 2>&1
 # --- per-layer conv table (HIP events, random data, 20 back-to-back launches per layer)
