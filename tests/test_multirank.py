@@ -223,3 +223,16 @@ def test_pretrain_gradient_sync_two_ranks_on_device():
     p = subprocess.run([sys.executable, os.path.join(repo, "tools", "dp_pretrain_check.py")], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "EQUIVALENT" in p.stdout and "MISMATCH" not in p.stdout
+
+
+def test_sweep_speedup_from_measured_seed_times():
+    """sweep.sweep_speedup_measured: the 10-seed plan's speed-up from measured seed-run times by group size (bench.py::sweep_model)."""
+    ms = {1: 4000.0, 2: 2200.0, 4: 1400.0, 8: 900.0}
+    assert sweep.sweep_speedup_measured(10, 1, ms) == pytest.approx(1.0)
+    assert sweep.sweep_speedup_measured(10, 2, ms) == pytest.approx(2.0)                     # five full rounds of two seeds
+    assert sweep.sweep_speedup_measured(10, 8, ms) == pytest.approx(10 * 4000.0 / (4000.0 + 1400.0))   # 8 x 1 rank, then 2 seeds x 4 ranks
+    assert sweep.sweep_speedup_measured(10, 4, ms) == pytest.approx(10 * 4000.0 / (2 * 4000.0 + 2200.0))   # two full rounds, then 2 seeds x 2 ranks
+    # with perfect sharding (time / g) the measured form equals the efficiency-1 model
+    perfect = {g: 4000.0 / g for g in (1, 2, 4, 8)}
+    for w in (2, 4, 8):
+        assert sweep.sweep_speedup_measured(10, w, perfect) == pytest.approx(sweep.sweep_speedup(10, w, dp_efficiency=1.0))
