@@ -45,6 +45,11 @@ __device__ float r64_diag[4096 * 12];   // [workgroup * 8 + wave][8]: tiles, set
 __device__ __attribute__((aligned(128))) unsigned r64_zero_line[32];
 
 constexpr int R64_P = 96;            // LDS rows per image row of the patch (W + 1 <= P, multiple of 16)
+constexpr int R64_PF = R64_P;        // ... in conv64_fused_first_kernel.  (Its planes are written by conv1, not by 16-row DMA pieces, but P must
+                                     // still be a multiple of 16: a tap's dy is an IMMEDIATE offset of dy * P rows on an address whose swizzle
+                                     // was computed for the dy = 0 row, so swz(row + P) has to equal swz(row).  P = 100 would keep a tile that
+                                     // crosses an image-row boundary conflict-free - and read the wrong slots; no 4-valued row swizzle with a
+                                     // period dividing P serves both, tests/test_host_cpu.py::test_layer1_plane_swizzle_emulation.)
 constexpr int R64_ROWB = 64;         // bytes per LDS row (32 bf16 channels)
 constexpr int R64_NW = 8;            // waves per workgroup
 
@@ -474,6 +479,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
 // Pipeline per iteration (tile T): [DMA fp32 patch of T+2] -> [conv1 of T+1 from the bf16 patch into the other plane pair] ->
 // [conv2 chunks of T from this pair, epilogue] -> barrier -> [convert the fp32 patch of T+2 to bf16] -> barrier.  Four planes
 // (two pairs), so conv1 of the next tile has no dependency on this tile's reads.  LINEAR tiles only (conv2 is not pooled).
+constexpr int R64_FUSED_LDS = 4 * (5 * R64_PF * R64_ROWB) + 3 * 7 * 96 * 4 + 7 * (96 + 4) * 8 + 6 * 64 * 16 + (4096 + 256) + 256;
 struct Conv64FusedArgs {
     const float* img;    // [B][3][H][W] fp32
     const char* w1;      // [64][32] bf16, k = 3 tap + c, BN scale folded (subreg_pack_conv_weight mode 1)
@@ -486,14 +492,15 @@ struct Conv64FusedArgs {
 };
 
 __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(const Conv64FusedArgs a) {
-    constexpr int P = R64_P, BLOCKS = 5, PROWS = BLOCKS * P, PLANE = PROWS * R64_ROWB;
+    constexpr int P = R64_PF, BLOCKS = 5, PROWS = BLOCKS * P, PLANE = PROWS * R64_ROWB;
     constexpr int XROWS = BLOCKS + 2;                                   // image rows under a tile's 5 conv1 rows
     constexpr int XF_BASE = 4 * PLANE, XF_BYTES = 3 * XROWS * 96 * 4;   // fp32 patch [c][row][x], DMA target
     constexpr int X4_BASE = XF_BASE + XF_BYTES, X4_ROW = (96 + 4) * 8, X4_BYTES = XROWS * X4_ROW;   // bf16 patch [row][x + 2][4]
     constexpr int WF_BASE = X4_BASE + X4_BYTES, WF_BYTES = 6 * 64 * 16; // conv1 A fragments [i][s][lane]
-    constexpr int SLAB_RS = 32 * 2 + 16, SLAB = 32 * SLAB_RS;
-    constexpr int SLAB_BASE = WF_BASE + WF_BYTES, SHIFT_BASE = SLAB_BASE + R64_NW * SLAB;
-    static_assert(SHIFT_BASE + 256 <= 160 * 1024, "LDS budget");
+    constexpr int SCR_BASE = WF_BASE + WF_BYTES, SCR_BYTES = 4096 + 256; // set-up scratch: conv1's packed weights + its BN shift
+    constexpr int SHIFT_BASE = SCR_BASE + SCR_BYTES;
+    static_assert(SHIFT_BASE + 256 <= 160 * 1024 && SHIFT_BASE + 256 == R64_FUSED_LDS, "LDS budget");
+    static_assert(PLANE % 16 == 0 && 2 * P * R64_ROWB < 65536, "plane bases are 16-byte aligned; tap offsets are 16-bit immediates");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -524,11 +531,11 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
     for (int o = tid * 8; o < X4_BYTES; o += R64_NW * 64 * 8) *reinterpret_cast<uint2*>(smem + X4_BASE + o) = make_uint2(0u, 0x3F800000u);
     float* const s_shift = reinterpret_cast<float*>(smem + SHIFT_BASE);
     if (tid < 64) s_shift[tid] = a.shift[tid];
-    // conv1's A fragments through the (still idle) slab region: fragment (i, s), lane (r, h) holds k' = 16 s + 8 h + j of output
+    // conv1's A fragments through the set-up scratch: fragment (i, s), lane (r, h) holds k' = 16 s + 8 h + j of output
     // channel 32 i + r, k' = 4 tap + c; c = 3: the BN shift (tap 4: bf16 hi part, tap 3: lo part) against the constant-1 channel
     {
-        __bf16* const wl = reinterpret_cast<__bf16*>(smem + SLAB_BASE);
-        float* const sh1 = reinterpret_cast<float*>(smem + SLAB_BASE + 4096);
+        __bf16* const wl = reinterpret_cast<__bf16*>(smem + SCR_BASE);
+        float* const sh1 = reinterpret_cast<float*>(smem + SCR_BASE + 4096);
         if (tid < 256) reinterpret_cast<uint4*>(wl)[tid] = reinterpret_cast<const uint4*>(a.w1)[tid];
         if (tid < 64) sh1[tid] = a.shift1[tid];
         __syncthreads();
@@ -689,11 +696,19 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
         // conv1 of the next tile needs nothing from this tile (its own plane pair, its own patch): the two waves of a SIMD (w and
         // w + 4) run it at opposite ends of the tile, so one wave's VALU / LDS-heavy conv1 phase meets its partner's MFMA chunks
         if (R64_CUT != 3 && more && (wid < 4 || !R64_FUSED_STAGGER)) conv1_tile(nk, pp ^ 1);
+        // conv2 runs with SWAPPED MFMA operands (A = the resident weights, B = the pixel fragments): lane (lr, lh) then holds pixel lr
+        // of a row tile and register r holds channel 32 wh + (r & 3) + 8 (r >> 2) + 4 lh - four consecutive channels per four
+        // registers, which is what the LDS-free epilogue below needs.  The accumulators start from the BN shift (LDS reads that
+        // complete under the chunk's own entry wait) instead of zero.
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(smem + SHIFT_BASE + (32 * wh + 8 * q + 4 * lh) * 4);
+                acc[i][4 * q] = v.x; acc[i][4 * q + 1] = v.y; acc[i][4 * q + 2] = v.z; acc[i][4 * q + 3] = v.w;
+            }
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));                 // (the loads are complete before the hand-counted LDS reads start)
         auto chunk = [&](int pl, auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int NRD = 36, RD = R64_DEPTH;
@@ -718,34 +733,37 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
                 constexpr int left = NRD - 1 - j;
                 u32x4 f = ring[j % RD];
                 if (R64_CUT != 2) f = lds_wait<(left >= RD - 1 ? RD - 1 : left)>(f);
-                if (R64_CUT != 1) acc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f),
-                                                                      __builtin_bit_cast(bf16x8, bw[c][j >> 2][(j >> 1) & 1]), acc[j & 1], 0, 0, 0);
+                if (R64_CUT != 1) acc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw[c][j >> 2][(j >> 1) & 1]),
+                                                                      __builtin_bit_cast(bf16x8, f), acc[j & 1], 0, 0, 0);
             });
         };
         chunk(2 * pp, std::integral_constant<int, 0>{});
         chunk(2 * pp + 1, std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
-        // ---- epilogue (LINEAR): + shift, LeakyReLU, bf16 through this wave's slab, 16-byte stores
-        char* const slab = smem + SLAB_BASE + wid * SLAB;
-        const float sh = s_shift[32 * wh + lr];
+        // ---- epilogue (LINEAR), no LDS: LeakyReLU, bf16 pairs, then v_permlane32_swap hands the upper lane's channels +4..7 of each
+        //      group of 16 to the lower lane and the lower lane's +8..11 to the upper one: every lane stores 16 bytes = 8 consecutive
+        //      channels of its pixel (a store instruction = 32 pixel rows x 32 contiguous bytes)
         const int rows_left = a.H - k_img * a.R, nvalid = (rows_left < a.R ? rows_left : a.R) * W;
         const long long pix0 = ((long long)b * a.H + (long long)k_img * a.R) * W;
+        const float slope = a.act ? 0.1f : 1.f;
+        auto lrelu2 = [&](float x0, float x1) -> unsigned {
+            float y0, y1;
+            asm("v_max_f32 %0, %1, %2" : "=v"(y0) : "v"(x0), "v"(x0 * slope));   // (fmaxf would add a canonicalising v_max per value)
+            asm("v_max_f32 %0, %1, %2" : "=v"(y1) : "v"(x1), "v"(x1 * slope));
+            return r64_pack(y0, y1);
+        };
 #pragma unroll
         for (int i = 0; i < (R64_CUT == 4 ? 0 : 2); ++i) {
-            const int jrow0 = wm * 64 + i * 32;
+            const int jrow = wm * 64 + i * 32 + lr;
+            char* const yrow = a.y + (size_t)(pix0 + jrow) * 128 + wh * 64 + lh * 16;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[i][r] + sh;
-                if (a.act) v = fmaxf(v, v * 0.1f);
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                *reinterpret_cast<__bf16*>(slab + row * SLAB_RS + lr * 2) = (__bf16)v;
-            }
-#pragma unroll
-            for (int v0 = 0; v0 < 128; v0 += 64) {
-                const int v = v0 + lane, row = v >> 2, c16 = v & 3;
-                const uint4 val = *reinterpret_cast<const uint4*>(slab + row * SLAB_RS + c16 * 16);
-                if (jrow0 + row < nvalid)
-                    *reinterpret_cast<uint4*>(a.y + (size_t)(pix0 + jrow0 + row) * 128 + wh * 64 + c16 * 16) = val;
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const unsigned p0 = lrelu2(acc[i][8 * g2], acc[i][8 * g2 + 1]), p1 = lrelu2(acc[i][8 * g2 + 2], acc[i][8 * g2 + 3]);
+                const unsigned p2 = lrelu2(acc[i][8 * g2 + 4], acc[i][8 * g2 + 5]), p3 = lrelu2(acc[i][8 * g2 + 6], acc[i][8 * g2 + 7]);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(p0, p2, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(p1, p3, false, false);
+                const u32x4 vec = {s0[0], s1[0], s0[1], s1[1]};
+                if (jrow < nvalid) *reinterpret_cast<u32x4*>(yrow + g2 * 32) = vec;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1119,7 +1137,7 @@ static int launch_r64(const Conv64Args& a, hipStream_t stream) {
 
 // conv1 + conv2 of layer1.0 fused (eval mode, bf16): SUBREG_EUNSUPPORTED for shapes outside the kernel's LDS plan.
 bool conv64_fused_first_supported(int B, int H, int W) {
-    return W % 4 == 0 && W >= 80 && W + 1 <= R64_P && H >= 2 && 256 / W == 3 && (long long)B * H * W < (1LL << 26);
+    return W % 4 == 0 && W >= 80 && W + 1 <= R64_PF && W <= 96 && H >= 2 && 256 / W == 3 && (long long)B * H * W < (1LL << 26);
 }
 int conv64_fused_first(const float* img, const void* w1, const float* shift1, const void* w2, const float* shift2, void* y, int B, int H,
                        int W, int act, hipStream_t stream) {
@@ -1132,7 +1150,7 @@ int conv64_fused_first(const float* img, const void* w1, const float* shift1, co
     a.ntiles = B * a.tpi;
     a.d_w = make_fastdiv(W);
     a.d_tpi = make_fastdiv(a.tpi);
-    constexpr size_t lds = 4 * (size_t)(5 * R64_P * R64_ROWB) + 3 * 7 * 96 * 4 + 7 * (96 + 4) * 8 + 6 * 64 * 16 + R64_NW * 32 * (32 * 2 + 16) + 256;
+    constexpr size_t lds = R64_FUSED_LDS;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static std::atomic<unsigned long long> lds_set{0};
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv64_fused_first_kernel), lds, lds_set)) return rc;
