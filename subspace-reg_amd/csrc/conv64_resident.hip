@@ -30,6 +30,9 @@ namespace subreg {
 #ifndef R64_FUSED_STAGGER
 #define R64_FUSED_STAGGER 1     // conv64_fused_first_kernel: waves 4-7 run conv1 of the next tile AFTER their conv2 chunks (0: all waves first)
 #endif
+#ifndef R64_FUSED_PRIO
+#define R64_FUSED_PRIO 1        // conv64_fused_first_kernel: s_setprio around the conv2 chunks (see there)
+#endif
 #ifndef R64_CUT
 #define R64_CUT 0       // conv64_fused_first_kernel, timing experiments only (WRONG results): leave one component out -
                         // 1 conv2's MFMAs, 2 conv2's A-fragment reads, 3 conv1, 4 the epilogue, 5 image DMA + patch conversion
@@ -476,10 +479,11 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
 // riding on the constant-1 channel, fragments kept in LDS) produces the 5 x W x 64 block straight into the swizzled, zero-bordered
 // plane layout the register-resident conv2 reads.  Extra MFMA work: 48 / 576 x 5 / 3 = 14 % of conv2's; HBM traffic of the pair:
 // 12 B + 128 B per pixel instead of 12 + 128 + 128 + 128.
-// Pipeline per iteration (tile T): [DMA fp32 patch of T+2] -> [conv1 of T+1 from the bf16 patch into the other plane pair] ->
-// [conv2 chunks of T from this pair, epilogue] -> barrier -> [convert the fp32 patch of T+2 to bf16] -> barrier.  Four planes
-// (two pairs), so conv1 of the next tile has no dependency on this tile's reads.  LINEAR tiles only (conv2 is not pooled).
-constexpr int R64_FUSED_LDS = 4 * (5 * R64_PF * R64_ROWB) + 3 * 7 * 96 * 4 + 7 * (96 + 4) * 8 + 6 * 64 * 16 + (4096 + 256) + 256;
+// Pipeline per iteration (tile T): [DMA fp32 patch rows of T+2] -> [conv1 of T+1 from its bf16 patch into the other plane pair] ->
+// [conv2 chunks of T from this pair, epilogue] -> [every wave converts the patch row it fetched itself into the other bf16 patch
+// buffer] -> ONE barrier.  Four planes (two pairs) and two bf16 patch buffers, so conv1 of the next tile has no dependency on this
+// tile's reads.  LINEAR tiles only (conv2 is not pooled).
+constexpr int R64_FUSED_LDS = 4 * (5 * R64_PF * R64_ROWB) + 7 * 1024 + 2 * 7 * (96 + 4) * 8 + 6 * 64 * 16 + (4096 + 256) + 256;
 struct Conv64FusedArgs {
     const float* img;    // [B][3][H][W] fp32
     const char* w1;      // [64][32] bf16, k = 3 tap + c, BN scale folded (subreg_pack_conv_weight mode 1)
@@ -494,8 +498,8 @@ struct Conv64FusedArgs {
 __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(const Conv64FusedArgs a) {
     constexpr int P = R64_PF, BLOCKS = 5, PROWS = BLOCKS * P, PLANE = PROWS * R64_ROWB;
     constexpr int XROWS = BLOCKS + 2;                                   // image rows under a tile's 5 conv1 rows
-    constexpr int XF_BASE = 4 * PLANE, XF_BYTES = 3 * XROWS * 96 * 4;   // fp32 patch [c][row][x], DMA target
-    constexpr int X4_BASE = XF_BASE + XF_BYTES, X4_ROW = (96 + 4) * 8, X4_BYTES = XROWS * X4_ROW;   // bf16 patch [row][x + 2][4]
+    constexpr int XF_BASE = 4 * PLANE, XF_BYTES = XROWS * 1024;         // fp32 patch: ONE 1 KB DMA piece per image row, [c][x] (3 W <= 256 floats)
+    constexpr int X4_BASE = XF_BASE + XF_BYTES, X4_ROW = (96 + 4) * 8, X4_BUF = XROWS * X4_ROW, X4_BYTES = 2 * X4_BUF;   // bf16 patch [2][row][x + 2][4]
     constexpr int WF_BASE = X4_BASE + X4_BYTES, WF_BYTES = 6 * 64 * 16; // conv1 A fragments [i][s][lane]
     constexpr int SCR_BASE = WF_BASE + WF_BYTES, SCR_BYTES = 4096 + 256; // set-up scratch: conv1's packed weights + its BN shift
     constexpr int SHIFT_BASE = SCR_BASE + SCR_BYTES;
@@ -567,28 +571,30 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
     };
     // ---- fp32 patch by LDS-DMA: XF = [c][row r][x] floats, r = 0..6 <-> image row R k - 2 + r; piece q = floats [256 q, +256)
     const size_t plane_px = (size_t)a.H * W;
-    const int xf_floats = 3 * XROWS * W, xf_pieces = (xf_floats + 255) >> 8;
+    // One piece per image row r of the patch, issued by wave r: lane l brings floats 4 l .. 4 l + 3 of [c][x] (c = 4 l / W; W % 4 == 0, so a
+    // float4 never straddles two channel rows).  The wave that issued a row's piece is also the one that converts it (convert_row, after its
+    // own vmcnt wait): no workgroup barrier stands between the DMA and the conversion.
+    const int dq_c = (4 * lane) / W, dq_x = 4 * lane - dq_c * W;
+    const bool dq_in = 4 * lane < 3 * W;
+    const unsigned dq_off = (unsigned)((size_t)dq_c * plane_px + (size_t)dq_x);                      // < 3 B H W < 2^28 floats
     auto dma_patch = [&](int b, int k_img) {
-        for (int q = wid; q < xf_pieces; q += R64_NW) {
-            const int idx = q * 256 + lane * 4;
-            const int c = idx / (XROWS * W), rem = idx - c * (XROWS * W), r = rem / W, x = rem - r * W;
-            const int h = a.R * k_img - 2 + r;
-            const bool ok = idx < xf_floats && h >= 0 && h < a.H;
-            const char* src = ok ? reinterpret_cast<const char*>(a.img + ((size_t)b * 3 + c) * plane_px + (size_t)h * W + x)
+        if (wid < XROWS) {
+            const int h = a.R * k_img - 2 + wid;
+            const bool ok = dq_in && h >= 0 && h < a.H;
+            const char* src = ok ? reinterpret_cast<const char*>(a.img + (size_t)b * 3 * plane_px + dq_off + (unsigned)(h * W))
                                  : reinterpret_cast<const char*>(r64_zero_line);
-            dma16_far(src, lds_base + XF_BASE + q * 1024);
+            dma16_far(src, lds_base + XF_BASE + wid * 1024);
         }
     };
-    // ---- fp32 patch -> bf16 [row][x + 2][c0 c1 c2 1]: item = (row, float4 column)
-    auto convert_patch = [&]() {
-        const int items = XROWS * W4;
-        for (int it = tid; it < items; it += R64_NW * 64) {
-            const int r = it / W4, j = it - r * W4;
-            const float4 v0 = *reinterpret_cast<const float4*>(smem + XF_BASE + ((0 * XROWS + r) * W + 4 * j) * 4);
-            const float4 v1 = *reinterpret_cast<const float4*>(smem + XF_BASE + ((1 * XROWS + r) * W + 4 * j) * 4);
-            const float4 v2 = *reinterpret_cast<const float4*>(smem + XF_BASE + ((2 * XROWS + r) * W + 4 * j) * 4);
+    // ---- fp32 row -> bf16 [row][x + 2][c0 c1 c2 1] of patch buffer `buf`: wave r, lane j = float4 column of its own row
+    auto convert_row = [&](int buf) {
+        if (wid < XROWS && lane < W4) {
+            const char* const xr = smem + XF_BASE + wid * 1024;
+            const float4 v0 = *reinterpret_cast<const float4*>(xr + (0 * W + 4 * lane) * 4);
+            const float4 v1 = *reinterpret_cast<const float4*>(xr + (1 * W + 4 * lane) * 4);
+            const float4 v2 = *reinterpret_cast<const float4*>(xr + (2 * W + 4 * lane) * 4);
             const unsigned one = 0x3F800000u;
-            uint4* dst = reinterpret_cast<uint4*>(smem + X4_BASE + r * X4_ROW + (4 * j + 2) * 8);
+            uint4* dst = reinterpret_cast<uint4*>(smem + X4_BASE + buf * X4_BUF + wid * X4_ROW + (4 * lane + 2) * 8);
             dst[0] = make_uint4(r64_pack(v0.x, v1.x), (r64_pack(v2.x, 0.f) & 0xffffu) | one, r64_pack(v0.y, v1.y), (r64_pack(v2.y, 0.f) & 0xffffu) | one);
             dst[1] = make_uint4(r64_pack(v0.z, v1.z), (r64_pack(v2.z, 0.f) & 0xffffu) | one, r64_pack(v0.w, v1.w), (r64_pack(v2.w, 0.f) & 0xffffu) | one);
         }
@@ -604,7 +610,15 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
             tap = tap < 9 ? tap : 8;
             toff[s][u] = (tap / 3) * X4_ROW + (tap % 3) * 8;
         }
-    auto conv1_tile = [&](int k_img, int pp) {
+    auto lrelu_pk = [&](float x0, float x1) -> unsigned {             // LeakyReLU(0.1) of two values as a bf16 pair
+        float y0, y1;
+        asm("v_max_f32 %0, %1, %2" : "=v"(y0) : "v"(x0), "v"(x0 * 0.1f));   // (fmaxf would add a canonicalising v_max per value)
+        asm("v_max_f32 %0, %1, %2" : "=v"(y1) : "v"(x1), "v"(x1 * 0.1f));
+        return r64_pack(y0, y1);
+    };
+    // EDGE (wave-uniform): some of the tile's 5 rows lie outside the image - only then do the stores need the per-lane select
+    auto conv1_groups = [&](int k_img, int pp, int buf, auto edge_c) {
+        constexpr bool EDGE = decltype(edge_c)::value;
         const int npx = BLOCKS * W;
         for (int g0 = wid * 32; g0 < npx; g0 += R64_NW * 32) {
             const int p = g0 + lr;
@@ -612,7 +626,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
             const int rb = valid ? (int)fdiv((unsigned)p, a.d_w) : 0, x = valid ? p - rb * W : 0;
             const int h = a.R * k_img - 1 + rb;
             const bool inside = h >= 0 && h < a.H;
-            const char* const base = smem + X4_BASE + rb * X4_ROW + (x + 1) * 8;
+            const char* const base = smem + X4_BASE + buf * X4_BUF + rb * X4_ROW + (x + 1) * 8;
             f32x16 acc1[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -638,17 +652,16 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float t = acc1[i][4 * q + e];
-                        v[e] = inside ? fmaxf(t, t * 0.1f) : 0.f;
-                    }
-                    if (valid)
-                        *reinterpret_cast<uint2*>(smem + (2 * pp + i) * PLANE + rbase + 16u * (unsigned)(q ^ sw)) =
-                            make_uint2(r64_pack(v[0], v[1]), r64_pack(v[2], v[3]));
+                    unsigned d0 = lrelu_pk(acc1[i][4 * q], acc1[i][4 * q + 1]), d1 = lrelu_pk(acc1[i][4 * q + 2], acc1[i][4 * q + 3]);
+                    if (EDGE) { d0 = inside ? d0 : 0u; d1 = inside ? d1 : 0u; }
+                    if (valid) *reinterpret_cast<uint2*>(smem + (2 * pp + i) * PLANE + rbase + 16u * (unsigned)(q ^ sw)) = make_uint2(d0, d1);
                 }
         }
+    };
+    auto conv1_tile = [&](int k_img, int pp, int buf) {
+        const int h0 = a.R * k_img - 1;                                 // first of the 5 rows
+        if (h0 < 0 || h0 + BLOCKS > a.H) conv1_groups(k_img, pp, buf, std::true_type{});
+        else conv1_groups(k_img, pp, buf, std::false_type{});
     };
 
     // ---- conv2's per-lane A addresses (LINEAR: the same for every tile)
@@ -666,28 +679,33 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
         }
     }
 
-    // ---- prologue: patch + conv1 of the first tile, patch of the second
+    // ---- prologue: patch (buffer 0) + conv1 of the first tile, patch of the second (buffer 1)
     int t = t_begin, b, k_img;
     tile_geom(t, b, k_img);
     dma_patch(b, k_img);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    convert_row(0);
     __syncthreads();
-    convert_patch();
-    __syncthreads();
-    conv1_tile(k_img, 0);
+    conv1_tile(k_img, 0, 0);
     int nb = 0, nk = 0;
     if (t + nslot < t_end) {
         tile_geom(t + nslot, nb, nk);
         dma_patch(nb, nk);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        convert_row(1);
     }
-    __syncthreads();                                                   // (conv1's reads of the bf16 patch are done)
-    if (t + nslot < t_end) convert_patch();
     __syncthreads();
 
+#if R64_DIAG
+    unsigned long long dq = __builtin_amdgcn_s_memtime(), dt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long d_c0 = dq, d_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int it = 0; t < t_end; ++it, t += nslot) {
         const int pp = it & 1;
         const bool more = t + nslot < t_end, more2 = t + 2 * nslot < t_end;
+#if R64_DIAG
+        dt[0] += 1;
+#endif
         int b2 = 0, k2 = 0;
         if (more2) {
             tile_geom(t + 2 * nslot, b2, k2);
@@ -695,7 +713,8 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
         }
         // conv1 of the next tile needs nothing from this tile (its own plane pair, its own patch): the two waves of a SIMD (w and
         // w + 4) run it at opposite ends of the tile, so one wave's VALU / LDS-heavy conv1 phase meets its partner's MFMA chunks
-        if (R64_CUT != 3 && more && (wid < 4 || !R64_FUSED_STAGGER)) conv1_tile(nk, pp ^ 1);
+        if (R64_CUT != 3 && more && (wid < 4 || !R64_FUSED_STAGGER)) conv1_tile(nk, pp ^ 1, pp ^ 1);
+        R64_STAMP(1);
         // conv2 runs with SWAPPED MFMA operands (A = the resident weights, B = the pixel fragments): lane (lr, lh) then holds pixel lr
         // of a row tile and register r holds channel 32 wh + (r & 3) + 8 (r >> 2) + 4 lh - four consecutive channels per four
         // registers, which is what the LDS-free epilogue below needs.  The accumulators start from the BN shift (LDS reads that
@@ -737,9 +756,21 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
                                                                       __builtin_bit_cast(bf16x8, f), acc[j & 1], 0, 0, 0);
             });
         };
+#if R64_FUSED_PRIO
+        // the MFMA phase runs at a raised issue priority, waves 4-7 (whose chunks come first in the tile) above waves 0-3: when wave w
+        // leaves conv1 while its SIMD partner w + 4 is still in its second chunk, the partner keeps the matrix pipe, finishes, and
+        // starts its long conv1 / epilogue phase under this wave's chunks - instead of being starved to the end of them (in-kernel
+        // stamps, profiles/r04_l1_fused_stamps.txt: partner's chunk 1 3.9 k cycles, then 3 k cycles of conv1 with this wave idle)
+        if (wid >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
+#endif
         chunk(2 * pp, std::integral_constant<int, 0>{});
+        R64_STAMP(2);
         chunk(2 * pp + 1, std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
+#if R64_FUSED_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        R64_STAMP(3);
         // ---- epilogue (LINEAR), no LDS: LeakyReLU, bf16 pairs, then v_permlane32_swap hands the upper lane's channels +4..7 of each
         //      group of 16 to the lower lane and the lower lane's +8..11 to the upper one: every lane stores 16 bytes = 8 consecutive
         //      channels of its pixel (a store instruction = 32 pixel rows x 32 contiguous bytes)
@@ -767,13 +798,28 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (R64_CUT != 3 && R64_FUSED_STAGGER && more && wid >= 4) conv1_tile(nk, pp ^ 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's patch pieces of tile t + 2 landed (and its stores)
-        __syncthreads();                                               // every wave: conv1 read the bf16 patch, every patch piece landed
-        if (more2 && R64_CUT != 5) convert_patch();
+        R64_STAMP(4);
+        if (R64_CUT != 3 && R64_FUSED_STAGGER && more && wid >= 4) conv1_tile(nk, pp ^ 1, pp ^ 1);
+        R64_STAMP(5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's patch row of tile t + 2 landed (and its stores are out)
+        R64_STAMP(6);
+        // the bf16 patch of t + 2 goes into the buffer tile t's patch had: its last readers (conv1 of t, one iteration ago) are behind
+        // the previous barrier, and conv1 of t + 1 (this iteration) reads the other buffer - ONE barrier per tile
+        if (more2 && R64_CUT != 5) convert_row(pp);
         __syncthreads();                                               // bf16 patch of t + 2 and the planes of t + 1 are complete
+        R64_STAMP(7);
         b = nb; k_img = nk; nb = b2; nk = k2;
     }
+#if R64_DIAG
+    if (lane == 0 && blockIdx.x * R64_NW + wid < 4096) {
+        // [tiles, conv1 (waves 0-3), chunk 0, chunk 1, epilogue, conv1 (waves 4-7), DMA wait + barrier, convert + barrier, -, -, -, GHz]
+        float* d = r64_diag + (size_t)(blockIdx.x * R64_NW + wid) * 12;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = (float)dt[k];
+        d[8] = d[9] = d[10] = 0.f;
+        d[11] = (float)(__builtin_amdgcn_s_memtime() - d_c0) / (float)(__builtin_amdgcn_s_memrealtime() - d_r0) * 0.1f;
+    }
+#endif
 }
 
 // all but the n youngest vector-memory operations (LDS-DMAs and stores, in issue order) of this wave are done; n wave-uniform

@@ -14,11 +14,38 @@ import torch         # noqa: E402
 from subreg_hip import _lib   # noqa: E402
 
 
+def fused(lib, raw, dev, B):
+    """conv64_fused_first_kernel (layer 1 conv1 -> conv2): cycles per tile and wave by phase, waves 0-3 and 4-7 apart (the two groups run
+    conv1 of the next tile at opposite ends of the tile)."""
+    H = 84
+    img = torch.randn(B, 3, H, H, device=dev)
+    w1 = (torch.randn(64, 32, device=dev) / 5).to(torch.bfloat16)
+    w2 = (torch.randn(64, 9, 64, device=dev) / 24).to(torch.bfloat16)
+    sh1, sh2 = torch.randn(64, device=dev), torch.randn(64, device=dev)
+    y = torch.empty(B * H * H, 64, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        _lib.check(lib.subreg_conv12_first_fused(_lib.ptr(img), _lib.ptr(w1), _lib.ptr(sh1), _lib.ptr(w2), _lib.ptr(sh2), _lib.ptr(y), B, H, H,
+                                                 _lib.CONV_LRELU, _lib.BF16, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    out = np.zeros(4096 * 12, np.float32)
+    assert raw.subreg_r64_diag_read(out.ctypes.data_as(C.c_void_p), out.size) == 0
+    d = out.reshape(-1, 8, 12)
+    d = d[d[:, 0, 0] > 0]
+    names = ["conv1 (first)", "chunk 0", "chunk 1", "epilogue", "conv1 (after)", "DMA wait + barrier", "convert + barrier"]
+    for grp, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
+        g = d[:, sl, :].reshape(-1, 12)
+        per = np.median(g[:, 1:8] / g[:, :1], axis=0)
+        print("fused conv1+conv2 B=%d %s: tiles/wave %.1f, clock %.2f GHz, cycles per tile %.0f = " % (B, grp, np.median(g[:, 0]), np.median(g[:, 11]), per.sum()) +
+              ", ".join("%s %.0f" % (n, v) for n, v in zip(names, per)))
+
+
 def main():
     lib = _lib.load()
     raw = C.CDLL(_lib.LIB_PATH)
     dev = torch.device("cuda:0")
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    if "--fused" in sys.argv:
+        return fused(lib, raw, dev, B)
     for pool, sc in ((False, False), (True, True)):
         H = 84
         x = torch.randn(B * H * H, 64, device=dev).to(torch.bfloat16)
