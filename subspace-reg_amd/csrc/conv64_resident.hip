@@ -33,6 +33,9 @@ namespace subreg {
 #ifndef R64_FUSED_PRIO
 #define R64_FUSED_PRIO 1        // conv64_fused_first_kernel: s_setprio around the conv2 chunks (see there)
 #endif
+#ifndef R64_FAST_STAGE
+#define R64_FAST_STAGE 1        // conv64_resident_kernel: branch-free patch staging for tiles whose blocks all lie inside the image
+#endif
 #ifndef R64_CUT
 #define R64_CUT 0       // conv64_fused_first_kernel, timing experiments only (WRONG results): leave one component out -
                         // 1 conv2's MFMAs, 2 conv2's A-fragment reads, 3 conv1, 4 the epilogue, 5 image DMA + patch conversion
@@ -125,6 +128,23 @@ __device__ __forceinline__ void dma16_far(const char* p, unsigned lds_addr) {
         : "memory");
 }
 
+// one LDS-DMA piece under a lane mask held in an SGPR pair (exec is put back inside the statement: the compiler never sees it move; no
+// s_and_saveexec / s_cbranch_execz pair around the piece)
+__device__ __forceinline__ void dma16_masked(const char* base, unsigned voff, unsigned lds_addr, unsigned long long mask) {
+    const unsigned lds_u = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    unsigned long long keep;
+    asm volatile(
+        "s_mov_b64 %0, exec\n\t"
+        "s_mov_b64 exec, %4\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(base), "s"(lds_u), "s"(mask)
+        : "memory", "m0");
+}
+
 // BLOCKS: image-row blocks per plane (LINEAR R + 2 = 5, POOL 2 row pairs + halo = 6)
 // IMG (with SC): the shortcut's input is the fp32 NCHW image (layer1.0's downsample conv, models/resnet_language.py:146-147,286):
 // each tile's own pixels are loaded from the three channel planes, converted to bf16 and written into logical slot 0 of
@@ -192,12 +212,12 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
     //      q / 6, columns 16 (q % 6) .. + 15 of the padded image row (column c holds pixel c - 1; 0 and W+1.. are pads)
     const int prl = lane >> 2, psl = lane & 3;                      // row within a piece, physical 16-byte slot
     unsigned goff[NPK], goff2[NPK];                                 // this lane's byte offset from the patch origin in x / in x2
-    bool isdata[NPK];
+    unsigned long long dmask[NPK];                                  // the piece's data lanes (pads are never written) as an exec mask
 #pragma unroll
     for (int k = 0; k < NPK; ++k) {
         const int q = wid + R64_NW * k, idx = q * 16 + prl, rb = q / PPB, c = idx - rb * P;
         const unsigned slot16 = (unsigned)(psl ^ swz<4>(idx)) << 4;
-        isdata[k] = q < PIECES && c >= 1 && c <= a.W;
+        dmask[k] = __ballot(q < PIECES && c >= 1 && c <= a.W);
         goff[k] = (unsigned)(rb * a.W + c - 1) * 128u + slot16;
         goff2[k] = (unsigned)(rb * a.W + c - 1) * 64u + slot16;
     }
@@ -205,6 +225,21 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
     auto stage = [&](unsigned dst, int c, int b, int h_first) {
         const long long origin = ((long long)b * a.H + h_first) * a.W;          // pixel index of (block 0, column 1); may lie before x
         const char* const zero = reinterpret_cast<const char*>(r64_zero_line);
+        if (R64_FAST_STAGE && h_first >= 0 && h_first + BLOCKS <= a.H) {
+            // every block of the patch lies inside the image (all tiles but the first and the last of an image): no per-piece
+            // decisions, one masked DMA statement per piece (measured: profiles/r04_ab_l1_conv3_stage.txt)
+            const char* const src = c == 2 ? a.x2 + origin * 64 : a.x + origin * 128 + c * 64;
+#pragma unroll
+            for (int k = 0; k < NPK; ++k) {
+                const int q = wid + R64_NW * k;
+                if (q < PIECES) {                                               // wave-uniform (compile-time true but for the last k)
+                    const int rb = q / PPB;
+                    if (!(c == 2 && (rb == 0 || rb == BLOCKS - 1)) && dmask[k])
+                        dma16_masked(src, c == 2 ? goff2[k] : goff[k], dst + q * 1024, dmask[k]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NPK; ++k) {
             const int q = wid + R64_NW * k;
@@ -212,7 +247,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
                 const int rb = q / PPB, h = h_first + rb;
                 const bool halo = rb == 0 || rb == BLOCKS - 1;                  // the shortcut GEMM reads the centre tap only
                 const bool inside = h >= 0 && h < a.H;                          // wave-uniform: a block is in or out of the image
-                if (!(c == 2 && halo) && isdata[k]) {
+                if (!(c == 2 && halo) && ((dmask[k] >> lane) & 1ull)) {
                     if (!inside) dma16(zero, (unsigned)psl << 4, dst + q * 1024);
                     else if (c == 2) dma16(a.x2 + origin * 64, goff2[k], dst + q * 1024);
                     else dma16(a.x + origin * 128 + c * 64, goff[k], dst + q * 1024);

@@ -51,6 +51,9 @@
                                  // 1-17 % SLOWER (profiles/r04_ab_staging_roles.txt): a step is as long as the wave with the most DMAs
                                  // takes to issue them, and 10 weight pieces over 3 waves is 4 on one of them at every step
 #endif
+#ifndef SUBREG_MMA_PRIO
+#define SUBREG_MMA_PRIO 0        // > 0: s_setprio of a step's fragment-read + MFMA block (0 again behind it)
+#endif
 #ifndef SUBREG_WAVES_K2
 #define SUBREG_WAVES_K2 1        // 1: grids of <= 256 workgroups (128-row tiles, 3 taps per step) put two waves on every tile
 #endif
@@ -532,7 +535,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
                 }
             }
             if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_issue += n - tq; tq = n; }
+            if (SUBREG_MMA_PRIO) __builtin_amdgcn_s_setprio(SUBREG_MMA_PRIO);
             mma_block(std::false_type{}, aoff, (step % NWB) * BBUF, tg, step);
+            if (SUBREG_MMA_PRIO) __builtin_amdgcn_s_setprio(0);
             ++step;
             if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_mma += n - tq; tq = n; }
             // end of step: the weight waves' DMAs (next step's weights) landed; at a chunk end the patch waves' too; this
@@ -573,7 +578,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
                 for (int q = wid; q < apieces; q += NW) patch_piece(a.x2, puoff, xrow1, q, (c + 1) & 1);
             }
             if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_issue += n - tq; tq = n; }
+            if (SUBREG_MMA_PRIO) __builtin_amdgcn_s_setprio(SUBREG_MMA_PRIO);
             mma_block(std::true_type{}, aoff, (step % NWB) * BBUF, 0, step);
+            if (SUBREG_MMA_PRIO) __builtin_amdgcn_s_setprio(0);
             ++step;
             if (STAMPS) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_mma += n - tq; tq = n; }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
