@@ -1034,19 +1034,50 @@ __global__ __launch_bounds__(256) void sgd_pack_train_kernel(const SgdPackJobs j
         return;
     }
     const int ncb = Cin / 32, o0 = (blk / ncb) * 32, c0 = (blk % ncb) * 32, run = 32 * taps;
-    for (int e = tid; e < 32 * run; e += 256) {
-        const int o = e / run, r = e - o * run;                 // r = c * taps + t: contiguous in OIHW for a fixed o
-        tile[o][r] = update(((size_t)(o0 + o) * Cin + c0) * taps + r);
+    // the update streams 16 bytes per lane where the three tensors allow it (their flat-buffer offsets are multiples of 4 floats for every
+    // resnet parameter; checked here, not assumed), and the two packed copies leave as 16-byte vectors: 8 bf16 / 4 f32 consecutive
+    // channels of one (tap, row) per lane - 64 lanes = 1 KB contiguous
+    const bool vec = (((size_t)p | (size_t)g | (size_t)m) & 15) == 0;
+    if (vec) {
+        const int run4 = run >> 2;
+        for (int e = tid; e < 32 * run4; e += 256) {
+            const int o = e / run4, r = (e - o * run4) << 2;        // r = c * taps + t: contiguous in OIHW for a fixed o
+            const size_t i = ((size_t)(o0 + o) * Cin + c0) * taps + r;
+            const float4 w = *reinterpret_cast<const float4*>(p + i), gr = *reinterpret_cast<const float4*>(g + i);
+            float4 b;
+            if (jobs.first) {
+                b = make_float4(gr.x + jobs.wd * w.x, gr.y + jobs.wd * w.y, gr.z + jobs.wd * w.z, gr.w + jobs.wd * w.w);
+            } else {
+                const float4 mo = *reinterpret_cast<const float4*>(m + i);
+                b = make_float4(jobs.momentum * mo.x + (gr.x + jobs.wd * w.x), jobs.momentum * mo.y + (gr.y + jobs.wd * w.y),
+                                jobs.momentum * mo.z + (gr.z + jobs.wd * w.z), jobs.momentum * mo.w + (gr.w + jobs.wd * w.w));
+            }
+            const float4 nw = make_float4(w.x - jobs.lr * b.x, w.y - jobs.lr * b.y, w.z - jobs.lr * b.z, w.w - jobs.lr * b.w);
+            *reinterpret_cast<float4*>(m + i) = b;
+            *reinterpret_cast<float4*>(p + i) = nw;
+            tile[o][r] = nw.x; tile[o][r + 1] = nw.y; tile[o][r + 2] = nw.z; tile[o][r + 3] = nw.w;
+        }
+    } else {
+        for (int e = tid; e < 32 * run; e += 256) {
+            const int o = e / run, r = e - o * run;
+            tile[o][r] = update(((size_t)(o0 + o) * Cin + c0) * taps + r);
+        }
     }
     __syncthreads();
     T* const raw = reinterpret_cast<T*>(jobs.raw[j]);
     T* const dg = reinterpret_cast<T*>(jobs.dgrad[j]);
-    for (int e = tid; e < taps * 1024; e += 256) {
-        const int t = e >> 10, a = (e >> 5) & 31, b = e & 31;
-        // raw: [tap][Cin/32][Cout][32]: a = o, b = c32 -> 2 KB contiguous per tap
-        raw[(((size_t)t * ncb + c0 / 32) * Cout + o0 + a) * 32 + b] = ElemTraits<T>::from_float(tile[a][b * taps + t]);
-        // dX: [flipped tap][Cout/32][Cin][32]: a = c, b = o32 -> 2 KB contiguous per tap
-        if (dg) dg[(((size_t)(taps - 1 - t) * (Cout / 32) + o0 / 32) * Cin + c0 + a) * 32 + b] = ElemTraits<T>::from_float(tile[b][a * taps + t]);
+    constexpr int EPT = 16 / (int)sizeof(T), GPR = 32 / EPT;        // elements per 16-byte vector, vectors per 32-channel row
+    for (int e = tid; e < taps * 32 * GPR; e += 256) {
+        const int t = e / (32 * GPR), a = (e / GPR) & 31, b0 = (e % GPR) * EPT;
+        alignas(16) T v[EPT];
+        alignas(16) T u[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            v[k] = ElemTraits<T>::from_float(tile[a][(b0 + k) * taps + t]);     // raw: [tap][Cin/32][Cout][32]: a = o, b = c32
+            u[k] = ElemTraits<T>::from_float(tile[b0 + k][a * taps + t]);       // dX: [flipped tap][Cout/32][Cin][32]: a = c, b = o32
+        }
+        *reinterpret_cast<uint4*>(raw + (((size_t)t * ncb + c0 / 32) * Cout + o0 + a) * 32 + b0) = *reinterpret_cast<const uint4*>(v);
+        if (dg) *reinterpret_cast<uint4*>(dg + (((size_t)(taps - 1 - t) * (Cout / 32) + o0 / 32) * Cin + c0 + a) * 32 + b0) = *reinterpret_cast<const uint4*>(u);
     }
 }
 
