@@ -30,6 +30,9 @@ namespace subreg {
 #ifndef R64_FUSED_STAGGER
 #define R64_FUSED_STAGGER 1     // conv64_fused_first_kernel: waves 4-7 run conv1 of the next tile AFTER their conv2 chunks (0: all waves first)
 #endif
+#ifndef R64_FUSED_ROLL
+#define R64_FUSED_ROLL 1        // conv64_fused_first_kernel: conv1 computes 3 new rows per tile and copies the 2 it shares with the tile above
+#endif
 #ifndef R64_FUSED_PRIO
 #define R64_FUSED_PRIO 1        // conv64_fused_first_kernel: s_setprio around the conv2 chunks (see there)
 #endif
@@ -548,9 +551,12 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const int W = a.W, W4 = W >> 2;
 
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = (nwg + 7 - xcd) >> 3;
-    const int per = (a.ntiles + 7) >> 3;
-    const int t_begin = xcd * per + slot, t_end = min((xcd + 1) * per, a.ntiles);
+    // ---- tile schedule: every workgroup walks ONE contiguous range of tiles, i.e. down its images (tile t + 1 is the three rows below
+    //      tile t until the image ends), so that conv1 can ROLL: of the 5 conv1 rows under tile t + 1 the first two are the last two of
+    //      tile t - copied from its planes, not recomputed (R64_FUSED_ROLL)
+    const int nwg = gridDim.x, nslot = 1;
+    const int per = a.ntiles / nwg, extra = a.ntiles - per * nwg;     // the first `extra` workgroups take one tile more
+    const int t_begin = blockIdx.x * per + min((int)blockIdx.x, extra), t_end = t_begin + per + ((int)blockIdx.x < extra ? 1 : 0);
     if (t_begin >= t_end) return;
 
     // ---- conv2's resident weights (as in conv64_resident_kernel)
@@ -652,13 +658,13 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
         return r64_pack(y0, y1);
     };
     // EDGE (wave-uniform): some of the tile's 5 rows lie outside the image - only then do the stores need the per-lane select
-    auto conv1_groups = [&](int k_img, int pp, int buf, auto edge_c) {
+    auto conv1_groups = [&](int k_img, int pp, int buf, int rb0, auto edge_c) {
         constexpr bool EDGE = decltype(edge_c)::value;
-        const int npx = BLOCKS * W;
+        const int npx = (BLOCKS - rb0) * W;                             // blocks rb0 .. 4 (rb0 = 2: the three rows a rolling tile adds)
         for (int g0 = wid * 32; g0 < npx; g0 += R64_NW * 32) {
             const int p = g0 + lr;
             const bool valid = p < npx;
-            const int rb = valid ? (int)fdiv((unsigned)p, a.d_w) : 0, x = valid ? p - rb * W : 0;
+            const int rbl = valid ? (int)fdiv((unsigned)p, a.d_w) : 0, x = valid ? p - rbl * W : 0, rb = rb0 + rbl;
             const int h = a.R * k_img - 1 + rb;
             const bool inside = h >= 0 && h < a.H;
             const char* const base = smem + X4_BASE + buf * X4_BUF + rb * X4_ROW + (x + 1) * 8;
@@ -693,10 +699,21 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
                 }
         }
     };
-    auto conv1_tile = [&](int k_img, int pp, int buf) {
+    // roll: the tile is the one below the tile whose planes are pair pp ^ 1 - its blocks 0, 1 are that pair's blocks 3, 4 (a straight
+    // copy of 16-byte slots: a block is 96 rows, a multiple of the swizzle period), only blocks 2 .. 4 are computed
+    auto conv1_tile = [&](int k_img, int pp, int buf, bool roll) {
         const int h0 = a.R * k_img - 1;                                 // first of the 5 rows
-        if (h0 < 0 || h0 + BLOCKS > a.H) conv1_groups(k_img, pp, buf, std::true_type{});
-        else conv1_groups(k_img, pp, buf, std::false_type{});
+        const int rb0 = roll ? 2 : 0;
+        if (roll) {
+            constexpr int SPAN = 2 * P * R64_ROWB;                      // two blocks of one plane
+            for (int o = tid * 16; o < 2 * SPAN; o += R64_NW * 64 * 16) {
+                const int c = o >= SPAN ? 1 : 0, off = o - c * SPAN;
+                *reinterpret_cast<uint4*>(smem + (2 * pp + c) * PLANE + off) =
+                    *reinterpret_cast<const uint4*>(smem + (2 * (pp ^ 1) + c) * PLANE + 3 * P * R64_ROWB + off);
+            }
+        }
+        if (h0 < 0 || h0 + BLOCKS > a.H) conv1_groups(k_img, pp, buf, rb0, std::true_type{});
+        else conv1_groups(k_img, pp, buf, rb0, std::false_type{});
     };
 
     // ---- conv2's per-lane A addresses (LINEAR: the same for every tile)
@@ -721,7 +738,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     convert_row(0);
     __syncthreads();
-    conv1_tile(k_img, 0, 0);
+    conv1_tile(k_img, 0, 0, false);
     int nb = 0, nk = 0;
     if (t + nslot < t_end) {
         tile_geom(t + nslot, nb, nk);
@@ -748,7 +765,8 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
         }
         // conv1 of the next tile needs nothing from this tile (its own plane pair, its own patch): the two waves of a SIMD (w and
         // w + 4) run it at opposite ends of the tile, so one wave's VALU / LDS-heavy conv1 phase meets its partner's MFMA chunks
-        if (R64_CUT != 3 && more && (wid < 4 || !R64_FUSED_STAGGER)) conv1_tile(nk, pp ^ 1, pp ^ 1);
+        const bool roll = R64_FUSED_ROLL && nb == b && nk == k_img + 1;  // (wave-uniform) the next tile lies directly below this one
+        if (R64_CUT != 3 && more && (wid < 4 || !R64_FUSED_STAGGER)) conv1_tile(nk, pp ^ 1, pp ^ 1, roll);
         R64_STAMP(1);
         // conv2 runs with SWAPPED MFMA operands (A = the resident weights, B = the pixel fragments): lane (lr, lh) then holds pixel lr
         // of a row tile and register r holds channel 32 wh + (r & 3) + 8 (r >> 2) + 4 lh - four consecutive channels per four
@@ -796,14 +814,15 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
         // leaves conv1 while its SIMD partner w + 4 is still in its second chunk, the partner keeps the matrix pipe, finishes, and
         // starts its long conv1 / epilogue phase under this wave's chunks - instead of being starved to the end of them (in-kernel
         // stamps, profiles/r04_l1_fused_stamps.txt: partner's chunk 1 3.9 k cycles, then 3 k cycles of conv1 with this wave idle)
-        if (wid >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
+        if (R64_FUSED_PRIO == 2) __builtin_amdgcn_s_setprio(0);          // (2: the other way round - the VALU-heavy phases run raised)
+        else if (wid >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
 #endif
         chunk(2 * pp, std::integral_constant<int, 0>{});
         R64_STAMP(2);
         chunk(2 * pp + 1, std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
 #if R64_FUSED_PRIO
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(R64_FUSED_PRIO == 2 ? 2 : 0);
 #endif
         R64_STAMP(3);
         // ---- epilogue (LINEAR), no LDS: LeakyReLU, bf16 pairs, then v_permlane32_swap hands the upper lane's channels +4..7 of each
@@ -834,7 +853,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
         }
         __builtin_amdgcn_sched_barrier(0);
         R64_STAMP(4);
-        if (R64_CUT != 3 && R64_FUSED_STAGGER && more && wid >= 4) conv1_tile(nk, pp ^ 1, pp ^ 1);
+        if (R64_CUT != 3 && R64_FUSED_STAGGER && more && wid >= 4) conv1_tile(nk, pp ^ 1, pp ^ 1, roll);
         R64_STAMP(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's patch row of tile t + 2 landed (and its stores are out)
         R64_STAMP(6);
