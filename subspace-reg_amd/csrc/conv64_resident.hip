@@ -30,6 +30,9 @@ namespace subreg {
 #ifndef R64_FUSED_STAGGER
 #define R64_FUSED_STAGGER 1     // conv64_fused_first_kernel: waves 4-7 run conv1 of the next tile AFTER their conv2 chunks (0: all waves first)
 #endif
+#ifndef R64_YOUNG_PRIO
+#define R64_YOUNG_PRIO 0        // conv64_resident_kernel: s_setprio of waves 4-7 for the whole kernel (measured: see profiles/r04_ab_l1_young_prio.txt)
+#endif
 #ifndef R64_FUSED_ROLL
 #define R64_FUSED_ROLL 1        // conv64_fused_first_kernel: conv1 computes 3 new rows per tile and copies the 2 it shares with the tile above
 #endif
@@ -179,6 +182,9 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
     const int t_begin = xcd * per + slot, t_end = min((xcd + 1) * per, a.ntiles);
     if (t_begin >= t_end) return;
 
+#if R64_YOUNG_PRIO
+    if (wid >= 4) __builtin_amdgcn_s_setprio(R64_YOUNG_PRIO);       // static priority for the later-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+#endif
     // ---- resident weights: B fragments of this wave's 32 output columns, all taps / chunks / k-steps (144 VGPRs)
     uint4 bw[2][9][2];
     {
