@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUBREG_ABI_VERSION 11
+#define SUBREG_ABI_VERSION 12
 
 #define SUBREG_OK 0
 #define SUBREG_EINVAL (-1)       /* bad argument (null pointer, shape not supported by contract) */
@@ -214,6 +214,18 @@ int subreg_block_tail_bwd(const void* grad_out, const unsigned char* keep_mask, 
                           const float* mask_scale_dev /* device override or NULL */, const void* raw3,
                           const float* scale3, const float* shift3, const void* residual, const float* res_scale,
                           const float* res_shift, void* dv, int B, int H, int W, int C, int pool, int dtype, void* stream);
+/* the same pass + the REDUCE pass of the BatchNorms that consume dV (BasicBlock's bn3 over raw3 and, with mean_d != NULL, the shortcut's
+ * BatchNorm over `residual`): partial3 / partial_d receive *slices (< subreg_bn_bwd_slices()) slices of (sum dV, sum dV * xhat), to be
+ * handed to subreg_bn_bwd_partials - two launches and four tensor reads less per block than subreg_block_tail_bwd + 2 x subreg_bn_bwd */
+int subreg_block_tail_bwd_stats(const void* grad_out, const unsigned char* keep_mask, float mask_scale,
+                                const float* mask_scale_dev, const void* raw3, const float* scale3, const float* shift3,
+                                const void* residual, const float* res_scale, const float* res_shift, void* dv, int B, int H, int W,
+                                int C, int pool, int dtype, const float* mean3, const float* invstd3, double* partial3,
+                                const float* mean_d, const float* invstd_d, double* partial_d, int* slices, void* stream);
+/* subreg_bn_bwd / subreg_bn_bwd_eval (eval_mode != 0) without their reduce pass: `partial` holds `slices` slices already */
+int subreg_bn_bwd_partials(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
+                           const float* gamma, double* partial, int slices, float* dgamma, float* dbeta, void* dx, long long npix,
+                           int C, int dtype, int eval_mode, void* stream);
 int subreg_avgpool_bwd(const float* dfeat, void* dx, int B, int H, int W, int C, int dtype, void* stream);
 /* torch.optim.SGD step (train_supervised.py:133-136): d = g + wd*p; buf = first ? d : m*buf + d; p -= lr*buf */
 /* the same update for n tensors in ONE launch: params / bufs are DEVICE arrays of n pointers, grad_offsets[n] element offsets

@@ -26,8 +26,12 @@ int conv_stash(const subreg_backbone_desc* d, const subreg_conv_desc& c, const s
 }
 
 // BN backward (+ fused LeakyReLU' of `act`): d(raw conv output) into `draw`, d gamma / d beta
+// pre_slices > 0: `partial` already holds that many slices of the reduce pass (subreg_block_tail_bwd_stats wrote them)
 int bn_backward(const subreg_backbone_desc* d, const subreg_conv_desc& c, const subreg_conv_train& tc, const void* dy, const void* act,
-                void* draw, double* partial, int B, int H, int W, void* stream, bool eval_mode = false) {
+                void* draw, double* partial, int B, int H, int W, void* stream, bool eval_mode = false, int pre_slices = 0) {
+    if (pre_slices > 0)
+        return subreg_bn_bwd_partials(dy, act, tc.raw, tc.mean, tc.invstd, c.bn_weight, partial, pre_slices, tc.grad_gamma, tc.grad_beta, draw,
+                                      (long long)B * H * W, c.cout, d->dtype, eval_mode ? 1 : 0, stream);
     return (eval_mode ? subreg_bn_bwd_eval : subreg_bn_bwd)(dy, act, tc.raw, tc.mean, tc.invstd, c.bn_weight, partial, tc.grad_gamma,
                                                            tc.grad_beta, draw, (long long)B * H * W, c.cout, d->dtype, stream);
 }
@@ -77,6 +81,7 @@ int fork_fwd_from() { static const int v = env_int("SUBREG_TRAIN_FORK_FWD_FROM",
 // in the first two blocks (84x84 / 42x42 maps) the dW chains are longer than the BN-backward -> dX chain and main would wait for them
 // (two gaps of ~100 us at the d(raw) buffer reuse in the trace); the shortcut branch is work main can take over.  The 1x1 convs
 // have a dW scratch of their own (subreg_hip/train.py), so the two streams never share one.
+bool tail_stats_on() { static const int v = env_int("SUBREG_NO_TAIL_STATS", 0); return v == 0; }   // (the switch is for A/B timing)
 int down_on_side_from() { static const int v = env_int("SUBREG_TRAIN_DOWN_SIDE_FROM", 2); return v; }
 
 }  // namespace
@@ -152,10 +157,10 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
         return SUBREG_OK;
     };
     auto bn_then_wgrad = [&](const subreg_conv_desc& c, const subreg_conv_train& tc, const void* dy, const void* act,
-                             const void* conv_input, int bh, int bw, const void** draw_out) -> int {
+                             const void* conv_input, int bh, int bw, const void** draw_out, int pre_slices = 0) -> int {
         const int k = use++ & 1;
         if (busy[k]) { TRY(f.main_waits(EV_DONE0 + k)); busy[k] = false; }
-        TRY(bn_backward(d, c, tc, dy, act, drb[k], t->bn_partial, B, bh, bw, stream, t->eval_mode != 0));
+        TRY(bn_backward(d, c, tc, dy, act, drb[k], t->bn_partial, B, bh, bw, stream, t->eval_mode != 0, pre_slices));
         if (fork) {
             TRY(f.main_to_side(EV_READY0 + k));
             TRY(weight_grad(d, t, c, tc, conv_input, drb[k], B, bh, bw, f.side));
@@ -186,9 +191,22 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
                                hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return SUBREG_EHIP;
         }
         // d(pre-activation sum) from d(out): keep mask, max-pool routing, LeakyReLU'
-        TRY(subreg_block_tail_bwd(t->g[gi], b.keep_mask, b.mask_scale, b.mask_scale_dev, tb.conv3.raw, tb.conv3.bscale, tb.conv3.bshift, res,
-                                  b.down.w ? tb.down.bscale : nullptr, b.down.w ? tb.down.bshift : nullptr, t->dv, B, bh, bw, C,
-                                  b.stride == 2, dt, stream));
+        // ... and, in the same pass, the reduce pass of the two BatchNorms that consume dV: bn3 (into bn_partial) and the shortcut's
+        // (into bn_partial_side: its finalize may run on the side stream, or on main after bn3 .. bn1 reused bn_partial).  The side
+        // stream's last use of bn_partial_side (the previous block's shortcut branch) is behind that block's main_waits(EV_DOWN).
+        const bool tail_stats = tail_stats_on();
+        const bool ds_stats = tail_stats && b.down.w && t->bn_partial_side;
+        int tail_slices = 0;
+        if (tail_stats) {
+            TRY(subreg_block_tail_bwd_stats(t->g[gi], b.keep_mask, b.mask_scale, b.mask_scale_dev, tb.conv3.raw, tb.conv3.bscale, tb.conv3.bshift, res,
+                                            b.down.w ? tb.down.bscale : nullptr, b.down.w ? tb.down.bshift : nullptr, t->dv, B, bh, bw, C,
+                                            b.stride == 2, dt, tb.conv3.mean, tb.conv3.invstd, t->bn_partial, ds_stats ? tb.down.mean : nullptr,
+                                            ds_stats ? tb.down.invstd : nullptr, ds_stats ? t->bn_partial_side : nullptr, &tail_slices, stream));
+        } else {
+            TRY(subreg_block_tail_bwd(t->g[gi], b.keep_mask, b.mask_scale, b.mask_scale_dev, tb.conv3.raw, tb.conv3.bscale, tb.conv3.bshift, res,
+                                      b.down.w ? tb.down.bscale : nullptr, b.down.w ? tb.down.bshift : nullptr, t->dv, B, bh, bw, C,
+                                      b.stride == 2, dt, stream));
+        }
         // shortcut branch (BN backward -> dr2, dW): needs only dv; all of it on the side stream
         // INVARIANT the two-stream schedule rests on: the shortcut convolution is 1x1, and the 1x1 path of subreg_conv_wgrad never
         // touches the dW scratch (t->pad_x / t->pad_dy) that the 3x3 dW chains of the OTHER stream are using at the same time; its
@@ -197,14 +215,15 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
         const bool down_side = fork && i >= down_on_side_from();
         if (b.down.w && down_side) {
             TRY(f.main_to_side(EV_FORK));
-            TRY(bn_backward(d, b.down, tb.down, t->dv, nullptr, t->dr2, t->bn_partial_side, B, bh, bw, f.side, t->eval_mode != 0));
+            TRY(bn_backward(d, b.down, tb.down, t->dv, nullptr, t->dr2, t->bn_partial_side, B, bh, bw, f.side, t->eval_mode != 0,
+                            ds_stats ? tail_slices : 0));
             TRY(weight_grad(d, t, b.down, tb.down, xin, t->dr2, B, bh, bw, f.side));
             TRY(f.mark_side(EV_DOWN));
             down_busy = true;
         }
         // main branch: bn3/conv3 -> bn2/conv2 -> bn1/conv1
         const void* dr = nullptr;
-        TRY(bn_then_wgrad(b.conv3, tb.conv3, t->dv, nullptr, tb.conv2.act, bh, bw, &dr));
+        TRY(bn_then_wgrad(b.conv3, tb.conv3, t->dv, nullptr, tb.conv2.act, bh, bw, &dr, tail_slices));
         TRY(subreg_conv_fwd_ws(dr, tb.conv3.w_dgrad, t->dt, nullptr, t->zero_shift, nullptr, nullptr, nullptr, nullptr, 0, B, bh, bw,
                                b.conv3.cout, b.conv3.cin, b.conv3.ksize_raw, 0, dt, t->splitk_ws, t->splitk_ws_floats, stream));
         TRY(bn_then_wgrad(b.conv2, tb.conv2, t->dt, tb.conv2.act, tb.conv1.act, bh, bw, &dr));
@@ -212,7 +231,8 @@ extern "C" int subreg_backbone_backward_blocks(const subreg_backbone_desc* d, co
                                b.conv2.cout, b.conv2.cin, b.conv2.ksize_raw, 0, dt, t->splitk_ws, t->splitk_ws_floats, stream));
         TRY(bn_then_wgrad(b.conv1, tb.conv1, t->dt, tb.conv1.act, xin, bh, bw, &dr));
         if (b.down.w && !down_side) {      // shortcut branch on the main stream
-            TRY(bn_backward(d, b.down, tb.down, t->dv, nullptr, t->dr2, t->bn_partial, B, bh, bw, stream, t->eval_mode != 0));
+            TRY(bn_backward(d, b.down, tb.down, t->dv, nullptr, t->dr2, ds_stats ? t->bn_partial_side : t->bn_partial, B, bh, bw, stream,
+                            t->eval_mode != 0, ds_stats ? tail_slices : 0));
             TRY(weight_grad(d, t, b.down, tb.down, xin, t->dr2, B, bh, bw, stream));
         }
         // the shortcut branch's results (dr2) and its reads of dv: main continues after them

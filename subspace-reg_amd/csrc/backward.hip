@@ -28,28 +28,47 @@ __device__ __forceinline__ float lrelu_grad(float pre) { return pre > 0.f ? 1.f 
 // lane) walking OUTPUT pixels (coefficients loaded once, 16-byte loads and stores).  A pooled output writes all four pixels
 // of its window - dV at the first maximum in scan order, zeros at the other three - and the windows at the right / bottom
 // edge also zero the column / row that floor pooling drops, so dV needs no separate zero-fill pass.
-template <typename T, bool POOL>
+// STATS: the kernel also emits the reduce pass of the two BatchNorms that consume dV (bn3 over raw3; the shortcut's BatchNorm over
+// `res` when stat.mean_d is set): partial[block][C][2] = (sum dV, sum dV * xhat) in fp64 across the block's pixel lanes, exactly what
+// bn_bwd_reduce_kernel would compute from dV and the raw tensors - which this kernel has in registers already (dV is non-zero at the
+// window's first maximum only, so one (raw3, res) pair per output element is all the sums need).  Two launches and four tensor reads
+// less per block of the backward.
+struct TailStats {
+    const float* mean3; const float* invstd3; double* partial3;
+    const float* mean_d; const float* invstd_d; double* partial_d;      // mean_d == NULL: no shortcut BatchNorm
+};
+template <typename T, bool POOL, bool STATS>
 __global__ __launch_bounds__(256) void block_tail_bwd_kernel(const T* __restrict__ gout, const unsigned char* __restrict__ keep,
                                                              float mask_scale_host, const float* __restrict__ mask_scale_dev,
                                                              const T* __restrict__ raw3,
                                                              const float* __restrict__ sc3, const float* __restrict__ sh3,
                                                              const T* __restrict__ res, const float* __restrict__ rsc,
                                                              const float* __restrict__ rsh, T* __restrict__ dv, int H, int W, int C,
-                                                             long long npo, int ppb) {
+                                                             long long npo, int ppb, const TailStats st) {
     constexpr int VEC = 16 / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char tsm[];
     const float mask_scale = mask_scale_dev ? *mask_scale_dev : mask_scale_host;
     const int ngrp = C / VEC, lanes = 256 / ngrp;
     const int cg = threadIdx.x % ngrp, pl = threadIdx.x / ngrp;
-    if (pl >= lanes) return;
+    if (!STATS && pl >= lanes) return;
     const int c0 = cg * VEC;
     float a[VEC], sft[VEC], ra[VEC], rs[VEC];
+    float s_g[VEC], s_x3[VEC], s_xd[VEC], m3[VEC], i3[VEC], md[VEC], id[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) { a[k] = sc3[c0 + k]; sft[k] = sh3[c0 + k]; ra[k] = rsc ? rsc[c0 + k] : 1.f; rs[k] = rsh ? rsh[c0 + k] : 0.f; }
+    if (STATS) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            s_g[k] = s_x3[k] = s_xd[k] = 0.f;
+            m3[k] = st.mean3[c0 + k]; i3[k] = st.invstd3[c0 + k];
+            md[k] = st.mean_d ? st.mean_d[c0 + k] : 0.f; id[k] = st.mean_d ? st.invstd_d[c0 + k] : 0.f;
+        }
+    }
     const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W, NQ = POOL ? 4 : 1;
     const long long p0 = (long long)blockIdx.x * ppb;
     long long p1 = p0 + ppb;
     if (p1 > npo) p1 = npo;
-    for (long long po = p0 + pl; po < p1; po += lanes) {
+    for (long long po = p0 + pl; pl < lanes && po < p1; po += lanes) {
         const int wo = (int)(po % Wo), ho = (int)((po / Wo) % Ho);
         const long long b = po / ((long long)Wo * Ho);
         const size_t pin = POOL ? ((size_t)b * H + 2 * ho) * W + 2 * wo : (size_t)po;
@@ -65,7 +84,7 @@ __global__ __launch_bounds__(256) void block_tail_bwd_kernel(const T* __restrict
             vr[q] = *reinterpret_cast<const uint4*>(res + e);
         }
         const T* tg = reinterpret_cast<const T*>(&vg);
-        float best[VEC];
+        float best[VEC], bx[VEC], br[VEC];
         int arg[VEC];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -73,8 +92,9 @@ __global__ __launch_bounds__(256) void block_tail_bwd_kernel(const T* __restrict
             const T* tr = reinterpret_cast<const T*>(&vr[q]);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float v = ElemTraits<T>::to_float(tx[k]) * a[k] + sft[k] + ElemTraits<T>::to_float(tr[k]) * ra[k] + rs[k];
-                if (q == 0 || v > best[k]) { best[k] = v; arg[k] = q; }           // first maximum in scan order
+                const float x3 = ElemTraits<T>::to_float(tx[k]), xr = ElemTraits<T>::to_float(tr[k]);
+                const float v = x3 * a[k] + sft[k] + xr * ra[k] + rs[k];
+                if (q == 0 || v > best[k]) { best[k] = v; arg[k] = q; if (STATS) { bx[k] = x3; br[k] = xr; } }   // first maximum in scan order
             }
         }
         float d[VEC];
@@ -83,6 +103,12 @@ __global__ __launch_bounds__(256) void block_tail_bwd_kernel(const T* __restrict
             float g = ElemTraits<T>::to_float(tg[k]);
             if (keep) g = ((kb >> (8 * k)) & 0xff) ? g * mask_scale : 0.f;
             d[k] = g * lrelu_grad(best[k]);
+            if (STATS) {
+                const float dr = ElemTraits<T>::to_float(ElemTraits<T>::from_float(d[k]));     // the value the BatchNorm passes will read back
+                s_g[k] += dr;
+                s_x3[k] += dr * (bx[k] - m3[k]) * i3[k];
+                s_xd[k] += dr * (br[k] - md[k]) * id[k];
+            }
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -104,6 +130,26 @@ __global__ __launch_bounds__(256) void block_tail_bwd_kernel(const T* __restrict
                 *reinterpret_cast<uint4*>(dv + (pin + 2 * (size_t)W) * C + c0) = z;
                 *reinterpret_cast<uint4*>(dv + (pin + 2 * (size_t)W + 1) * C + c0) = z;
                 if (ec) *reinterpret_cast<uint4*>(dv + (pin + 2 * (size_t)W + 2) * C + c0) = z;
+            }
+        }
+    }
+    if (STATS) {
+        float* const l1 = reinterpret_cast<float*>(tsm);           // [lanes][C] x 3
+        float* const l2 = l1 + (size_t)lanes * C;
+        float* const l3 = l2 + (size_t)lanes * C;
+        if (pl < lanes) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { l1[pl * C + c0 + k] = s_g[k]; l2[pl * C + c0 + k] = s_x3[k]; l3[pl * C + c0 + k] = s_xd[k]; }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            for (int l = 0; l < lanes; ++l) { t1 += (double)l1[l * C + c]; t2 += (double)l2[l * C + c]; t3 += (double)l3[l * C + c]; }
+            st.partial3[((size_t)blockIdx.x * C + c) * 2] = t1;
+            st.partial3[((size_t)blockIdx.x * C + c) * 2 + 1] = t2;
+            if (st.mean_d) {
+                st.partial_d[((size_t)blockIdx.x * C + c) * 2] = t1;
+                st.partial_d[((size_t)blockIdx.x * C + c) * 2 + 1] = t3;
             }
         }
     }
@@ -1135,26 +1181,54 @@ using namespace subreg;
     else if ((dtype) == SUBREG_BF16) { CALL_BF16; } \
     else return SUBREG_EINVAL;
 
-extern "C" int subreg_block_tail_bwd(const void* grad_out, const unsigned char* keep_mask, float mask_scale,
-                                     const float* mask_scale_dev, const void* raw3,
-                                     const float* scale3, const float* shift3, const void* residual, const float* res_scale,
-                                     const float* res_shift, void* dv, int B, int H, int W, int C, int pool, int dtype,
-                                     void* stream) {
+static int block_tail_launch(const void* grad_out, const unsigned char* keep_mask, float mask_scale,
+                             const float* mask_scale_dev, const void* raw3,
+                             const float* scale3, const float* shift3, const void* residual, const float* res_scale,
+                             const float* res_shift, void* dv, int B, int H, int W, int C, int pool, int dtype,
+                             const TailStats* st, int* slices, void* stream) {
     SUBREG_CHECK_ARG(grad_out && raw3 && scale3 && shift3 && residual && dv && B > 0 && H > 0 && W > 0 && C > 0);
     hipStream_t s = (hipStream_t)stream;
     const int vec = dtype == SUBREG_BF16 ? 8 : 4;
     SUBREG_CHECK_ARG(C % vec == 0 && C / vec <= 256 && (!pool || (H >= 2 && W >= 2)));
     const long long npo = (long long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
     const int lanes = 256 / (C / vec);
-    long long ppb = (npo + 4095) / 4096;                    // ~4096 blocks, whole rounds of the pixel lanes
+    // ~4096 blocks, whole rounds of the pixel lanes; with the fused statistics at most 512 (a block is a slice of the finalize pass,
+    // whose scratch holds subreg_bn_bwd_slices() of them)
+    long long ppb = (npo + (st ? 511 : 4095)) / (st ? 512 : 4096);
     ppb = (ppb + lanes - 1) / lanes * lanes;
     if (ppb < lanes) ppb = lanes;
     const int grid = (int)((npo + ppb - 1) / ppb);
-#define BTB(TT, P) hipLaunchKernelGGL((block_tail_bwd_kernel<TT, P>), grid, 256, 0, s, (const TT*)grad_out, keep_mask, mask_scale, mask_scale_dev, (const TT*)raw3, \
-                                      scale3, shift3, (const TT*)residual, res_scale, res_shift, (TT*)dv, H, W, C, npo, (int)ppb)
-    DISPATCH_T(dtype, if (pool) BTB(float, true); else BTB(float, false), if (pool) BTB(__bf16, true); else BTB(__bf16, false));
+    const TailStats none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t lds = st ? (size_t)lanes * C * 3 * sizeof(float) : 0;
+#define BTB(TT, P, S) hipLaunchKernelGGL((block_tail_bwd_kernel<TT, P, S>), grid, 256, lds, s, (const TT*)grad_out, keep_mask, mask_scale, mask_scale_dev, (const TT*)raw3, \
+                                      scale3, shift3, (const TT*)residual, res_scale, res_shift, (TT*)dv, H, W, C, npo, (int)ppb, st ? *st : none)
+#define BTB2(TT) if (st) { if (pool) BTB(TT, true, true); else BTB(TT, false, true); } else { if (pool) BTB(TT, true, false); else BTB(TT, false, false); }
+    DISPATCH_T(dtype, BTB2(float), BTB2(__bf16));
+#undef BTB2
 #undef BTB
+    if (slices) *slices = grid;
     return launch_status();
+}
+
+extern "C" int subreg_block_tail_bwd(const void* grad_out, const unsigned char* keep_mask, float mask_scale,
+                                     const float* mask_scale_dev, const void* raw3,
+                                     const float* scale3, const float* shift3, const void* residual, const float* res_scale,
+                                     const float* res_shift, void* dv, int B, int H, int W, int C, int pool, int dtype,
+                                     void* stream) {
+    return block_tail_launch(grad_out, keep_mask, mask_scale, mask_scale_dev, raw3, scale3, shift3, residual, res_scale, res_shift, dv, B, H, W, C,
+                             pool, dtype, nullptr, nullptr, stream);
+}
+
+extern "C" int subreg_block_tail_bwd_stats(const void* grad_out, const unsigned char* keep_mask, float mask_scale,
+                                           const float* mask_scale_dev, const void* raw3,
+                                           const float* scale3, const float* shift3, const void* residual, const float* res_scale,
+                                           const float* res_shift, void* dv, int B, int H, int W, int C, int pool, int dtype,
+                                           const float* mean3, const float* invstd3, double* partial3, const float* mean_d,
+                                           const float* invstd_d, double* partial_d, int* slices, void* stream) {
+    SUBREG_CHECK_ARG(mean3 && invstd3 && partial3 && slices && ((mean_d != nullptr) == (invstd_d != nullptr)) && (!mean_d || partial_d));
+    const TailStats st = {mean3, invstd3, partial3, mean_d, invstd_d, partial_d};
+    return block_tail_launch(grad_out, keep_mask, mask_scale, mask_scale_dev, raw3, scale3, shift3, residual, res_scale, res_shift, dv, B, H, W, C,
+                             pool, dtype, &st, slices, stream);
 }
 
 // slices of the reduce pass + one more slice-sized region of `partial` that holds the apply pass's coefficients
@@ -1166,7 +1240,7 @@ extern "C" int subreg_bn_bwd_slices(long long npix) { (void)npix; return 512 + 1
 // and d(beta) are the same sums over x_hat = (raw - mean) * invstd in both modes
 static int bn_bwd_impl(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
                        const float* gamma, double* partial, float* dgamma, float* dbeta, void* dx, long long npix, int C,
-                       int dtype, bool eval_mode, void* stream);
+                       int dtype, bool eval_mode, void* stream, int pre_slices = 0);
 
 extern "C" int subreg_bn_bwd(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
                              const float* gamma, double* partial, float* dgamma, float* dbeta, void* dx, long long npix, int C,
@@ -1180,9 +1254,16 @@ extern "C" int subreg_bn_bwd_eval(const void* dy, const void* act, const void* r
     return bn_bwd_impl(dy, act, raw, mean, invstd, gamma, partial, dgamma, dbeta, dx, npix, C, dtype, true, stream);
 }
 
+extern "C" int subreg_bn_bwd_partials(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
+                                      const float* gamma, double* partial, int slices, float* dgamma, float* dbeta, void* dx,
+                                      long long npix, int C, int dtype, int eval_mode, void* stream) {
+    SUBREG_CHECK_ARG(slices > 0 && slices < subreg_bn_bwd_slices(npix));
+    return bn_bwd_impl(dy, act, raw, mean, invstd, gamma, partial, dgamma, dbeta, dx, npix, C, dtype, eval_mode != 0, stream, slices);
+}
+
 static int bn_bwd_impl(const void* dy, const void* act, const void* raw, const float* mean, const float* invstd,
                        const float* gamma, double* partial, float* dgamma, float* dbeta, void* dx, long long npix, int C,
-                       int dtype, bool eval_mode, void* stream) {
+                       int dtype, bool eval_mode, void* stream, int pre_slices) {
     SUBREG_CHECK_ARG(dy && raw && mean && invstd && gamma && partial && dgamma && dbeta && dx && npix > 0 && C > 0);
     hipStream_t s = (hipStream_t)stream;
     // at most 512 slices (two per CU): the finalize pass walks every slice of a channel, and at 1764 slices (64 x 84 x 84
@@ -1193,14 +1274,16 @@ static int bn_bwd_impl(const void* dy, const void* act, const void* raw, const f
     const int lanes_ = C / vec_ > 0 && C / vec_ <= 256 ? 256 / (C / vec_) : 1;
     long long pps = (npix + 511) / 512;
     if (pps < 4LL * lanes_) pps = 4LL * lanes_;
-    const int slices = (int)((npix + pps - 1) / pps);                                     // <= 512
+    const int slices = pre_slices > 0 ? pre_slices : (int)((npix + pps - 1) / pps);     // <= 512 (pre_slices: the reduce pass was done by the producer of dy)
     float* const coef = reinterpret_cast<float*>(partial + (size_t)slices * C * 2);     // 3*C floats in the extra slice (4*C)
     const int vec = dtype == SUBREG_BF16 ? 8 : 4;
     SUBREG_CHECK_ARG(C % vec == 0 && C / vec <= 256);
     const size_t lds = (size_t)(256 / (C / vec)) * C * 2 * sizeof(float);
-    DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, slices, 256, lds, s, (const float*)dy, (const float*)act, (const float*)raw, mean, invstd, partial, npix, C, (int)pps),
-               hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, slices, 256, lds, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, partial, npix, C, (int)pps));
+    if (pre_slices <= 0) {
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, slices, 256, lds, s, (const float*)dy, (const float*)act, (const float*)raw, mean, invstd, partial, npix, C, (int)pps),
+                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, slices, 256, lds, s, (const __bf16*)dy, (const __bf16*)act, (const __bf16*)raw, mean, invstd, partial, npix, C, (int)pps));
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, (C + 7) / 8, 256, 0, s, partial, slices, C, mean, invstd, gamma,
                        eval_mode ? 0.0 : 1.0 / (double)npix, dgamma, dbeta, coef);
     long long ppb = (npix + 4095) / 4096;                   // apply pass: ~4096 blocks, whole unrolled rounds of the pixel lanes

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SUBREG_LIB") or os.path.join(_HERE, "libsubreg_hip.so
 F32, BF16 = 0, 1
 CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
 FWD_TRAIN = 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_QUERY_SETS = 32                          # SUBREG_MAX_QUERY_SETS
 
 c_void_p, c_int, c_float, c_longlong = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -109,6 +109,8 @@ SIGNATURES = {
     "subreg_bn_bwd_eval": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "subreg_bn_eval_stash": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P]),
     "subreg_block_tail_bwd": (_I, [_P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "subreg_block_tail_bwd_stats": (_I, [_P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "subreg_bn_bwd_partials": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _I, _P]),
     "subreg_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_sgd_momentum": (_I, [_P, _P, _P, _L, _F, _F, _F, _I, _P]),
     "subreg_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),

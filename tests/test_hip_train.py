@@ -6,6 +6,7 @@ Tolerances: f32 mode - gradients 1e-3 of the tensor's magnitude (the reference i
 B*H*W pixels in fp32), BN/activation gradients 2e-4; bf16 mode - 5e-2 of the tensor's magnitude (activations AND
 gradient tensors are rounded to bf16 between layers) on the gradient norms and the sampled tensors.
 """
+import ctypes as C
 import os
 from types import SimpleNamespace
 
@@ -182,6 +183,67 @@ def test_block_tail_backward(pool, dtype):
     torch.cuda.synchronize()
     tol = 1e-5 if dtype == "f32" else 1e-2
     _cmp("dv", dv.float().cpu().numpy().reshape(B, H, W, Cc), want, tol, tol)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("pool,shortcut_bn", [(1, True), (0, False), (1, False), (0, True)])
+def test_block_tail_with_fused_bn_statistics(pool, shortcut_bn, dtype):
+    """subreg_block_tail_bwd_stats + subreg_bn_bwd_partials (the block tail emits the reduce pass of bn3 and of the shortcut's BatchNorm)
+    against the three separate passes subreg_block_tail_bwd + 2 x subreg_bn_bwd on the same inputs: dV identical, d gamma / d beta / d x of
+    both BatchNorms equal up to the summation order (BasicBlock.forward :288-299 backwards)."""
+    B, H, W, Cc = 3, 10, 12, 160
+    lib = _lib.load()
+    rs = np.random.RandomState(31 + pool + 2 * shortcut_bn)
+    dev = _dev()
+    td = _td(dtype)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev, td)
+    raw3, res = f(rs.standard_normal((B, H, W, Cc))), f(rs.standard_normal((B, H, W, Cc)))
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    gout = f(rs.standard_normal((B, Ho, Wo, Cc)))
+    keep = torch.from_numpy((rs.random_sample((B, Ho, Wo, Cc)) > 0.2).astype(np.uint8)).to(dev)
+    sc, sh, rsc, rsh = (_t(rs.uniform(0.5, 1.5, Cc).astype(np.float32)), _t((rs.standard_normal(Cc) * 0.1).astype(np.float32)),
+                        _t(rs.uniform(0.5, 1.5, Cc).astype(np.float32)), _t((rs.standard_normal(Cc) * 0.1).astype(np.float32)))
+    mean3, inv3, g3 = _t(rs.standard_normal(Cc) * 0.1), _t(rs.uniform(0.5, 2.0, Cc)), _t(rs.uniform(0.5, 1.5, Cc))
+    meand, invd, gd_ = _t(rs.standard_normal(Cc) * 0.1), _t(rs.uniform(0.5, 2.0, Cc)), _t(rs.uniform(0.5, 1.5, Cc))
+    npix, dt = B * H * W, _lib.dtype_code(dtype)
+    nsl = lib.subreg_bn_bwd_slices(npix)
+    part = lambda: torch.zeros(nsl * Cc * 2, dtype=torch.float64, device=dev)
+    new = lambda: torch.full((B * H * W * Cc,), float("nan"), device=dev, dtype=td)
+    vec = lambda: torch.empty(Cc, device=dev)
+    rsc_p, rsh_p = (_lib.ptr(rsc), _lib.ptr(rsh)) if shortcut_bn else (None, None)
+    # separate passes
+    dv_a, dx3_a, dxd_a, pa = new(), new(), new(), part()
+    dg3_a, db3_a, dgd_a, dbd_a = vec(), vec(), vec(), vec()
+    _lib.check(lib.subreg_block_tail_bwd(_lib.ptr(gout), _lib.ptr(keep), 1.25, None, _lib.ptr(raw3), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(res),
+                                         rsc_p, rsh_p, _lib.ptr(dv_a), B, H, W, Cc, pool, dt, _lib.stream_ptr()))
+    _lib.check(lib.subreg_bn_bwd(_lib.ptr(dv_a), None, _lib.ptr(raw3), _lib.ptr(mean3), _lib.ptr(inv3), _lib.ptr(g3), _lib.ptr(pa), _lib.ptr(dg3_a),
+                                 _lib.ptr(db3_a), _lib.ptr(dx3_a), npix, Cc, dt, _lib.stream_ptr()))
+    if shortcut_bn:
+        _lib.check(lib.subreg_bn_bwd(_lib.ptr(dv_a), None, _lib.ptr(res), _lib.ptr(meand), _lib.ptr(invd), _lib.ptr(gd_), _lib.ptr(pa), _lib.ptr(dgd_a),
+                                     _lib.ptr(dbd_a), _lib.ptr(dxd_a), npix, Cc, dt, _lib.stream_ptr()))
+    # fused statistics
+    dv_b, dx3_b, dxd_b, p3, pd = new(), new(), new(), part(), part()
+    dg3_b, db3_b, dgd_b, dbd_b = vec(), vec(), vec(), vec()
+    slices = C.c_int(0)
+    _lib.check(lib.subreg_block_tail_bwd_stats(_lib.ptr(gout), _lib.ptr(keep), 1.25, None, _lib.ptr(raw3), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(res),
+                                               rsc_p, rsh_p, _lib.ptr(dv_b), B, H, W, Cc, pool, dt, _lib.ptr(mean3), _lib.ptr(inv3), _lib.ptr(p3),
+                                               _lib.ptr(meand) if shortcut_bn else None, _lib.ptr(invd) if shortcut_bn else None,
+                                               _lib.ptr(pd) if shortcut_bn else None, C.byref(slices), _lib.stream_ptr()))
+    assert 0 < slices.value < nsl
+    _lib.check(lib.subreg_bn_bwd_partials(_lib.ptr(dv_b), None, _lib.ptr(raw3), _lib.ptr(mean3), _lib.ptr(inv3), _lib.ptr(g3), _lib.ptr(p3), slices.value,
+                                          _lib.ptr(dg3_b), _lib.ptr(db3_b), _lib.ptr(dx3_b), npix, Cc, dt, 0, _lib.stream_ptr()))
+    if shortcut_bn:
+        _lib.check(lib.subreg_bn_bwd_partials(_lib.ptr(dv_b), None, _lib.ptr(res), _lib.ptr(meand), _lib.ptr(invd), _lib.ptr(gd_), _lib.ptr(pd),
+                                              slices.value, _lib.ptr(dgd_b), _lib.ptr(dbd_b), _lib.ptr(dxd_b), npix, Cc, dt, 0, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(dv_a.float(), dv_b.float())
+    tol = 2e-5 if dtype == "f32" else 1e-2
+    pairs = [("dgamma3", dg3_a, dg3_b), ("dbeta3", db3_a, db3_b), ("dx3", dx3_a, dx3_b)]
+    if shortcut_bn:
+        pairs += [("dgamma_d", dgd_a, dgd_b), ("dbeta_d", dbd_a, dbd_b), ("dx_d", dxd_a, dxd_b)]
+    for name, a_, b_ in pairs:
+        a_, b_ = a_.float().cpu().numpy(), b_.float().cpu().numpy()
+        _cmp(name, b_, a_, tol * max(1.0, float(np.abs(a_).max())), tol)
 
 
 def _train_net(dtype):
