@@ -3,11 +3,18 @@
 // mode, on caller-owned workspaces.  Keeping the per-layer orchestration native removes
 // ~25 Python->ctypes round trips per forward and makes the whole forward capturable into
 // one hipGraph by the host side.
+#include <stdlib.h>
 #include <string.h>
 
 #include "subreg_common.h"
 
 namespace {
+
+// images per call from which layer 1's conv1 + conv2 run as the fused kernel (SUBREG_FUSED12_MIN overrides, for measurements)
+int fused12_min_batch() {
+    static const int v = [] { const char* e = getenv("SUBREG_FUSED12_MIN"); return e && *e ? atoi(e) : 192; }();
+    return v;
+}
 
 struct Shape { int h, w; };
 
@@ -160,7 +167,7 @@ extern "C" int subreg_backbone_forward(const subreg_backbone_desc* d, const floa
             // (below ~190 images per call the fused kernel - one workgroup per CU owning the CU's whole LDS - loses to the two
             // launches, whose workgroups share CUs with the other eval lane's kernels: -3 % at 125 images per lane, +0.5 % at 250,
             // +1.2 % at 375; profiles/r03_forward_ab_layer1.txt)
-            if (img_in && b.conv2.cin == 64 && b.conv2.cout == 64 && B >= 192)
+            if (img_in && b.conv2.cin == 64 && b.conv2.cout == 64 && B >= fused12_min_batch())
                 fused = subreg_conv12_first_fused(x_nchw, b.conv1.w_folded, b.conv1.shift, b.conv2.w_folded, b.conv2.shift, Bf, B, h, w,
                                                   SUBREG_CONV_LRELU, dt, stream);
             if (fused != SUBREG_OK) {
