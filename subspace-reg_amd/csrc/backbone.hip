@@ -12,7 +12,7 @@ namespace {
 
 // images per call from which layer 1's conv1 + conv2 run as the fused kernel (SUBREG_FUSED12_MIN overrides, for measurements)
 int fused12_min_batch() {
-    static const int v = [] { const char* e = getenv("SUBREG_FUSED12_MIN"); return e && *e ? atoi(e) : 192; }();
+    static const int v = [] { const char* e = getenv("SUBREG_FUSED12_MIN"); return e && *e ? atoi(e) : 1; }();
     return v;
 }
 
@@ -164,9 +164,9 @@ extern "C" int subreg_backbone_forward(const subreg_backbone_desc* d, const floa
             const bool img_in = direct && i == 0;
             // layer 1 from the image: conv1 + conv2 in one launch where the fused kernel takes the shape, else conv1 by itself
             int fused = SUBREG_EUNSUPPORTED;
-            // (below ~190 images per call the fused kernel - one workgroup per CU owning the CU's whole LDS - loses to the two
-            // launches, whose workgroups share CUs with the other eval lane's kernels: -3 % at 125 images per lane, +0.5 % at 250,
-            // +1.2 % at 375; profiles/r03_forward_ab_layer1.txt)
+            // (round 3's fused kernel lost to the two launches below ~190 images per call and was gated on that; since its round-4
+            // rework it wins at every batch: +1-2 % on the whole forward at 8-32 images, +5-12 % at 64-100, +3-4.5 % on two-lane
+            // forwards of 130-380 images; profiles/r04_forward_fused12_threshold.txt)
             if (img_in && b.conv2.cin == 64 && b.conv2.cout == 64 && B >= fused12_min_batch())
                 fused = subreg_conv12_first_fused(x_nchw, b.conv1.w_folded, b.conv1.shift, b.conv2.w_folded, b.conv2.shift, Bf, B, h, w,
                                                   SUBREG_CONV_LRELU, dt, stream);
