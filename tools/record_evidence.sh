@@ -15,7 +15,8 @@ G="grep -v amdgpu.ids"
 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 SUBREG_EVAL_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_bench -o b -- python3 $R/bench.py --no-cpu-baseline --sweep-seeds 0 --no-extra-legs > $O/bench_lanes1.json 2> /dev/null
 f=$(find /tmp/ev_bench -name "*kernel_stats.csv" | head -1); cut -c1-140 "$f" > $O/kernel_stats.csv
-f=$(find /tmp/ev_bench -name "*kernel_trace.csv" | head -1); python3 $R/tools/prof_summary.py "$f" --top 25 --conv > $O/kernel_summary.txt 2>&1
+# (--images: the 559 000 images of the 8 timed steps + the 27 000 of the warm-up episode, which the trace contains as well)
+f=$(find /tmp/ev_bench -name "*kernel_trace.csv" | head -1); python3 $R/tools/prof_summary.py "$f" --top 25 --conv --images 586000 > $O/kernel_summary.txt 2>&1
 # --- per-layer conv table (HIP events, random data, 20 back-to-back launches per layer)
 for b in 256 700 1125; do python3 $R/tools/bench_conv.py --batch $b 2>&1 | $G > $O/conv_layers_b$b.txt; done
 python3 $R/tools/bench_conv.py --batch 700 --unfused --only L1 2>&1 | $G > $O/conv_l1_unfused_b700.txt
