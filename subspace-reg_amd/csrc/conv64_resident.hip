@@ -30,6 +30,9 @@ namespace subreg {
 #ifndef R64_FUSED_STAGGER
 #define R64_FUSED_STAGGER 1     // conv64_fused_first_kernel: waves 4-7 run conv1 of the next tile AFTER their conv2 chunks (0: all waves first)
 #endif
+#ifndef R64_SPLIT_STAGE
+#define R64_SPLIT_STAGE 0       // conv64_resident_kernel: 1 = waves 4-7 stage their chunk-0 pieces of the next tile behind the mid barrier (measured: no effect, profiles/r04_ab_l1_young_prio.txt)
+#endif
 #ifndef R64_YOUNG_PRIO
 #define R64_YOUNG_PRIO 0        // conv64_resident_kernel: s_setprio of waves 4-7 for the whole kernel (measured: see profiles/r04_ab_l1_young_prio.txt)
 #endif
@@ -348,7 +351,10 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
         int nb = 0, nk = 0, nh = 0, ns0 = 0;
         if (more) {
             tile_geom(tn, nb, nk, nh, ns0);
-            stage(lds_base + pf * PLANE, 0, nb, nh);               // next tile's chunk 0 -> the free plane
+            // next tile's chunk 0 -> the free plane: waves 0-3 stage their pieces here, waves 4-7 theirs behind the mid barrier
+            // (R64_SPLIT_STAGE): a wave stalls ~100 cycles per piece while eight waves stage at once, and with both waves of a SIMD
+            // in the same phase nothing runs under that; split, one half's MFMAs run under the other half's DMA issue
+            if (!R64_SPLIT_STAGE || wid < 4) stage(lds_base + pf * PLANE, 0, nb, nh);
         }
         if (POOL) {
             // GEMM row j = window s0 + j / 4 counted from the start of the tile's first row pair, pixel j % 4 of that window
@@ -422,6 +428,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
         if (more) {
             if (IMG) img_load(nb, nh);                              // (ordinary loads first: the compiler's wait for them must not
                                                                     // cover the DMAs below, which are issued AFTER them)
+            if (R64_SPLIT_STAGE && wid >= 4) stage(lds_base + pf * PLANE, 0, nb, nh);
             stage(lds_base + p0 * PLANE, 1, nb, nh);                // next tile's chunk 1 -> the plane chunk 0 just left
             if (SC && !IMG) stage(lds_base + X_BASE, 2, nb, nh);
         }
