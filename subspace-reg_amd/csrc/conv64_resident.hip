@@ -521,6 +521,241 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_resident_kernel(const C
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// conv3 of layer1.0 (3x3, 64 -> 64, + the 1x1 shortcut from the image + MaxPool2d(2), eval mode) re-cut after the fused kernel below:
+// conv64_resident_kernel<true, true, 6, true> runs its eight waves in lockstep - patch staging (22 LDS-DMA pieces per wave and tile at ~100
+// cycles of issue each), two barriers, epilogue: 51 % of a tile with the matrix pipe idle (in-kernel stamps, profiles/r04_ab_l1_conv3_stage.txt).
+// Here:  * the image's three channels live in a compact [block][column][c0 c1 c2 0] bf16 patch (8 B per pixel, double-buffered, 6 KB) instead
+//          of slot 0 of a fourth 36 KB plane; the freed LDS holds a FOURTH conv plane: two plane PAIRS (this tile's, the next tile's), so
+//          the next tile's two chunks are staged any time during this tile and the tile has ONE barrier;
+//        * the two waves of a SIMD stage at opposite ends of the tile: waves 0-3 issue their pieces first, waves 4-7 between their chunks
+//          and their epilogue - one half's MFMAs run under the other half's DMA issue; the chunks run at a raised issue priority.
+// Same tiles (63 windows = 1.5 row pairs, two alternating geometries), planes, swizzle, register-resident weights, chunk loop and pooled
+// slab epilogue as conv64_resident_kernel.
+constexpr int R64_PI_PLANE = 6 * R64_P * R64_ROWB, R64_PI_IMGB = 4 * R64_P * 8, R64_PI_SLAB = 8 * (32 * 2 + 16);
+constexpr int R64_PI_LDS = 4 * R64_PI_PLANE + 2 * R64_PI_IMGB + R64_NW * R64_PI_SLAB + 256;
+static_assert(R64_PI_LDS <= 160 * 1024, "LDS budget");
+__global__ __launch_bounds__(R64_NW * 64, 2) void conv64_pool_img_kernel(const Conv64Args a) {
+    constexpr int P = R64_P, BLOCKS = 6, PROWS = BLOCKS * P, PLANE = R64_PI_PLANE, PIECES = PROWS / 16, PPB = P / 16;
+    constexpr int NPK = (PIECES + R64_NW - 1) / R64_NW;
+    constexpr int SLAB_RS = 32 * 2 + 16, SLAB = R64_PI_SLAB, IMGB = R64_PI_IMGB;
+    constexpr int IMG_BASE = 4 * PLANE, SLAB_BASE = IMG_BASE + 2 * IMGB, SHIFT_BASE = SLAB_BASE + R64_NW * SLAB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wh = wid & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = (nwg + 7 - xcd) >> 3;
+    const int per = (a.ntiles + 7) >> 3;
+    const int t_begin = xcd * per + slot, t_end = min((xcd + 1) * per, a.ntiles);
+    if (t_begin >= t_end) return;
+
+    uint4 bw[2][9][2];
+    {
+        const char* wl = a.w + (size_t)(32 * wh + lr) * R64_ROWB + lh * 16;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    bw[c][t][s] = *reinterpret_cast<const uint4*>(wl + (size_t)((t * 2 + c) * 64) * R64_ROWB + s * 32);
+    }
+    // shortcut: the packed 1x1 weights of the first layer sit at k = 12..14 of their row; the compact patch carries the channels at k = 0..2
+    uint4 bw2;
+    {
+        const unsigned short* wr = reinterpret_cast<const unsigned short*>(a.w2 + (size_t)(32 * wh + lr) * R64_ROWB);
+        const unsigned w12 = wr[12], w13 = wr[13], w14 = wr[14];
+        bw2 = lh == 0 ? make_uint4(w12 | (w13 << 16), w14, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    for (int o = tid * 16; o < SLAB_BASE; o += R64_NW * 64 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
+    float* const s_shift = reinterpret_cast<float*>(smem + SHIFT_BASE);
+    if (tid < 64) s_shift[tid] = a.shift[tid];
+    __syncthreads();
+
+    const int prl = lane >> 2, psl = lane & 3;
+    unsigned goff[NPK];
+    unsigned long long dmask[NPK];
+#pragma unroll
+    for (int k = 0; k < NPK; ++k) {
+        const int q = wid + R64_NW * k, idx = q * 16 + prl, rb = q / PPB, c = idx - rb * P;
+        dmask[k] = __ballot(q < PIECES && c >= 1 && c <= a.W);
+        goff[k] = (unsigned)(rb * a.W + c - 1) * 128u + ((unsigned)(psl ^ swz<4>(idx)) << 4);
+    }
+    // both 32-channel chunks of the patch whose block 0 is image row h_first of image b -> plane pair `pair`
+    auto stage_pair = [&](int pair, int b, int h_first) {
+        const long long origin = ((long long)b * a.H + h_first) * a.W;
+        const unsigned dst = lds_base + 2 * pair * PLANE;
+        if (h_first >= 0 && h_first + BLOCKS <= a.H) {                  // every block inside the image: no per-piece decisions
+            const char* const src = a.x + origin * 128;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int k = 0; k < NPK; ++k) {
+                    const int q = wid + R64_NW * k;
+                    if (q < PIECES && dmask[k]) dma16_masked(src + c * 64, goff[k], dst + c * PLANE + q * 1024, dmask[k]);
+                }
+            return;
+        }
+        const char* const zero = reinterpret_cast<const char*>(r64_zero_line);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < NPK; ++k) {
+                const int q = wid + R64_NW * k;
+                if (q < PIECES) {
+                    const int h = h_first + q / PPB;
+                    if ((dmask[k] >> lane) & 1ull) {
+                        if (h < 0 || h >= a.H) dma16(zero, (unsigned)psl << 4, dst + c * PLANE + q * 1024);
+                        else dma16(a.x + origin * 128 + c * 64, goff[k], dst + c * PLANE + q * 1024);
+                    }
+                }
+            }
+    };
+    // the image under the tile's four non-halo blocks: thread (block ib, column ix) loads its pixel's three channels ...
+    const int ib = tid >> 7, ix = tid & 127;
+    float iv[3] = {0.f, 0.f, 0.f};
+    auto img_load = [&](int b, int h_first) {
+        const int h = h_first + 1 + ib;
+        const bool ok = ix < a.W && h >= 0 && h < a.H;
+        const size_t plane = (size_t)a.H * a.W;
+        const float* p = a.img + (size_t)b * 3 * plane + (size_t)(ok ? h : 0) * a.W + (ok ? ix : 0);
+        const float v0 = p[0], v1 = p[plane], v2 = p[2 * plane];
+        iv[0] = ok ? v0 : 0.f; iv[1] = ok ? v1 : 0.f; iv[2] = ok ? v2 : 0.f;
+    };
+    // ... and writes them as [c0 c1 c2 0] bf16 into compact patch `buf`
+    auto img_store = [&](int buf) {
+        if (ix < a.W)
+            *reinterpret_cast<uint2*>(smem + IMG_BASE + buf * IMGB + (ib * P + ix) * 8) = make_uint2(r64_pack(iv[0], iv[1]), r64_pack(iv[2], 0.f));
+    };
+
+    unsigned areg[2][3][2], ioff[2];
+    auto set_addresses = [&](int i, int hrel, int w) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int row = hrel * P + w + dx;
+            const unsigned ad = (unsigned)row * R64_ROWB + 16u * (lh ^ swz<4>(row));
+            areg[i][dx][0] = ad;
+            areg[i][dx][1] = ad ^ 32u;
+        }
+        ioff[i] = (unsigned)(hrel * P + w) * 8u;                      // the pixel itself in the compact image patch
+    };
+    auto tile_geom = [&](int t, int& b, int& k_img, int& h_first, int& s0) {
+        const int bb = (int)fdiv((unsigned)t, a.d_tpi), k = t - bb * a.tpi;
+        b = __builtin_amdgcn_readfirstlane(bb);
+        k_img = __builtin_amdgcn_readfirstlane(k);
+        const int win0 = k_img * a.WT, rp0 = (int)fdiv((unsigned)win0, a.d_wp);
+        h_first = __builtin_amdgcn_readfirstlane(2 * rp0 - 1);
+        s0 = __builtin_amdgcn_readfirstlane(win0 - rp0 * a.Wp);
+    };
+
+    int t = t_begin, b, k_img, h_first, s0;
+    tile_geom(t, b, k_img, h_first, s0);
+    img_load(b, h_first);
+    stage_pair(0, b, h_first);
+    img_store(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int it = 0; t < t_end; ++it, t += nslot) {
+        const int pp = it & 1;
+        const int tn = t + nslot;
+        const bool more = tn < t_end;
+        int nb = 0, nk = 0, nh = 0, ns0 = 0;
+        if (more) {
+            tile_geom(tn, nb, nk, nh, ns0);
+            if (wid < 4) {                                              // (ordinary loads first: the compiler's wait for them must not
+                img_load(nb, nh);                                       //  cover the DMAs, which are issued AFTER them)
+                stage_pair(pp ^ 1, nb, nh);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = wm * 64 + i * 32 + lr, wq = s0 + (j >> 2), sub = j & 3;
+            const int rp = wq >= a.Wp ? 1 : 0, wp = wq - (wq >= 2 * a.Wp ? 2 : rp) * a.Wp;
+            set_addresses(i, 2 * rp + (sub >> 1), 2 * wp + (sub & 1));
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        auto chunk = [&](int pl, auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int NRD = 36, RD = R64_DEPTH;
+            unsigned ta[2][3][2];
+            const unsigned pb = lds_base + pl * PLANE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) ta[i][dx][s] = areg[i][dx][s] + pb;
+            u32x4 ring[RD];
+            auto rd = [&](auto jc) {
+                constexpr int j = decltype(jc)::value, tt = j >> 2, s = (j >> 1) & 1, i = j & 1, dy = tt / 3, dx = tt % 3;
+                ring[j % RD] = lds_read16<dy * P * R64_ROWB>(ta[i][dx][s]);
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            static_for<0, RD - 1>(rd);
+            static_for<0, NRD>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (j + RD - 1 < NRD) rd(std::integral_constant<int, j + RD - 1>{});
+                constexpr int left = NRD - 1 - j;
+                u32x4 f = ring[j % RD];
+                f = lds_wait<(left >= RD - 1 ? RD - 1 : left)>(f);
+                acc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f),
+                                                                      __builtin_bit_cast(bf16x8, bw[c][j >> 2][(j >> 1) & 1]), acc[j & 1], 0, 0, 0);
+            });
+        };
+        {   // shortcut GEMM: one k-step from the compact patch (every lane reads its pixel: the k = 8..15 lanes meet zero weights)
+            const uint2 p0 = *reinterpret_cast<const uint2*>(smem + IMG_BASE + pp * IMGB + ioff[0]);
+            const uint2 p1 = *reinterpret_cast<const uint2*>(smem + IMG_BASE + pp * IMGB + ioff[1]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, make_uint4(p0.x, p0.y, 0u, 0u)), __builtin_bit_cast(bf16x8, bw2), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, make_uint4(p1.x, p1.y, 0u, 0u)), __builtin_bit_cast(bf16x8, bw2), acc[1], 0, 0, 0);
+        }
+        if (wid >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
+        chunk(2 * pp, std::integral_constant<int, 0>{});
+        chunk(2 * pp + 1, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+        if (more && wid >= 4) {                                         // the later half stages here: its DMAs fly under its epilogue
+            img_load(nb, nh);
+            stage_pair(pp ^ 1, nb, nh);
+        }
+        // ---- epilogue: + shift, (2x2 max), LeakyReLU, bf16, through this wave's LDS slab, 16-byte stores (as conv64_resident_kernel)
+        char* const slab = smem + SLAB_BASE + wid * SLAB;
+        const float sh = s_shift[32 * wh + lr];
+        const int win0 = k_img * a.WT, left = a.nwin - win0, nv = left < a.WT ? left : a.WT;
+        const long long out0 = (long long)b * a.nwin + win0;
+        const bool ragged = nv <= 56;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int wrow0 = (wm * 64 + i * 32) >> 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float best = fmaxf(fmaxf(acc[i][4 * q], acc[i][4 * q + 1]), fmaxf(acc[i][4 * q + 2], acc[i][4 * q + 3])) + sh;
+                if (a.act) best = fmaxf(best, best * 0.1f);
+                *reinterpret_cast<__bf16*>(slab + (2 * q + lh) * SLAB_RS + lr * 2) = (__bf16)best;
+            }
+            const int row = lane >> 2, c16 = lane & 3;
+            if (lane < 32) {
+                const uint4 val = *reinterpret_cast<const uint4*>(slab + row * SLAB_RS + c16 * 16);
+                if (wrow0 + row < nv)
+                    *reinterpret_cast<uint4*>(a.y + (size_t)(out0 + wrow0 + row) * 128 + wh * 64 + c16 * 16) = val;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's DMAs are older than the epilogue's two store instructions (fewer where a ragged tile skipped them: wait for all)
+        if (ragged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (more) img_store(pp ^ 1);
+        __syncthreads();                                                // the next tile's planes and image patch are complete; this tile's are free
+        b = nb; k_img = nk; h_first = nh; s0 = ns0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // conv1 -> conv2 of layer1.0 in ONE kernel (models/resnet_language.py:249-253: conv3x3(3 -> 64) + BN + LeakyReLU, then
 // conv3x3(64 -> 64) + BN + LeakyReLU, eval mode): the 64-channel intermediate never leaves the chip.  The resident kernel above
 // stages, per tile of 3 image rows, the 5 rows x W pixels x 64 channels of conv1's OUTPUT from HBM (128 B per pixel written by
@@ -1320,7 +1555,21 @@ int conv64_resident(const void* x, const void* w, void* y, const float* shift, c
     a.tpi = (a.nwin + wt - 1) / wt;
     a.ntiles = B * a.tpi;
     a.d_tpi = make_fastdiv(a.tpi);
-    if (img) return launch_r64<true, true, 6, true>(a, stream);
+    if (img) {
+        static const bool old_on = [] { const char* e = getenv("SUBREG_L1_CONV3_OLD"); return e && e[0] == '1'; }();   // A/B switch
+        if (old_on) return launch_r64<true, true, 6, true>(a, stream);
+        static std::atomic<unsigned long long> lds_set{0};
+        if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv64_pool_img_kernel), R64_PI_LDS, lds_set)) return rc;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        int grid = cus < a.ntiles ? cus : a.ntiles;
+        grid = (grid + 7) / 8 * 8;
+        hipLaunchKernelGGL(conv64_pool_img_kernel, dim3(grid), dim3(R64_NW * 64), R64_PI_LDS, stream, a);
+        return launch_status();
+    }
     return x2 ? launch_r64<true, true, 6>(a, stream) : launch_r64<true, false, 6>(a, stream);
 }
 
