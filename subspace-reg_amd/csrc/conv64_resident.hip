@@ -30,6 +30,12 @@ namespace subreg {
 #ifndef R64_FUSED_STAGGER
 #define R64_FUSED_STAGGER 1     // conv64_fused_first_kernel: waves 4-7 run conv1 of the next tile AFTER their conv2 chunks (0: all waves first)
 #endif
+#ifndef R64_PI_STAGGER
+#define R64_PI_STAGGER 1        // conv64_pool_img_kernel: waves 4-7 stage the next tile between their chunks and their epilogue (0: all waves first)
+#endif
+#ifndef R64_PI_PRIO
+#define R64_PI_PRIO 1           // conv64_pool_img_kernel: s_setprio around the chunks
+#endif
 #ifndef R64_SPLIT_STAGE
 #define R64_SPLIT_STAGE 0       // conv64_resident_kernel: 1 = waves 4-7 stage their chunk-0 pieces of the next tile behind the mid barrier (measured: no effect, profiles/r04_ab_l1_young_prio.txt)
 #endif
@@ -582,35 +588,27 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_pool_img_kernel(const C
         dmask[k] = __ballot(q < PIECES && c >= 1 && c <= a.W);
         goff[k] = (unsigned)(rb * a.W + c - 1) * 128u + ((unsigned)(psl ^ swz<4>(idx)) << 4);
     }
-    // both 32-channel chunks of the patch whose block 0 is image row h_first of image b -> plane pair `pair`
+    // both 32-channel chunks of the patch whose block 0 is image row h_first of image b -> plane pair `pair`: one masked DMA statement per
+    // piece and chunk; a block outside the image (first / last tile of an image) reads the zero line instead - a scalar select, no second
+    // code path (two paths at three call sites cost 52 spilled SGPRs, read back by v_readlane inside the staging code)
+    const unsigned zoff = (unsigned)psl << 4;
     auto stage_pair = [&](int pair, int b, int h_first) {
         const long long origin = ((long long)b * a.H + h_first) * a.W;
-        const unsigned dst = lds_base + 2 * pair * PLANE;
-        if (h_first >= 0 && h_first + BLOCKS <= a.H) {                  // every block inside the image: no per-piece decisions
-            const char* const src = a.x + origin * 128;
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int k = 0; k < NPK; ++k) {
-                    const int q = wid + R64_NW * k;
-                    if (q < PIECES && dmask[k]) dma16_masked(src + c * 64, goff[k], dst + c * PLANE + q * 1024, dmask[k]);
-                }
-            return;
-        }
+        const char* const src = a.x + origin * 128;
         const char* const zero = reinterpret_cast<const char*>(r64_zero_line);
+        const unsigned dst = lds_base + 2 * pair * PLANE;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int k = 0; k < NPK; ++k) {
-                const int q = wid + R64_NW * k;
-                if (q < PIECES) {
-                    const int h = h_first + q / PPB;
-                    if ((dmask[k] >> lane) & 1ull) {
-                        if (h < 0 || h >= a.H) dma16(zero, (unsigned)psl << 4, dst + c * PLANE + q * 1024);
-                        else dma16(a.x + origin * 128 + c * 64, goff[k], dst + c * PLANE + q * 1024);
-                    }
-                }
+        for (int k = 0; k < NPK; ++k) {
+            const int q = wid + R64_NW * k;
+            if (q < PIECES && dmask[k]) {                               // wave-uniform
+                const int h = h_first + q / PPB;
+                const bool inside = h >= 0 && h < a.H;                  // wave-uniform: a block is in or out of the image
+                const char* const s0 = inside ? src : zero;
+                const unsigned vo = inside ? goff[k] : zoff;
+                dma16_masked(s0, vo, dst + q * 1024, dmask[k]);
+                dma16_masked(inside ? s0 + 64 : s0, vo, dst + PLANE + q * 1024, dmask[k]);
             }
+        }
     };
     // the image under the tile's four non-halo blocks: thread (block ib, column ix) loads its pixel's three channels ...
     const int ib = tid >> 7, ix = tid & 127;
@@ -657,14 +655,21 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_pool_img_kernel(const C
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+#if R64_DIAG
+    unsigned long long dq = __builtin_amdgcn_s_memtime(), dt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long d_c0 = dq, d_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int it = 0; t < t_end; ++it, t += nslot) {
         const int pp = it & 1;
         const int tn = t + nslot;
+#if R64_DIAG
+        dt[0] += 1;
+#endif
         const bool more = tn < t_end;
         int nb = 0, nk = 0, nh = 0, ns0 = 0;
         if (more) {
             tile_geom(tn, nb, nk, nh, ns0);
-            if (wid < 4) {                                              // (ordinary loads first: the compiler's wait for them must not
+            if (wid < 4 || !R64_PI_STAGGER) {                           // (ordinary loads first: the compiler's wait for them must not
                 img_load(nb, nh);                                       //  cover the DMAs, which are issued AFTER them)
                 stage_pair(pp ^ 1, nb, nh);
             }
@@ -675,6 +680,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_pool_img_kernel(const C
             const int rp = wq >= a.Wp ? 1 : 0, wp = wq - (wq >= 2 * a.Wp ? 2 : rp) * a.Wp;
             set_addresses(i, 2 * rp + (sub >> 1), 2 * wp + (sub & 1));
         }
+        R64_STAMP(1);
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -714,15 +720,18 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_pool_img_kernel(const C
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, make_uint4(p0.x, p0.y, 0u, 0u)), __builtin_bit_cast(bf16x8, bw2), acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, make_uint4(p1.x, p1.y, 0u, 0u)), __builtin_bit_cast(bf16x8, bw2), acc[1], 0, 0, 0);
         }
-        if (wid >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
+        if (R64_PI_PRIO) { if (wid >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
         chunk(2 * pp, std::integral_constant<int, 0>{});
+        R64_STAMP(2);
         chunk(2 * pp + 1, std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(0);
-        if (more && wid >= 4) {                                         // the later half stages here: its DMAs fly under its epilogue
+        if (R64_PI_PRIO) __builtin_amdgcn_s_setprio(0);
+        R64_STAMP(3);
+        if (R64_PI_STAGGER && more && wid >= 4) {                                         // the later half stages here: its DMAs fly under its epilogue
             img_load(nb, nh);
             stage_pair(pp ^ 1, nb, nh);
         }
+        R64_STAMP(4);
         // ---- epilogue: + shift, (2x2 max), LeakyReLU, bf16, through this wave's LDS slab, 16-byte stores (as conv64_resident_kernel)
         char* const slab = smem + SLAB_BASE + wid * SLAB;
         const float sh = s_shift[32 * wh + lr];
@@ -747,12 +756,25 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_pool_img_kernel(const C
         }
         __builtin_amdgcn_sched_barrier(0);
         // this wave's DMAs are older than the epilogue's two store instructions (fewer where a ragged tile skipped them: wait for all)
+        R64_STAMP(5);
         if (ragged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        R64_STAMP(6);
         if (more) img_store(pp ^ 1);
         __syncthreads();                                                // the next tile's planes and image patch are complete; this tile's are free
+        R64_STAMP(7);
         b = nb; k_img = nk; h_first = nh; s0 = ns0;
     }
+#if R64_DIAG
+    if (lane == 0 && blockIdx.x * R64_NW + wid < 4096) {
+        // [tiles, staging (waves 0-3) + addresses, chunk 0, chunk 1, staging (waves 4-7), epilogue, DMA wait, barrier, -, -, -, GHz]
+        float* d = r64_diag + (size_t)(blockIdx.x * R64_NW + wid) * 12;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = (float)dt[k];
+        d[8] = d[9] = d[10] = 0.f;
+        d[11] = (float)(__builtin_amdgcn_s_memtime() - d_c0) / (float)(__builtin_amdgcn_s_memrealtime() - d_r0) * 0.1f;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -39,6 +39,31 @@ def fused(lib, raw, dev, B):
               ", ".join("%s %.0f" % (n, v) for n, v in zip(names, per)))
 
 
+def conv3(lib, raw, dev, B):
+    """conv64_pool_img_kernel (layer 1 conv3 + image shortcut + pool): cycles per tile and wave by phase, waves 0-3 and 4-7 apart."""
+    H = 84
+    img = torch.randn(B, 3, H, H, device=dev)
+    x = torch.randn(B * H * H, 64, device=dev).to(torch.bfloat16)
+    w = (torch.randn(64, 9, 64, device=dev) / 24).to(torch.bfloat16)
+    w2 = (torch.randn(64, 32, device=dev) / 6).to(torch.bfloat16)
+    shift = torch.randn(64, device=dev)
+    y = torch.empty(B * (H // 2) * (H // 2), 64, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        _lib.check(lib.subreg_conv_fwd_image_shortcut(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), _lib.ptr(shift), _lib.ptr(img), _lib.ptr(w2), B, H, H, 64, 64,
+                                                      _lib.CONV_LRELU | _lib.CONV_POOL2, _lib.BF16, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    out = np.zeros(4096 * 12, np.float32)
+    assert raw.subreg_r64_diag_read(out.ctypes.data_as(C.c_void_p), out.size) == 0
+    d = out.reshape(-1, 8, 12)
+    d = d[d[:, 0, 0] > 0]
+    names = ["staging (first) + addresses", "chunk 0", "chunk 1", "staging (after)", "epilogue", "DMA wait", "barrier"]
+    for grp, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
+        g = d[:, sl, :].reshape(-1, 12)
+        per = np.median(g[:, 1:8] / g[:, :1], axis=0)
+        print("conv3 + image shortcut + pool B=%d %s: tiles/wave %.1f, clock %.2f GHz, cycles per tile %.0f = " % (B, grp, np.median(g[:, 0]), np.median(g[:, 11]), per.sum()) +
+              ", ".join("%s %.0f" % (n, v) for n, v in zip(names, per)))
+
+
 def main():
     lib = _lib.load()
     raw = C.CDLL(_lib.LIB_PATH)
@@ -46,6 +71,8 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     if "--fused" in sys.argv:
         return fused(lib, raw, dev, B)
+    if "--conv3" in sys.argv:
+        return conv3(lib, raw, dev, B)
     for pool, sc in ((False, False), (True, True)):
         H = 84
         x = torch.randn(B * H * H, 64, device=dev).to(torch.bfloat16)
