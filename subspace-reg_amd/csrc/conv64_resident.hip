@@ -42,6 +42,9 @@ namespace subreg {
 #ifndef R64_YOUNG_PRIO
 #define R64_YOUNG_PRIO 0        // conv64_resident_kernel: s_setprio of waves 4-7 for the whole kernel (measured: see profiles/r04_ab_l1_young_prio.txt)
 #endif
+#ifndef R64_FUSED_CONV1_HALF
+#define R64_FUSED_CONV1_HALF 0  // conv64_fused_first_kernel, experiment: 1 = waves 0-3 compute ALL of conv1 (before their chunks), waves 4-7 none
+#endif
 #ifndef R64_FUSED_ROLL
 #define R64_FUSED_ROLL 1        // conv64_fused_first_kernel: conv1 computes 3 new rows per tile and copies the 2 it shares with the tile above
 #endif
@@ -931,7 +934,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
     auto conv1_groups = [&](int k_img, int pp, int buf, int rb0, auto edge_c) {
         constexpr bool EDGE = decltype(edge_c)::value;
         const int npx = (BLOCKS - rb0) * W;                             // blocks rb0 .. 4 (rb0 = 2: the three rows a rolling tile adds)
-        for (int g0 = wid * 32; g0 < npx; g0 += R64_NW * 32) {
+        for (int g0 = (R64_FUSED_CONV1_HALF ? wid & 3 : wid) * 32; g0 < npx; g0 += (R64_FUSED_CONV1_HALF ? 4 : R64_NW) * 32) {
             const int p = g0 + lr;
             const bool valid = p < npx;
             const int rbl = valid ? (int)fdiv((unsigned)p, a.d_w) : 0, x = valid ? p - rbl * W : 0, rb = rb0 + rbl;
@@ -976,7 +979,8 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
         const int rb0 = roll ? 2 : 0;
         if (roll) {
             constexpr int SPAN = 2 * P * R64_ROWB;                      // two blocks of one plane
-            for (int o = tid * 16; o < 2 * SPAN; o += R64_NW * 64 * 16) {
+            constexpr int CPT = R64_FUSED_CONV1_HALF ? 256 : R64_NW * 64;   // threads that take part (the waves that run conv1)
+            for (int o = (tid & (CPT - 1)) * 16; o < 2 * SPAN; o += CPT * 16) {
                 const int c = o >= SPAN ? 1 : 0, off = o - c * SPAN;
                 *reinterpret_cast<uint4*>(smem + (2 * pp + c) * PLANE + off) =
                     *reinterpret_cast<const uint4*>(smem + (2 * (pp ^ 1) + c) * PLANE + 3 * P * R64_ROWB + off);
@@ -1123,7 +1127,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void conv64_fused_first_kernel(cons
         }
         __builtin_amdgcn_sched_barrier(0);
         R64_STAMP(4);
-        if (R64_CUT != 3 && R64_FUSED_STAGGER && more && wid >= 4) conv1_tile(nk, pp ^ 1, pp ^ 1, roll);
+        if (R64_CUT != 3 && R64_FUSED_STAGGER && !R64_FUSED_CONV1_HALF && more && wid >= 4) conv1_tile(nk, pp ^ 1, pp ^ 1, roll);
         R64_STAMP(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's patch row of tile t + 2 landed (and its stores are out)
         R64_STAMP(6);
