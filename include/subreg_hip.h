@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUBREG_ABI_VERSION 12
+#define SUBREG_ABI_VERSION 13
 
 #define SUBREG_OK 0
 #define SUBREG_EINVAL (-1)       /* bad argument (null pointer, shape not supported by contract) */
@@ -41,6 +41,10 @@ extern "C" {
 #define SUBREG_CONV_LRELU 1     /* nn.LeakyReLU(0.1), models/resnet_language.py:251 */
 #define SUBREG_CONV_POOL2 2     /* nn.MaxPool2d(2) floor mode, :256,290 */
 #define SUBREG_CONV_RAW_STATS 4 /* train mode: raw conv output + per-channel (sum,sumsq) partials */
+/* kernel selection of subreg_conv_fwd for Cout % 160 == 0 (default: a measured rule): force the general kernel (conv_fwd.hip) or the
+ * one-wave-per-SIMD kernel (conv_wide.hip; SUBREG_EUNSUPPORTED where it does not take the problem).  Parity tests and A/B runs. */
+#define SUBREG_CONV_KERNEL_GENERAL 256
+#define SUBREG_CONV_KERNEL_WIDE 512
 
 /* flags of subreg_backbone_forward */
 #define SUBREG_FWD_TRAIN 1 /* BN batch statistics + running-stat update + keep masks (net.train(), eval/language_eval.py:211) */

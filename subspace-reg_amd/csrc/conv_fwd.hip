@@ -27,6 +27,7 @@
 
 #include <type_traits>
 
+#include "conv_args.h"
 #include "conv_index.h"
 #include "subreg_common.h"
 
@@ -74,23 +75,6 @@ template <typename T> constexpr int mfma_tile(int NI, int NJ) {
     return (SUBREG_BF16_MFMA16 && sizeof(T) == 2 && (NI == 1 || SUBREG_BF16_MFMA16 >= 2) && NJ == 5) ? 16 : 32;   // (2: measurement builds)
 }
 
-struct ConvArgs {
-    const char* x;       // [npix][Cin] T
-    const char* w;       // [taps][Cin/32][Cout][32] T
-    const char* x2;      // fused shortcut GEMM: [npix][Cin2] T (centre tap only) or null
-    const char* w2;      // [Cin2/32][Cout][32] T
-    char* y;             // LINEAR [npix][Cout] T ; POOL [B*Hp*Wp][Cout] T
-    const float* scale;  // [Cout] or null (scale folded into the weights)
-    const float* shift;  // [Cout]
-    const char* res;     // [npix][Cout] T residual or null
-    float* stats;        // raw: [m_tiles*WAVES_M][Cout][2] partial (sum, sumsq)
-    ConvGeom g;
-    int Cin, Cin2, Cout;
-    int act;             // LeakyReLU(0.1) after scale/shift/residual
-    int raw;             // write the un-normalised conv + stats partials
-    float* part;         // SPLITK kernels: fp32 partial sums [ksplit][M][Cout] (grid.y = ksplit); splitk_reduce_kernel finishes
-    int ksplit;
-};
 
 template <int TR> struct AccT;                       // accumulator registers of one TR x TR tile (TR*TR/64 per lane)
 template <> struct AccT<32> { typedef f32x16 type; };
@@ -1196,6 +1180,17 @@ static int conv_fwd_impl(const void* x, const void* w, void* y, const float* sca
         if (Cin == 64 && Cout == 64 && a.g.taps == 9 && !raw && !residual && !scale && resident64_enabled()) {
             const int rc = conv64_resident(x, w, y, shift, x2, w2, Cin2, B, H, W, pool, a.act, s);
             if (rc != SUBREG_EUNSUPPORTED) return rc;
+        }
+        // wide layers, eval mode: the one-wave-per-SIMD kernel of conv_wide.hip where its measured rule prefers it
+        // (SUBREG_CONV_KERNEL_WIDE / _GENERAL in `flags` force one of the two: parity tests, A/B runs)
+        if (wide && !(flags & SUBREG_CONV_KERNEL_GENERAL)) {
+            const bool force = flags & SUBREG_CONV_KERNEL_WIDE;
+            if (force || conv_wide_preferred(a, pool)) {
+                const int rc = conv_wide(a, pool, s);
+                if (rc != SUBREG_EUNSUPPORTED || force) return rc;
+            }
+        } else if (flags & SUBREG_CONV_KERNEL_WIDE) {
+            return SUBREG_EUNSUPPORTED;
         }
         if (!wide) {
             // Cout = 64 (layer 1): the unpooled convs stage 3 taps per step (64x64 wave tiles are barrier-bound at one)

@@ -1,0 +1,626 @@
+// Implicit-GEMM 3x3 convolution forward for the WIDE layers (Cout % 160 == 0: layers 2-4 of the ResNet18 of
+// models/resnet_language.py:402-405, BasicBlock.forward :268-301), eval mode, bf16: ONE wave per SIMD.
+//
+// Why a second kernel (round 5).  conv_fwd.hip keeps two or three 4-wave workgroups per CU (64x160 / 32x160 wave tiles, 160 / 80
+// accumulator registers) and lets them cover each other's DMA issue, waits and barriers.  Its measured limits:
+// the 128-row tiles stage a 10 KB weight tile per 128 x 160 x 32 MACs and run at the chip's L2 -> LDS rate, every operand byte is
+// re-read from LDS once per 64 (32) rows, and the chip holds 1.5-1.65 GHz under that LDS + MFMA load.  This kernel spends the
+// register file differently: a wave owns the WHOLE 512-register budget of its SIMD (one 4-wave workgroup per CU) and a
+// 128 x 160 output tile (320 accumulator registers), so
+//   * a staged weight tile serves 512 rows (half the L2 -> LDS bytes per MAC of the 256-row tile, a quarter of the 128-row tile),
+//   * an operand byte read from LDS feeds 128 / 160 instead of 64 / 160 (32 / 160) MACs (-36 % / -62 % LDS bytes per MAC),
+//   * there is ONE barrier per 40 MFMAs (1280 matrix-pipe cycles) and the wave never waits for anything it issued less than
+//     half a step earlier: fragments are double-buffered in registers one k-step (20 MFMAs) ahead, weight tiles arrive by
+//     LDS-DMA into a ring of three 1.5 steps ahead, the next chunk's patch is spread over eight steps.
+// With one wave per SIMD nothing covers a stall, so every wait sits behind at least 640 cycles of MFMAs by construction.
+//
+// Step t = (32-channel chunk c, tap): K = 32 = two k-steps of v_mfma_f32_32x32x16_bf16.
+//   H1(t): MFMAs of k-step 0 (fragment set 0) | ds_reads of k-step 1 -> set 1
+//   MID(t): s_waitcnt vmcnt(0) (the DMAs issued at MID(t-1): weights of step t+1, patch pieces) ; s_barrier ;
+//           issue DMAs: weights of step t+2 -> ring slot (t+2) % 3, 1/8 of the next chunk's patch
+//   H2(t): MFMAs of k-step 1 (set 1) | ds_reads of step t+1, k-step 0 -> set 0
+// WAR: slot (t+2) % 3 held step t-1, whose last reads fed the MFMAs of H2(t-1); every wave is past those when it passes MID(t).
+// The patch buffer of chunk c+1 held chunk c-1; it is written from MID(c, tap 0) on, when every wave has left chunk c-1.
+// RAW: data issued at MID(t-1) is waited for (vmcnt) by its issuing wave before the barrier of MID(t) and read after it.
+//
+// Data layout, LDS image, swizzle, patch reuse over the nine taps, window-major rows for the pooled convolutions and the
+// shortcut GEMM as a second phase: as conv_fwd.hip (conv_index.h).  Epilogues: un-pooled tiles run with swapped MFMA operands
+// (lane = pixel, registers = consecutive channels; BN shift pre-loaded into the accumulators), pooled tiles pixel-major
+// (2x2 max over four registers); both leave through a per-wave LDS slab as whole 16-byte vectors.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "conv_args.h"
+#include "conv_index.h"
+#include "subreg_common.h"
+
+#ifndef SUBREG_WIDE_DIAG
+#define SUBREG_WIDE_DIAG 0       // 1 = no in-loop staging, 2 = no LDS reads / MFMAs (wrong results: timing only);
+                                 // 3 = per-wave s_memtime stamps into a.stats (tools/diag_conv.py --kernel wide);
+                                 // 4 / 5 = no in-loop patch / weight staging (timing only)
+#endif
+
+namespace subreg {
+
+namespace {
+
+__device__ __forceinline__ void mma32(const uint4& a, const uint4& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+template <int N> struct IC { static constexpr int value = N; };
+
+// slot G of a step's DMA list: staged when G < count (wave-uniform, an SGPR) - the test, M0 and the DMA in ONE asm statement
+template <int G>
+__device__ __forceinline__ void dma16_slot(int count_sgpr, const char* base_in, unsigned voff, unsigned lds_addr) {
+    const unsigned long long bu = (unsigned long long)(size_t)base_in;
+    const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bu);
+    const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bu >> 32));
+    const char* base = (const char*)(size_t)(((unsigned long long)bhi << 32) | blo);
+    const unsigned lds_u = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+#if SUBREG_WIDE_DIAG == 6      // timing only: every slot issues (no test, no branch)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_u) : "memory", "m0");
+#elif SUBREG_WIDE_DIAG == 7    // EXEC mask instead of a branch
+    asm volatile(
+        "s_cmp_gt_i32 %3, %4\n\t"
+        "s_cselect_b64 exec, -1, 0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1\n\t"
+        "s_mov_b64 exec, -1"
+        :
+        : "v"(voff), "s"(base), "s"(lds_u), "s"(count_sgpr), "n"(G)
+        : "memory", "m0", "scc");
+#else
+    asm volatile(
+        "s_cmp_le_i32 %3, %4\n\t"
+        "s_cbranch_scc1 1f\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1\n"
+        "1:"
+        :
+        : "v"(voff), "s"(base), "s"(lds_u), "s"(count_sgpr), "n"(G)
+        : "memory", "m0", "scc");
+#endif
+}
+
+// dma16 (subreg_common.h) under a wave-uniform condition, as ONE asm statement: the branch stays inside it, so a step's code remains
+// one basic block for the scheduler and the register allocator (with C++ branches around the DMAs every slot became two blocks,
+// the loop body ~80, and hipcc shuffled accumulators through scratch where the blocks merged)
+__device__ __forceinline__ void dma16_if(int ok, const char* base_in, unsigned voff, unsigned lds_addr) {
+    const unsigned long long bu = (unsigned long long)(size_t)base_in;
+    const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bu);
+    const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bu >> 32));
+    const char* base = (const char*)(size_t)(((unsigned long long)bhi << 32) | blo);
+    const unsigned lds_u = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    const int ok_u = __builtin_amdgcn_readfirstlane(ok);
+    asm volatile(
+        "s_cmp_eq_u32 %3, 0\n\t"
+        "s_cbranch_scc1 1f\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1\n"
+        "1:"
+        :
+        : "v"(voff), "s"(base), "s"(lds_u), "s"(ok_u)
+        : "memory", "m0", "scc");
+}
+
+}  // namespace
+
+// WM x WN waves of (32 MI) x 160 output tiles; POOL: window-major rows + 2x2 max; AROWS: patch rows per LDS buffer.
+// MI = 3 (96 rows, 240 accumulator registers): hipcc (ROCm 7.2) keeps MFMA accumulators in the 256 AGPRs only - with the 320 of a
+// 128-row tile it parks 64 of them in VGPRs and copies them in and out around every MFMA (11 k v_accvgpr instructions, 1.8 KB of scratch).
+template <int MI, int WM, int WN, bool POOL, int AROWS>
+__global__ __launch_bounds__(WM* WN * 64, 1) void conv_wide_kernel(const ConvArgs a) {
+    constexpr bool SWAPC = !POOL;
+    constexpr int NW = WM * WN, MJ = 5, TM = WM * MI * 32, TN = WN * 160;
+    constexpr int ROWB = 64, RPP = 16, SLOTS = 4, ELEM = 2, TAPS = 9, CENTER = 4;
+    constexpr int BTAP = TN * ROWB, NWB = 3;             // one step's weight tile; ring of three
+    constexpr int ABUF = (AROWS + 1) * ROWB;             // one patch buffer + its zero row
+    constexpr int A_BASE = NWB * BTAP;                   // weights first: their fragment reads take immediate offsets
+    constexpr int WPT = TN / RPP;                        // weight pieces (1 KiB) per step
+    constexpr int WPW = (WPT + NW - 1) / NW;             // ... per wave
+    // In-loop staging roles (fixed per wave): the first NWW waves stage weight tiles (the tile of step t+2 at MID(t), waited for at
+    // MID(t+1): L2 hits), the other NPW waves stage the next chunk's patch - all of it in the chunk's FIRST steps, waited for only
+    // at the chunk's last MID.  vmcnt counts a wave's DMAs in issue order, so a wave that issued both kinds would wait for its
+    // patch pieces with its weights, one step after issuing them; the patch of the 42x42 / 21x21 maps comes from HBM (395 / 197 MB
+    // of activations), and its round trip under load is several steps (measured with every wave staging both: 155-170 cycles of
+    // vmcnt wait per 960-cycle step on layers 2 / 3.0, 8-20 on the MALL-resident 10x10 / 5x5 maps).
+    constexpr int NWW = NW / 2, NPW = NW - NWW;
+    constexpr int SPW = 5;                               // DMA slots per wave and step: one in front of each MFMA group of H2
+    static_assert(WPT <= NWW * SPW, "weight pieces of a step over the weight waves");
+    constexpr int PSTEPS = (AROWS / RPP + NPW * SPW - 1) / (NPW * SPW);   // steps of a chunk that carry patch pieces
+    static_assert(PSTEPS <= 6, "the patch must be issued early in the chunk (steps 0 .. PSTEPS; the last piece at step PSTEPS)");
+    static_assert(MI >= 2 && MI <= 4, "read schedule below");
+    static_assert(AROWS % RPP == 0 && ABUF < 65536, "patch buffer: whole pieces, 16-bit row addresses");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using T = __bf16;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wid / WN, wave_n = wid % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const ConvGeom g = a.g;
+    constexpr bool STAMPS = SUBREG_WIDE_DIAG == 3;
+    unsigned long long t_begin = 0, t_loop = 0, t_wait = 0, t_bar = 0, r_begin = 0;
+    if (STAMPS) { t_begin = __builtin_amdgcn_s_memtime(); r_begin = __builtin_amdgcn_s_memrealtime(); }
+    // XCD-aware tile order: each of the 8 XCDs owns a contiguous tile range, n-tile fastest (conv_fwd.hip)
+    const int ntn = a.Cout / TN;
+    int vtile;
+    {
+        const int nwg = gridDim.x, lid = blockIdx.x, q8 = nwg / 8, r8 = nwg % 8, xcd = lid % 8, slot = lid / 8;
+        vtile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int mtile = vtile / ntn;
+    const int m0 = mtile * TM;
+    const int n0 = (vtile % ntn) * TN;
+
+    int plo, phi;
+    patch_range<POOL>(g, m0, TM, &plo, &phi);
+    const int prow = phi - plo;
+    const int apieces = (prow + RPP - 1) / RPP;
+
+    float* const s_shift = reinterpret_cast<float*>(smem + A_BASE + 2 * ABUF);
+    if constexpr (POOL) {
+        for (int t = tid; t < TN; t += NW * 64) s_shift[t] = a.shift[n0 + t];
+    }
+    if (tid < 2 * (ROWB / 16)) {                         // zero rows (index AROWS of each patch buffer)
+        const int b = tid / (ROWB / 16), q = tid % (ROWB / 16);
+        *reinterpret_cast<uint4*>(smem + A_BASE + b * ABUF + AROWS * ROWB + q * 16) = make_uint4(0, 0, 0, 0);
+    }
+
+    f32x16 acc[MI][MJ];
+    // ---- staging (LDS-DMA): lane l of a piece writes LDS row 16 q + l / 4, physical slot l % 4, so it fetches logical slot
+    //      (l % 4) ^ swz(row): the swizzle lives on the source address
+    const int prl = lane / SLOTS, psl = lane % SLOTS;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned xrow0 = (unsigned)a.Cin * ELEM, xrow1 = (unsigned)a.Cin2 * ELEM;
+    const unsigned porg0 = (unsigned)plo * xrow0, porg1 = (unsigned)plo * xrow1;
+    const unsigned swzo = (unsigned)((psl ^ swz<SLOTS>(prl)) << 4);            // (RPP = 16: the swizzle of a piece row does not depend on the piece)
+    auto rfl = [](unsigned v) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    // piece q of the patch whose 32-channel chunk starts at byte uoff of src (row pitch xrow) into patch buffer buf
+    auto patch_piece = [&](const char* src, unsigned uoff, unsigned xrow, int q, int buf) {
+        int row = q * RPP + prl;
+        row = row < prow ? row : prow - 1;                                     // tail rows of the last piece: any valid row
+        dma16(src, uoff + (unsigned)row * xrow + swzo, lds_base + A_BASE + buf * ABUF + q * 1024);
+    };
+    unsigned wvoff[WPW];                                                       // per-lane source offsets of this wave's weight pieces
+#pragma unroll
+    for (int k = 0; k < WPW; ++k) {
+        const int i = wid + NW * k;
+        const int row = (i < WPT ? i : WPT - 1) * RPP + prl;
+        wvoff[k] = (unsigned)(n0 + row) * ROWB + swzo;
+    }
+    // in-loop roles: weight wave w stages pieces SPW w .. SPW w + SPW - 1 of every step's tile; patch wave p stages pieces
+    // (tap NPW + p) SPW + g of the next chunk's patch at MID(tap), tap < PSTEPS
+    const bool wrole = wid < NWW;
+    const int pw = __builtin_amdgcn_readfirstlane(wrole ? 0 : wid - NWW);
+    unsigned rvoff[SPW];                                                       // role W: per-lane source offsets of this wave's pieces
+#pragma unroll
+    for (int gq = 0; gq < SPW; ++gq) {
+        const int i = (wrole ? wid : 0) * SPW + gq;
+        rvoff[gq] = (unsigned)(n0 + (i < WPT ? i : WPT - 1) * RPP + prl) * ROWB + swzo;
+    }
+    // this wave's weight pieces of the tile at byte offset soff of wsrc into ring slot `slot`
+    auto stage_weights = [&](const char* wsrc, unsigned soff, int slot) {
+#pragma unroll
+        for (int k = 0; k < WPW; ++k) {
+            const int i = wid + NW * k;
+            if (i < WPT) dma16(wsrc, wvoff[k] + rfl(soff), lds_base + slot * BTAP + i * 1024);
+        }
+    };
+    const int nch0 = a.Cin / 32, nch1 = a.x2 ? a.Cin2 / 32 : 0;
+    const unsigned wtile = (unsigned)a.Cout * ROWB, wtap = (unsigned)nch0 * wtile;   // bytes of one (tap, chunk) tile / of one tap
+    // weight tile of global step index s (phase 0: s = 9 c + tap; phase 1: s = 9 nch0 + d): source and byte offset
+    // ---- prologue: chunk 0's patch, the weights of steps 0 and 1
+    for (int q = wid; q < apieces; q += NW) patch_piece(a.x, porg0, xrow0, q, 0);
+    stage_weights(a.w, 0, 0);
+    stage_weights(a.w, wtap, 1);
+
+    // per-lane LDS offsets (within a patch buffer) of this lane's A rows for every tap, k-step 0 (k-step 1: ^ 32), as 16-bit halves
+    constexpr int NAP = (MI * TAPS + 1) / 2;
+    unsigned apk[NAP];
+    {
+#pragma unroll
+        for (int k = 0; k < NAP; ++k) apk[k] = 0;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + (wave_m * MI + i) * 32 + lr;
+            const bool mv = m < g.M;
+            const Pix px = row_to_pixel<POOL>(g, mv ? m : 0);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                const bool ok = mv && tap_valid(g, px.h, px.w, dy, dx);
+                const int row = px.p + dy * g.W + dx - plo;
+                const unsigned ad = ok ? row * ROWB + 16 * (lh ^ swz<SLOTS>(row)) : AROWS * ROWB + 16 * lh;
+                apk[(i * TAPS + t) >> 1] |= ad << (16 * ((i * TAPS + t) & 1));
+            }
+        }
+    }
+    auto aaddr = [&](int i, int t) -> int {
+        const int idx = i * TAPS + t;
+        return (idx & 1) ? (int)(apk[idx >> 1] >> 16) : (int)(apk[idx >> 1] & 0xffffu);
+    };
+    const int baddr0 = (wave_n * MJ * 32 + lr) * ROWB + 16 * (lh ^ swz<SLOTS>(lr));
+
+    // accumulators: zero, or (swapped operands) the BN shift of the register's channel - the epilogue then has no affine step
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+        if constexpr (SWAPC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wave_n * 160 + j * 32 + 8 * q + 4 * lh;
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = sh[e];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto mma_ab = [&](const uint4& xa, const uint4& wb, f32x16& c) {
+        if constexpr (SWAPC) mma32(wb, xa, c); else mma32(xa, wb, c);
+    };
+    // fragment reads of one k-step: A rows of tap `tap` in the patch buffer at byte offset aoff, weight tile at byte offset boff
+    // (tap -1: the step that follows a chunk's last one - tap 0 of the next chunk, or the centre tap of the first shortcut step)
+    int after_last_is_center = 0;                                         // set per chunk (wave-uniform)
+    auto rd_a = [&](int i, int aoff, int tap, int ks) -> uint4 {
+        const int ad = tap >= 0 ? aaddr(i, tap) : (after_last_is_center ? aaddr(i, CENTER) : aaddr(i, 0));
+        return *reinterpret_cast<const uint4*>(smem + aoff + (ad ^ (32 * ks)));
+    };
+    auto rd_b = [&](int j, int boff, int ks) -> uint4 {
+        return *reinterpret_cast<const uint4*>(smem + boff + j * (32 * ROWB) + (baddr0 ^ (32 * ks)));
+    };
+    // One half step: the 20 MFMAs of the fragment set (ca, cb) in five groups of four (column tile g); in front of group g the
+    // wave issues DMA slot g (dma(g): a no-op where the step has none) and two of the nine fragment reads of the NEXT k-step into
+    // (na, nb) (RD).  The order inside a group is pinned with sched_group_barriers, the groups with sched_barriers.
+    auto half = [&](uint4(&ca)[MI], uint4(&cb)[MJ], uint4(&na)[MI], uint4(&nb)[MJ], auto rd_tag, int n_aoff, auto ntap_tag, auto nks_tag,
+                    int n_boff, auto&& dma) {
+        constexpr bool RD = decltype(rd_tag)::value;
+        constexpr int NTAP = decltype(ntap_tag)::value, NKS = decltype(nks_tag)::value;
+        auto group = [&](auto g_tag) {
+            constexpr int gq = decltype(g_tag)::value;
+            if (SUBREG_WIDE_DIAG != 1) dma(g_tag);
+            if constexpr (SUBREG_WIDE_DIAG != 2) {
+                // the MI + 5 fragment reads of the next k-step in the order b0 a0 .. a(MI-1) b1 .. b4 (the next half's first group
+                // needs every a and b0), RPG(g) of them in front of group g
+                constexpr int NRD = MI + MJ, R0 = gq * NRD / MJ, R1 = (gq + 1) * NRD / MJ;
+                if constexpr (RD) {
+#pragma unroll
+                    for (int r = R0; r < R1; ++r) {
+                        if (r == 0) nb[0] = rd_b(0, n_boff, NKS);
+                        else if (r <= MI) na[r - 1] = rd_a(r - 1, n_aoff, NTAP, NKS);
+                        else nb[r - MI] = rd_b(r - MI, n_boff, NKS);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i) mma_ab(ca[i], cb[gq], acc[i][gq]);
+                if constexpr (RD && R1 > R0) __builtin_amdgcn_sched_group_barrier(0x100, R1 - R0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MI, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        group(IC<0>{});
+        group(IC<1>{});
+        group(IC<2>{});
+        group(IC<3>{});
+        group(IC<4>{});
+    };
+    auto no_dma = [](auto) {};
+    uint4 fa0[MI], fb0[MJ], fa1[MI], fb1[MJ];
+    // the first step's k-step 0
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa0[i] = rd_a(i, A_BASE, 0, 0);
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) fb0[j] = rd_b(j, 0, 0);
+
+    // MID of a step: wait for this wave's DMAs of the previous MID, barrier
+    auto mid_sync = [&](bool drain_lds, int do_wait = 1) {
+        unsigned long long q0 = 0, q1 = 0;
+        if (STAMPS) q0 = __builtin_amdgcn_s_memtime();
+        if (drain_lds) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(0)\n1:" : : "s"(__builtin_amdgcn_readfirstlane(do_wait)) : "memory", "scc");
+        if (STAMPS) q1 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (STAMPS) { const unsigned long long q2 = __builtin_amdgcn_s_memtime(); t_wait += q1 - q0; t_bar += q2 - q1; }
+    };
+    if (STAMPS) t_loop = __builtin_amdgcn_s_memtime();
+
+    // ---- From here on the kernel exists TWICE, once per staging role (`rest` below; the workgroup's waves branch once and never meet
+    //      again - each copy runs to its own s_endpgm, so no register assignment has to agree where copies would merge: with the
+    //      two copies of the main loop alone, hipcc shuffled the accumulators through scratch at the merge).  With one wave per SIMD
+    //      every instruction a wave issues between two MFMAs is matrix-pipe time (budget ~5 per MFMA), and a CONDITIONAL DMA slot
+    //      costs three times an unconditional one (tools/probes/dma_slot.hip: s_cmp + s_cbranch + DMA +29 cycles per slot, the
+    //      DMA alone +10; EXEC masking is no better): so a slot is v_add (source offset), s_add (M0), the DMA - and nothing is
+    //      conditional: a slot without a piece of its own re-stages a neighbour's (the same bytes to the same LDS address).
+    // ---- phase 0: the convolution chunks, nine steps each (unrolled: tap, ring slot and fragment addresses are compile-time)
+    const unsigned wlds = lds_base + (unsigned)(wrole ? wid : 0) * (SPW * 1024);    // weight waves: LDS offset of this wave's piece 0 in a ring slot
+    for (int c = 0; c < nch0; ++c) {
+        const int aoff = A_BASE + (c & 1) * ABUF;
+        const int naoff = A_BASE + ((c + 1) & 1) * ABUF;
+        const bool last_c = c + 1 >= nch0;
+        // the chunk that follows (its patch is staged during this one); after the last one: this chunk again, into the idle buffer
+        const bool to_x2 = last_c && nch1 > 0;
+        const char* const psrc = to_x2 ? a.x2 : a.x;
+        const unsigned pxrow = to_x2 ? xrow1 : xrow0;
+        const unsigned puoff = to_x2 ? porg1 : porg0 + (unsigned)(last_c ? c : c + 1) * (32 * ELEM);
+        const unsigned plds = lds_base + A_BASE + ((c + 1) & 1) * ABUF;
+        after_last_is_center = last_c ? 1 : 0;
+        unsigned cw = (unsigned)c * wtile;                               // byte offset of this chunk's weight tiles within a tap
+        asm volatile("" : "+s"(cw));                                     // (opaque: per-step sums stay in the loop, not in 30 hoisted SGPRs)
+        // patch waves: per-lane source offset of a piece's rows (pv) / of the LAST piece's rows, tail clamped to the patch's last row
+        const int lim = prow - 1 - (apieces - 1) * RPP;
+        const unsigned pv = __umul24((unsigned)prl, pxrow) + swzo, pv_last = __umul24((unsigned)(prl < lim ? prl : lim), pxrow) + swzo;
+        const unsigned gs = (unsigned)RPP * pxrow;                       // source offset step from piece to piece
+        auto step = [&](auto tap_tag) {
+            constexpr int TAP = decltype(tap_tag)::value;
+            constexpr int SL = TAP % NWB;
+            // H1: k-step 0 on set 0 | reads of k-step 1 -> set 1
+            half(fa0, fb0, fa1, fb1, std::true_type{}, aoff, IC<TAP>{}, IC<1>{}, SL * BTAP, no_dma);
+            mid_sync(false, (wrole || TAP == 8) ? 1 : 0);
+            // DMAs of this MID.  Weight waves: their SPW pieces of the tile of step t+2 (ring slot (t+2) % 3; past the last step:
+            // tile 0 again, into a slot nobody reads).  Patch waves, steps 0 .. PSTEPS - 1 of a chunk: SPW consecutive regular pieces
+            // (0 .. apieces - 2) of the next chunk's patch from piece (tap NPW + pw) SPW on, clamped; step PSTEPS: the last piece.
+            constexpr int WSL = (TAP + 2) % NWB;
+            const char* wsrc = a.w;
+            unsigned woff = cw;
+            if constexpr (TAP + 2 <= 8) {
+                woff += (unsigned)(TAP + 2) * wtap;
+            } else {
+                constexpr int T2 = TAP + 2 - 9;                           // step 0 or 1 of what follows this chunk
+                if (!last_c) woff += (unsigned)T2 * wtap + wtile;
+                else if (T2 < nch1) { wsrc = a.w2; woff = (unsigned)T2 * wtile; }
+                else woff = 0;
+            }
+            int q0 = (TAP * NPW + pw) * SPW;                              // (opaque per step, as cw)
+            asm volatile("" : "+s"(q0));
+            auto dma_w = [&](auto g_tag) {
+                constexpr int gq = decltype(g_tag)::value;
+                const int i = wid * SPW + gq;                                 // (WPT = NWW SPW for TN = 160: every slot has its piece)
+                if (NWW * SPW == WPT || i < WPT) dma16(wsrc, rvoff[gq] + rfl(woff), wlds + WSL * BTAP + gq * 1024);
+            };
+            auto dma_p = [&](auto g_tag) {
+                constexpr int gq = decltype(g_tag)::value;
+                if constexpr (TAP < PSTEPS) {
+                    int q = q0 + gq;
+                    q = q < apieces - 2 ? q : apieces - 2;
+                    dma16(psrc, pv + rfl(puoff + (unsigned)q * gs), plds + (unsigned)q * 1024u);
+                } else if constexpr (TAP == PSTEPS) {
+                    if constexpr (gq == 0) dma16(psrc, pv_last + rfl(puoff + (unsigned)(apieces - 1) * gs), plds + (unsigned)(apieces - 1) * 1024u);
+                }
+            };
+            // H2: k-step 1 on set 1 | reads of the next step's k-step 0 -> set 0.  The step after tap 8 is tap 0 of the next chunk or
+            // the first shortcut step (centre tap): ONE code path with the tap's addresses selected (after the very last step the
+            // reads fetch stale LDS into registers nobody uses).  H2 exists once per role (ONE wave-uniform branch per step).
+            constexpr bool SAME = TAP < 8;                                // the next step belongs to this chunk
+            if (wrole) half(fa1, fb1, fa0, fb0, std::true_type{}, SAME ? aoff : naoff, IC<(SAME ? TAP + 1 : -1)>{}, IC<0>{}, ((TAP + 1) % NWB) * BTAP, dma_w);
+            else half(fa1, fb1, fa0, fb0, std::true_type{}, SAME ? aoff : naoff, IC<(SAME ? TAP + 1 : -1)>{}, IC<0>{}, ((TAP + 1) % NWB) * BTAP, dma_p);
+        };
+        step(IC<0>{});
+        step(IC<1>{});
+        step(IC<2>{});
+        step(IC<3>{});
+        step(IC<4>{});
+        step(IC<5>{});
+        step(IC<6>{});
+        step(IC<7>{});
+        step(IC<8>{});
+    }
+    // ---- phase 1: the fused shortcut GEMM's chunks, ONE step each (centre tap).  A step consumes a whole patch, so the next
+    //      chunk's patch is staged at MID and waited for at the end of the step (two patch buffers: not pipelined deeper).
+    for (int d = 0; d < nch1; ++d) {
+        const int s = 9 * nch0 + d;
+        const int aoff = A_BASE + ((nch0 + d) & 1) * ABUF;
+        const int naoff = A_BASE + ((nch0 + d + 1) & 1) * ABUF;
+        const int boff = (s % NWB) * BTAP, nboff = ((s + 1) % NWB) * BTAP;
+        const bool more = d + 1 < nch1;
+        half(fa0, fb0, fa1, fb1, std::true_type{}, aoff, IC<CENTER>{}, IC<1>{}, boff, no_dma);
+        mid_sync(true);                                                   // (the patch buffer written below is the one step s-1 read)
+        if (SUBREG_WIDE_DIAG != 1) {
+            if (d + 2 < nch1) stage_weights(a.w2, (unsigned)(d + 2) * wtile, (s + 2) % NWB);
+            if (more) for (int q = wid; q < apieces; q += NW) patch_piece(a.x2, porg1 + (unsigned)(d + 1) * (32 * ELEM), xrow1, q, (nch0 + d + 1) & 1);
+        }
+        half(fa1, fb1, fa0, fb0, std::false_type{}, 0, IC<0>{}, IC<0>{}, 0, no_dma);
+        if (more) {
+            mid_sync(false);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa0[i] = rd_a(i, naoff, CENTER, 0);
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) fb0[j] = rd_b(j, nboff, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                      // every wave is done with the staging LDS: it becomes the slabs
+    struct EpilogueStamp {                  // DIAG = 3: cycles from the end of the main loop to the kernel's last instruction
+        float* dst;
+        unsigned long long t0;
+        __device__ ~EpilogueStamp() { if (dst) *dst = (float)(__builtin_amdgcn_s_memtime() - t0); }
+    } epi_stamp{nullptr, 0};
+    if (STAMPS && a.stats && lane == 0) {
+        const unsigned long long n = __builtin_amdgcn_s_memtime(), rn = __builtin_amdgcn_s_memrealtime();
+        float* d = a.stats + ((size_t)blockIdx.x * NW + wid) * 8;
+        d[0] = (float)(t_loop - t_begin); d[1] = (float)(n - t_loop); d[2] = 0.f; d[3] = (float)(n - t_loop) - (float)t_wait - (float)t_bar;
+        d[4] = (float)t_wait; d[5] = (float)t_bar; d[6] = (float)(rn - r_begin);
+        epi_stamp.dst = d + 7;
+        epi_stamp.t0 = n;
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    T* const y = reinterpret_cast<T*>(a.y);
+    const bool full = m0 + TM <= g.M;
+    constexpr int TNW = 160, RS = TNW * ELEM + 16, VPR = TNW * ELEM / 16;
+    char* const slab = smem + wid * (32 * RS);
+    static_assert(NW * 32 * RS <= A_BASE + 2 * ABUF, "slabs reuse the staging LDS");
+    const float slope = a.act ? 0.1f : 1.f;                               // LeakyReLU(0.1) as max(v, slope v)
+    if constexpr (SWAPC) {
+        // lane = pixel (row lr of block i), registers 4q..4q+3 of tile (i, j) = channels 32 j + 8 q + 4 lh + {0..3}
+        auto lrelu_pack = [&](const f32x16& cfr, int q) -> uint2 {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = cfr[4 * q + e] * slope;
+                asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(cfr[4 * q + e]), "v"(t));
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+            return __builtin_bit_cast(uint2, o);
+        };
+        if (full) {
+            constexpr int NV = 32 * VPR;
+            char* const wbase = slab + lr * RS + 4 * lh * ELEM;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int j = 0; j < MJ; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<uint2*>(wbase + (j * 32 + 8 * q) * ELEM) = lrelu_pack(acc[i][j], q);
+                const int mrow0 = m0 + (wave_m * MI + i) * 32;
+                char* const ybase = a.y + ((size_t)mrow0 * a.Cout + n0 + wave_n * TNW) * ELEM;
+#pragma unroll
+                for (int v0 = 0; v0 < NV; v0 += 64) {
+                    const int v = v0 + lane;
+                    const int row = v / VPR, c16 = v % VPR;
+                    const uint4 val = *reinterpret_cast<const uint4*>(slab + row * RS + c16 * 16);
+                    *reinterpret_cast<uint4*>(ybase + (size_t)row * a.Cout * ELEM + c16 * 16) = val;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + (wave_m * MI + i) * 32 + lr;
+#pragma unroll
+                for (int j = 0; j < MJ; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + wave_n * TNW + j * 32 + 8 * q + 4 * lh;
+                        if (m < g.M) *reinterpret_cast<uint2*>(y + (size_t)m * a.Cout + n) = lrelu_pack(acc[i][j], q);
+                    }
+            }
+        }
+    } else {
+        // pixel-major: column = lane % 32 (channel), register r = row (r & 3) + 8 (r >> 2) + 4 lh; registers 4q..4q+3 = one 2x2 window
+        if (full) {
+            constexpr int NV = 8 * VPR;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int j = 0; j < MJ; ++j) {
+                    const float sh = s_shift[wave_n * TNW + j * 32 + lr];
+                    const f32x16& cfr = acc[i][j];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float best = fmaxf(fmaxf(cfr[4 * q], cfr[4 * q + 1]), fmaxf(cfr[4 * q + 2], cfr[4 * q + 3])) + sh;
+                        best = fmaxf(best, best * slope);                 // monotone: lrelu(max) == max(lrelu)
+                        *reinterpret_cast<T*>(slab + (2 * q + lh) * RS + (j * 32 + lr) * ELEM) = (T)best;
+                    }
+                }
+                const int win0 = (m0 + (wave_m * MI + i) * 32) >> 2;      // first pooled pixel of this block
+                char* const ybase = a.y + ((size_t)win0 * a.Cout + n0 + wave_n * TNW) * ELEM;
+#pragma unroll
+                for (int v0 = 0; v0 < NV; v0 += 64) {
+                    const int v = v0 + lane;
+                    if (v < NV) {
+                        const int row = v / VPR, c16 = v % VPR;
+                        const uint4 val = *reinterpret_cast<const uint4*>(slab + row * RS + c16 * 16);
+                        *reinterpret_cast<uint4*>(ybase + (size_t)row * a.Cout * ELEM + c16 * 16) = val;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) {
+                const int n = n0 + wave_n * TNW + j * 32 + lr;
+                const float sh = s_shift[wave_n * TNW + j * 32 + lr];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int mb = m0 + (wave_m * MI + i) * 32 + 4 * lh;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int m = mb + 8 * q;
+                        if (m < g.M) {
+                            const f32x16& cfr = acc[i][j];
+                            float best = fmaxf(fmaxf(cfr[4 * q], cfr[4 * q + 1]), fmaxf(cfr[4 * q + 2], cfr[4 * q + 3])) + sh;
+                            best = fmaxf(best, best * slope);
+                            y[(size_t)(m >> 2) * a.Cout + n] = (T)best;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- host side
+namespace {
+
+template <bool POOL>
+int worst_patch_rows_w(const ConvGeom& g, int TM) {
+    int worst = 0;
+    for (int m0 = 0; m0 < g.M; m0 += TM) {
+        int lo, hi;
+        patch_range<POOL>(g, m0, TM, &lo, &hi);
+        if (hi - lo > worst) worst = hi - lo;
+    }
+    return worst;
+}
+
+template <int MI, int WM, int WN, bool POOL, int AROWS>
+int launch_wide(const ConvArgs& a, hipStream_t stream) {
+    constexpr int TM = WM * MI * 32, TN = WN * 160;
+    const size_t lds = 3 * (size_t)TN * 64 + 2 * (size_t)(AROWS + 1) * 64 + TN * sizeof(float);
+    auto kern = conv_wide_kernel<MI, WM, WN, POOL, AROWS>;
+    static std::atomic<unsigned long long> lds_set{0};
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set)) return rc;
+    dim3 grid(((a.g.M + TM - 1) / TM) * (a.Cout / TN));
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, a);
+    return launch_status();
+}
+
+constexpr int WIDE_MI = 3, WIDE_TM = 4 * WIDE_MI * 32;              // 384-row tiles
+constexpr int AR_LIN = 480, AR_POOL = 544;                           // patch rows: 384 + 2 (W + 1) at W <= 42; pooled window-major tiles
+
+}  // namespace
+
+bool conv_wide_supported(const ConvArgs& a, bool pool) {
+    if (a.g.taps != 9 || a.raw || a.res || a.scale || !a.shift || a.part) return false;
+    if (a.Cout % 160 != 0 || a.Cin % 32 != 0 || a.Cin < 32) return false;
+    if (a.x2 && (a.Cin2 % 32 != 0 || a.Cin2 < 32)) return false;
+    if ((long long)a.g.M * a.Cout >= (1LL << 31) || (long long)a.g.npix * a.Cout >= (1LL << 31)) return false;
+    if ((long long)a.g.npix * a.Cin * 2 >= (1LL << 32) || (long long)a.g.npix * a.Cin2 * 2 >= (1LL << 32) ||
+        (long long)a.g.taps * a.Cin * a.Cout * 2 >= (1LL << 32))
+        return false;
+    if (a.g.npix < 16) return false;                                   // (a patch piece's tail rows re-read valid rows)
+    const int worst = pool ? worst_patch_rows_w<true>(a.g, WIDE_TM) : worst_patch_rows_w<false>(a.g, WIDE_TM);
+    return worst <= (pool ? AR_POOL : AR_LIN);
+}
+
+// Measured rule (profiles/r05_*): the kernel runs ONE 384 x 160 tile per CU and round, so it wants whole rounds.
+bool conv_wide_preferred(const ConvArgs& a, bool pool) {
+    static const int mode = [] { const char* e = getenv("SUBREG_WIDE"); return e && *e ? atoi(e) : -1; }();   // 0 never, 1 always, -1 rule
+    if (mode == 0) return false;
+    if (!conv_wide_supported(a, pool)) return false;
+    if (mode == 1) return true;
+    return false;                                                      // (until the kernel beats conv_fwd.hip on a layer: forced by flag / SUBREG_WIDE=1 only)
+}
+
+int conv_wide(const ConvArgs& a, bool pool, hipStream_t stream) {
+    if (!conv_wide_supported(a, pool)) return SUBREG_EUNSUPPORTED;
+    return pool ? launch_wide<WIDE_MI, 4, 1, true, AR_POOL>(a, stream) : launch_wide<WIDE_MI, 4, 1, false, AR_LIN>(a, stream);
+}
+
+}  // namespace subreg

@@ -14,8 +14,9 @@ LIB_PATH = os.environ.get("SUBREG_LIB") or os.path.join(_HERE, "libsubreg_hip.so
 
 F32, BF16 = 0, 1
 CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
+CONV_KERNEL_GENERAL, CONV_KERNEL_WIDE = 256, 512   # kernel selection of subreg_conv_fwd (Cout % 160 == 0): conv_fwd.hip / conv_wide.hip
 FWD_TRAIN = 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_QUERY_SETS = 32                          # SUBREG_MAX_QUERY_SETS
 
 c_void_p, c_int, c_float, c_longlong = C.c_void_p, C.c_int, C.c_float, C.c_longlong

@@ -80,6 +80,20 @@ def _round_bf16(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).to(torch.float32).numpy()
 
 
+# Kernel selection of subreg_conv_fwd for the wide layers (Cout % 160 == 0, bf16, eval mode): "auto" = the dispatcher's measured rule,
+# "general" = conv_fwd.hip forced, "wide" = the one-wave-per-SIMD kernel of conv_wide.hip forced.  The parity tests below run over
+# all three.
+KERNELS = ["auto", "general", "wide"]
+
+
+def _kernel_flag(kernel, dtype, Cout, k=3):
+    if kernel == "auto":
+        return 0
+    if dtype != "bf16" or Cout % 160 != 0 or k != 3:
+        pytest.skip("one kernel only for this problem")
+    return _lib.CONV_KERNEL_GENERAL if kernel == "general" else _lib.CONV_KERNEL_WIDE
+
+
 CONV_CASES = [
     # B, H, W, Cin, Cout, k, pool, residual      (shapes of the 14 unique convs, SURVEY.md 8a-3, + ragged/edge ones)
     (2, 84, 84, 64, 64, 3, False, False),
@@ -271,9 +285,10 @@ FUSED_CASES = [
 ]
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("case", FUSED_CASES, ids=lambda c: "B%d_%dx%d_%d-%d_sc%d_p%d" % tuple(int(v) for v in c))
-def test_conv_folded_scale_and_fused_shortcut(case, dtype):
+def test_conv_folded_scale_and_fused_shortcut(case, dtype, kernel):
     """Eval-mode conv3 as the backbone runs it: BN scale folded into the packed weights, the shortcut branch
     accumulated as a second GEMM (x2 * w2^T), one shift, LeakyReLU, optional 2x2 max-pool."""
     B, H, W, Cin, Cout, Cin2, pool = case
@@ -304,7 +319,7 @@ def test_conv_folded_scale_and_fused_shortcut(case, dtype):
         _lib.check(lib.subreg_pack_identity(_lib.ptr(w2d), Cout, _lib.dtype_code(dtype), _lib.stream_ptr()))
     else:
         w2d = _pack_w(w2, dtype, fold=sc2)
-    flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0)
+    flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0) | _kernel_flag(kernel, dtype, Cout)
     _lib.check(lib.subreg_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), None, _lib.ptr(shd), None, None, _lib.ptr(x2d),
                                    _lib.ptr(w2d), c2, B, H, W, Cin, Cout, 3, flags, _lib.dtype_code(dtype), _lib.stream_ptr()),
                "conv_fwd(fused)")
@@ -404,7 +419,7 @@ def _sample_positions(rs, B, Ho, Wo, n_random=384):
             for w in (0, 1, Wo // 2, Wo - 2, Wo - 1):
                 pts.add((b, max(h, 0), max(w, 0)))
     n = B * Ho * Wo
-    for t in (128, 256, 512, 768, n - 256, n - 128):      # output rows next to tile boundaries (LINEAR order)
+    for t in (128, 256, 384, 512, 768, 1152, n - 384, n - 256, n - 128):      # output rows next to tile boundaries (LINEAR order)
         for d in (-1, 0, 1):
             m = min(max(t + d, 0), n - 1)
             pts.add((m // (Ho * Wo), (m // Wo) % Ho, m % Wo))
@@ -414,9 +429,10 @@ def _sample_positions(rs, B, Ho, Wo, n_random=384):
     return p[:, 0], p[:, 1], p[:, 2]
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 @pytest.mark.parametrize("case", BIG_CONV_CASES, ids=lambda c: "B%d_%dx%d_%d-%d_k%d_p%d_sc%d" % tuple(int(v) for v in c))
-def test_conv_fwd_production_tiles(case, dtype):
+def test_conv_fwd_production_tiles(case, dtype, kernel):
     B, H, W, Cin, Cout, k, pool, Cin2 = case
     lib = _lib.load()
     rs = np.random.RandomState(hash(case) % (2 ** 31))
@@ -461,7 +477,7 @@ def test_conv_fwd_production_tiles(case, dtype):
         w2d = _pack_w(w2, dtype, fold=sc2)
     y = torch.full((B * Ho * Wo, Cout), float("nan"), dtype=td, device=_dev())
     shd = _t(shift)
-    flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0)
+    flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0) | _kernel_flag(kernel, dtype, Cout, k)
     _lib.check(lib.subreg_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), None, _lib.ptr(shd), None, None, _lib.ptr(x2d),
                                    _lib.ptr(w2d), (Cout if Cin2 == 0 else max(Cin2, 0)), B, H, W, Cin, Cout, k, flags,
                                    _lib.dtype_code(dtype), _lib.stream_ptr()), "conv_fwd(big)")

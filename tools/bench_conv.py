@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--im2col", action="store_true", help="layer 1 over the K = 32 im2col buffer (the round-2 route) + pack_input")
     ap.add_argument("--unfused", action="store_true", help="conv1 (from the image) and conv2 of layer 1 as two launches")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "general", "wide"],
+                    help="wide layers (Cout % 160 == 0): the dispatcher's rule, conv_fwd.hip forced, conv_wide.hip forced")
     a = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -121,6 +123,8 @@ def main():
             x2 = torch.randn(npix, c2, device=dev).to(td)
             w2 = (torch.eye(Cout, device=dev) if cin2 == 0 else torch.randn(Cout, c2, device=dev) / c2 ** 0.5).to(td).contiguous()
         flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0)
+        if Cout % 160 == 0 and a.dtype == "bf16":
+            flags |= {"auto": 0, "general": _lib.CONV_KERNEL_GENERAL, "wide": _lib.CONV_KERNEL_WIDE}[a.kernel]
 
         def run():
             _lib.check(lib.subreg_conv_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), None, _lib.ptr(shift), None, None,

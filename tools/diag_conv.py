@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--only", default="")
+    ap.add_argument("--kernel", default="general", choices=["general", "wide"])
     a = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -47,7 +48,7 @@ def main():
             c2 = Cout if cin2 == 0 else cin2
             x2 = torch.randn(npix, c2, device=dev).to(td)
             w2 = (torch.eye(Cout, device=dev) if cin2 == 0 else torch.randn(Cout, c2, device=dev) / c2 ** 0.5).to(td).contiguous()
-        flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0)
+        flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0) | (_lib.CONV_KERNEL_WIDE if a.kernel == "wide" else _lib.CONV_KERNEL_GENERAL)
         stamps = torch.zeros(((npix + 63) // 64) * ((Cout + 63) // 64) * 8 * 8 + 1024, device=dev)
 
         def run():
