@@ -51,6 +51,29 @@ __device__ __forceinline__ void mma32(const uint4& a, const uint4& b, f32x16& ac
 
 template <int N> struct IC { static constexpr int value = N; };
 
+// wave-uniform selects as instructions (written as C++ selects on a per-wave condition, hipcc turns them into branches around the
+// DMAs: ~80 basic blocks per loop body, accumulators shuffled through scratch where they merge)
+__device__ __forceinline__ unsigned ssel(int c, unsigned a, unsigned b) {
+    unsigned r;
+    asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, %2, %3"
+        : "=s"(r)
+        : "s"(__builtin_amdgcn_readfirstlane(c)), "s"(__builtin_amdgcn_readfirstlane((int)a)), "s"(__builtin_amdgcn_readfirstlane((int)b))
+        : "scc");
+    return r;
+}
+__device__ __forceinline__ const char* ssel_ptr(int c, const char* a, const char* b) {
+    const unsigned long long ua = (unsigned long long)(size_t)a, ub = (unsigned long long)(size_t)b;
+    const unsigned lo = ssel(c, (unsigned)ua, (unsigned)ub), hi = ssel(c, (unsigned)(ua >> 32), (unsigned)(ub >> 32));
+    return (const char*)(size_t)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned vsel(unsigned long long mask, unsigned a, unsigned b) {   // mask ? a : b
+    unsigned r;
+    const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mask);
+    const unsigned long long m2 = ((unsigned long long)m << 32) | m;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m2));
+    return r;
+}
+
 // slot G of a step's DMA list: staged when G < count (wave-uniform, an SGPR) - the test, M0 and the DMA in ONE asm statement
 template <int G>
 __device__ __forceinline__ void dma16_slot(int count_sgpr, const char* base_in, unsigned voff, unsigned lds_addr) {
@@ -123,17 +146,22 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void conv_wide_kernel(const ConvArg
     constexpr int A_BASE = NWB * BTAP;                   // weights first: their fragment reads take immediate offsets
     constexpr int WPT = TN / RPP;                        // weight pieces (1 KiB) per step
     constexpr int WPW = (WPT + NW - 1) / NW;             // ... per wave
-    // In-loop staging roles (fixed per wave): the first NWW waves stage weight tiles (the tile of step t+2 at MID(t), waited for at
-    // MID(t+1): L2 hits), the other NPW waves stage the next chunk's patch - all of it in the chunk's FIRST steps, waited for only
-    // at the chunk's last MID.  vmcnt counts a wave's DMAs in issue order, so a wave that issued both kinds would wait for its
-    // patch pieces with its weights, one step after issuing them; the patch of the 42x42 / 21x21 maps comes from HBM (395 / 197 MB
-    // of activations), and its round trip under load is several steps (measured with every wave staging both: 155-170 cycles of
-    // vmcnt wait per 960-cycle step on layers 2 / 3.0, 8-20 on the MALL-resident 10x10 / 5x5 maps).
-    constexpr int NWW = NW / 2, NPW = NW - NWW;
-    constexpr int SPW = 5;                               // DMA slots per wave and step: one in front of each MFMA group of H2
-    static_assert(WPT <= NWW * SPW, "weight pieces of a step over the weight waves");
-    constexpr int PSTEPS = (AROWS / RPP + NPW * SPW - 1) / (NPW * SPW);   // steps of a chunk that carry patch pieces
-    static_assert(PSTEPS <= 6, "the patch must be issued early in the chunk (steps 0 .. PSTEPS; the last piece at step PSTEPS)");
+    // In-loop staging: ONE instruction stream for every wave, nothing conditional (with one wave per SIMD every instruction issued
+    // between two MFMAs is matrix-pipe time, and a conditional DMA slot costs three times an unconditional one: tools/probes/
+    // dma_slot.hip).  A step's list is its WPT = 10 weight pieces (the tile of step t+2) and NPP = 6 pieces of the next chunk's patch;
+    // wave w has four slots, issued in this order:
+    //   S2: weight piece w + 8 (w < 2) or patch piece w (w >= 2) - the one slot whose kind depends on the wave (selected as DATA)
+    //   W0, W1: weight pieces w, w + 4
+    //   S3: patch piece w (w < 2) or w + 2 (w >= 2); steps 0 .. PLAST only
+    // Patch pieces 0 .. apieces - 2 go six per step from step 0 on (a slot beyond them re-stages piece apieces - 2: same bytes, same
+    // place); the last piece (its tail rows are clamped to the patch's last row) is every wave's S3 of step PLAST.
+    // MID(t) waits vmcnt(1) after a step with an S3: a wave's DMAs complete in issue order, so that leaves exactly its S3 patch
+    // piece in flight for a second step (the patch of the 42x42 / 21x21 maps comes from HBM: 395 / 197 MB of activations; with
+    // vmcnt(0) every step the wait was 155-170 cycles per 960-cycle step there, 8-20 on the MALL-resident small maps).
+    constexpr int NPP = 6;
+    constexpr int PLAST = (AROWS / RPP - 1 + NPP - 1) / NPP;   // first step without regular patch pieces: the last piece's step
+    static_assert(NW == 4 && WPT == 10, "slot table above");
+    static_assert(PLAST <= 6, "S3 exists in steps 0 .. 6; everything has landed at MID(8)");
     static_assert(MI >= 2 && MI <= 4, "read schedule below");
     static_assert(AROWS % RPP == 0 && ABUF < 65536, "patch buffer: whole pieces, 16-bit row addresses");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -194,16 +222,11 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void conv_wide_kernel(const ConvArg
         const int row = (i < WPT ? i : WPT - 1) * RPP + prl;
         wvoff[k] = (unsigned)(n0 + row) * ROWB + swzo;
     }
-    // in-loop roles: weight wave w stages pieces SPW w .. SPW w + SPW - 1 of every step's tile; patch wave p stages pieces
-    // (tap NPW + p) SPW + g of the next chunk's patch at MID(tap), tap < PSTEPS
-    const bool wrole = wid < NWW;
-    const int pw = __builtin_amdgcn_readfirstlane(wrole ? 0 : wid - NWW);
-    unsigned rvoff[SPW];                                                       // role W: per-lane source offsets of this wave's pieces
-#pragma unroll
-    for (int gq = 0; gq < SPW; ++gq) {
-        const int i = (wrole ? wid : 0) * SPW + gq;
-        rvoff[gq] = (unsigned)(n0 + (i < WPT ? i : WPT - 1) * RPP + prl) * ROWB + swzo;
-    }
+    // in-loop slot table of this wave (see the kernel's head): S2 is a weight piece on waves 0-1, a patch piece on waves 2-3
+    const int s2w = __builtin_amdgcn_readfirstlane(wid < 2 ? 1 : 0);
+    const unsigned s2m = (unsigned)__builtin_amdgcn_readfirstlane(wid < 2 ? -1 : 0);
+    const unsigned long long s2mask = ((unsigned long long)s2m << 32) | s2m;     // (v_cndmask mask of that select)
+    const int p2 = wid, p3 = wid < 2 ? wid : wid + 2;                          // patch piece of S2 (waves 2-3) / S3 within a step's six
     // this wave's weight pieces of the tile at byte offset soff of wsrc into ring slot `slot`
     auto stage_weights = [&](const char* wsrc, unsigned soff, int slot) {
 #pragma unroll
@@ -277,7 +300,9 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void conv_wide_kernel(const ConvArg
     // (tap -1: the step that follows a chunk's last one - tap 0 of the next chunk, or the centre tap of the first shortcut step)
     int after_last_is_center = 0;                                         // set per chunk (wave-uniform)
     auto rd_a = [&](int i, int aoff, int tap, int ks) -> uint4 {
-        const int ad = tap >= 0 ? aaddr(i, tap) : (after_last_is_center ? aaddr(i, CENTER) : aaddr(i, 0));
+        // (the select as an instruction: written in C++, hipcc turns it into a run-time index and moves the table to scratch)
+        const int ad = tap >= 0 ? aaddr(i, tap)
+                                : (int)vsel(after_last_is_center ? ~0ull : 0ull, (unsigned)aaddr(i, CENTER), (unsigned)aaddr(i, 0));
         return *reinterpret_cast<const uint4*>(smem + aoff + (ad ^ (32 * ks)));
     };
     auto rd_b = [&](int j, int boff, int ks) -> uint4 {
@@ -327,11 +352,12 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void conv_wide_kernel(const ConvArg
     for (int j = 0; j < MJ; ++j) fb0[j] = rd_b(j, 0, 0);
 
     // MID of a step: wait for this wave's DMAs of the previous MID, barrier
-    auto mid_sync = [&](bool drain_lds, int do_wait = 1) {
+    auto mid_sync = [&](bool drain_lds, int do_wait = 0) {   // do_wait: DMAs of this wave that may stay in flight (0 or 1)
         unsigned long long q0 = 0, q1 = 0;
         if (STAMPS) q0 = __builtin_amdgcn_s_memtime();
         if (drain_lds) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(0)\n1:" : : "s"(__builtin_amdgcn_readfirstlane(do_wait)) : "memory", "scc");
+        else if (do_wait == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (STAMPS) q1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -339,15 +365,8 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void conv_wide_kernel(const ConvArg
     };
     if (STAMPS) t_loop = __builtin_amdgcn_s_memtime();
 
-    // ---- From here on the kernel exists TWICE, once per staging role (`rest` below; the workgroup's waves branch once and never meet
-    //      again - each copy runs to its own s_endpgm, so no register assignment has to agree where copies would merge: with the
-    //      two copies of the main loop alone, hipcc shuffled the accumulators through scratch at the merge).  With one wave per SIMD
-    //      every instruction a wave issues between two MFMAs is matrix-pipe time (budget ~5 per MFMA), and a CONDITIONAL DMA slot
-    //      costs three times an unconditional one (tools/probes/dma_slot.hip: s_cmp + s_cbranch + DMA +29 cycles per slot, the
-    //      DMA alone +10; EXEC masking is no better): so a slot is v_add (source offset), s_add (M0), the DMA - and nothing is
-    //      conditional: a slot without a piece of its own re-stages a neighbour's (the same bytes to the same LDS address).
     // ---- phase 0: the convolution chunks, nine steps each (unrolled: tap, ring slot and fragment addresses are compile-time)
-    const unsigned wlds = lds_base + (unsigned)(wrole ? wid : 0) * (SPW * 1024);    // weight waves: LDS offset of this wave's piece 0 in a ring slot
+    const unsigned wl0 = lds_base + (unsigned)wid * 1024u;                // LDS offset of weight piece `wid` within a ring slot
     for (int c = 0; c < nch0; ++c) {
         const int aoff = A_BASE + (c & 1) * ABUF;
         const int naoff = A_BASE + ((c + 1) & 1) * ABUF;
@@ -361,19 +380,19 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void conv_wide_kernel(const ConvArg
         after_last_is_center = last_c ? 1 : 0;
         unsigned cw = (unsigned)c * wtile;                               // byte offset of this chunk's weight tiles within a tap
         asm volatile("" : "+s"(cw));                                     // (opaque: per-step sums stay in the loop, not in 30 hoisted SGPRs)
-        // patch waves: per-lane source offset of a piece's rows (pv) / of the LAST piece's rows, tail clamped to the patch's last row
+        // per-lane source offset of a patch piece's rows (pv) / of the LAST piece's rows, tail clamped to the patch's last row
         const int lim = prow - 1 - (apieces - 1) * RPP;
         const unsigned pv = __umul24((unsigned)prl, pxrow) + swzo, pv_last = __umul24((unsigned)(prl < lim ? prl : lim), pxrow) + swzo;
         const unsigned gs = (unsigned)RPP * pxrow;                       // source offset step from piece to piece
+        const unsigned l2 = vsel(s2mask, wvoff[2], pv);                  // S2's per-lane part
         auto step = [&](auto tap_tag) {
             constexpr int TAP = decltype(tap_tag)::value;
             constexpr int SL = TAP % NWB;
             // H1: k-step 0 on set 0 | reads of k-step 1 -> set 1
             half(fa0, fb0, fa1, fb1, std::true_type{}, aoff, IC<TAP>{}, IC<1>{}, SL * BTAP, no_dma);
-            mid_sync(false, (wrole || TAP == 8) ? 1 : 0);
-            // DMAs of this MID.  Weight waves: their SPW pieces of the tile of step t+2 (ring slot (t+2) % 3; past the last step:
-            // tile 0 again, into a slot nobody reads).  Patch waves, steps 0 .. PSTEPS - 1 of a chunk: SPW consecutive regular pieces
-            // (0 .. apieces - 2) of the next chunk's patch from piece (tap NPW + pw) SPW on, clamped; step PSTEPS: the last piece.
+            mid_sync(false, (TAP >= 1 && TAP - 1 <= PLAST) ? 1 : 0);     // (the previous step had an S3: it may stay in flight)
+            // DMAs of this MID: the weight tile of step t+2 (ring slot (t+2) % 3; past the last step: tile 0 again, into a slot
+            // nobody reads), six pieces of the next chunk's patch
             constexpr int WSL = (TAP + 2) % NWB;
             const char* wsrc = a.w;
             unsigned woff = cw;
@@ -385,29 +404,31 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void conv_wide_kernel(const ConvArg
                 else if (T2 < nch1) { wsrc = a.w2; woff = (unsigned)T2 * wtile; }
                 else woff = 0;
             }
-            int q0 = (TAP * NPW + pw) * SPW;                              // (opaque per step, as cw)
+            int q0 = TAP * NPP;                                           // (opaque per step, as cw)
             asm volatile("" : "+s"(q0));
-            auto dma_w = [&](auto g_tag) {
+            auto dma = [&](auto g_tag) {
                 constexpr int gq = decltype(g_tag)::value;
-                const int i = wid * SPW + gq;                                 // (WPT = NWW SPW for TN = 160: every slot has its piece)
-                if (NWW * SPW == WPT || i < WPT) dma16(wsrc, rvoff[gq] + rfl(woff), wlds + WSL * BTAP + gq * 1024);
-            };
-            auto dma_p = [&](auto g_tag) {
-                constexpr int gq = decltype(g_tag)::value;
-                if constexpr (TAP < PSTEPS) {
-                    int q = q0 + gq;
+                if constexpr (gq == 0) {                                  // S2
+                    int q = q0 + p2;
+                    q = q < apieces - 2 ? q : apieces - 2;
+                    const unsigned so = ssel(s2w, woff, puoff + (unsigned)q * gs);
+                    const unsigned la = ssel(s2w, wl0 + WSL * BTAP + 8 * 1024, plds + (unsigned)q * 1024u);
+                    dma16(ssel_ptr(s2w, wsrc, psrc), l2 + so, la);
+                } else if constexpr (gq == 1 || gq == 2) {                // W0, W1
+                    dma16(wsrc, wvoff[gq - 1] + rfl(woff), wl0 + WSL * BTAP + (gq - 1) * 4096);
+                } else if constexpr (gq == 3 && TAP < PLAST) {            // S3: a regular patch piece
+                    int q = q0 + p3;
                     q = q < apieces - 2 ? q : apieces - 2;
                     dma16(psrc, pv + rfl(puoff + (unsigned)q * gs), plds + (unsigned)q * 1024u);
-                } else if constexpr (TAP == PSTEPS) {
-                    if constexpr (gq == 0) dma16(psrc, pv_last + rfl(puoff + (unsigned)(apieces - 1) * gs), plds + (unsigned)(apieces - 1) * 1024u);
+                } else if constexpr (gq == 3 && TAP == PLAST) {           // S3: the last patch piece
+                    dma16(psrc, pv_last + rfl(puoff + (unsigned)(apieces - 1) * gs), plds + (unsigned)(apieces - 1) * 1024u);
                 }
             };
             // H2: k-step 1 on set 1 | reads of the next step's k-step 0 -> set 0.  The step after tap 8 is tap 0 of the next chunk or
             // the first shortcut step (centre tap): ONE code path with the tap's addresses selected (after the very last step the
-            // reads fetch stale LDS into registers nobody uses).  H2 exists once per role (ONE wave-uniform branch per step).
+            // reads fetch stale LDS into registers nobody uses)
             constexpr bool SAME = TAP < 8;                                // the next step belongs to this chunk
-            if (wrole) half(fa1, fb1, fa0, fb0, std::true_type{}, SAME ? aoff : naoff, IC<(SAME ? TAP + 1 : -1)>{}, IC<0>{}, ((TAP + 1) % NWB) * BTAP, dma_w);
-            else half(fa1, fb1, fa0, fb0, std::true_type{}, SAME ? aoff : naoff, IC<(SAME ? TAP + 1 : -1)>{}, IC<0>{}, ((TAP + 1) % NWB) * BTAP, dma_p);
+            half(fa1, fb1, fa0, fb0, std::true_type{}, SAME ? aoff : naoff, IC<(SAME ? TAP + 1 : -1)>{}, IC<0>{}, ((TAP + 1) % NWB) * BTAP, dma);
         };
         step(IC<0>{});
         step(IC<1>{});
