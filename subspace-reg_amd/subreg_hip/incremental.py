@@ -299,23 +299,20 @@ class IncrementalRunner:
         d.stable_mode, d.target_loss, d.convergence_eps = int(opt.stable), opt.target_train_loss, opt.convergence_epsilon
         fwd_per_epoch = 1 + (1 if Bm else 0) + n_sets     # forwards the reference makes per epoch (feeds DropBlock's gamma)
 
-        def step_and_validate():
-            _lib.check(lib.subreg_finetune_step(C.byref(d), s()), "finetune_step")
+        def validate_only():
             if n_sets <= _lib.MAX_QUERY_SETS:          # all query sets in one launch (rows and labels are consecutive)
                 _lib.check(lib.subreg_validate_sets(_lib.ptr(feats[q_off[0]:]), _lib.ptr(query_labels), _lib.ptr(W), bias_p, set_rows,
                                                     n_sets, N, D, _lib.ptr(ses.state), _lib.ptr(ses.correct), _lib.ptr(ses.correct5),
                                                     n_sets, 1, s()), "validate_sets")
                 return
-            for j in range(n_sets):
+            for j in range(n_sets):                    # more sessions than one launch takes: one launch per set
                 _lib.check(lib.subreg_validate(_lib.ptr(feats[q_off[j]:]), _lib.ptr(query_id[j]), _lib.ptr(W), bias_p,
                                                query_x[j].shape[0], N, D, _lib.ptr(ses.state), _lib.ptr(ses.correct), j,
                                                n_sets, int(j == n_sets - 1), s()), "validate")
 
-        def validate_only():
-            assert n_sets <= _lib.MAX_QUERY_SETS
-            _lib.check(lib.subreg_validate_sets(_lib.ptr(feats[q_off[0]:]), _lib.ptr(query_labels), _lib.ptr(W), bias_p, set_rows,
-                                                n_sets, N, D, _lib.ptr(ses.state), _lib.ptr(ses.correct), _lib.ptr(ses.correct5),
-                                                n_sets, 1, s()), "validate_sets")
+        def step_and_validate():
+            _lib.check(lib.subreg_finetune_step(C.byref(d), s()), "finetune_step")
+            validate_only()
 
         trainable = [] if self.backbone_frozen else [p_ for n_, p_ in net.named_parameters()
                                                        if not n_.startswith("classifier") and p_.requires_grad]
@@ -326,6 +323,13 @@ class IncrementalRunner:
             #      the forward used) goes back through the backbone's HIP backward, and every backbone parameter takes the same
             #      SGD(lr, momentum, weight_decay) step (get_optim builds ONE optimiser over net.parameters() per session, :231);
             #      the query sets are then forwarded through the UPDATED backbone.  The regularizers do not reach the backbone.
+            #      Semantics AFTER the freeze are those of torch >= 2.0 (the torch the goldens were generated with, 2.10):
+            #      optimizer.zero_grad() sets gradients to None, so a frozen parameter (requires_grad False, grad None) is skipped by
+            #      SGD - no weight decay, no coasting momentum.  Under the reference's documented environment (setup.sh: torch 1.7,
+            #      zero_grad(set_to_none=False)) the frozen parameters keep ZERO gradient tensors and the session's single SGD
+            #      optimiser goes on applying weight decay and momentum to the backbone after epoch K; that legacy behaviour is
+            #      NOT emulated here (it is an artefact of the old default, not something language_eval.py asks for), and the
+            #      golden loop_hw32_freeze3.npz does not pin it.
             from .train import SGD as _BackboneSGD
             if getattr(opt, "adam", False):
                 raise NotImplementedError("freeze_backbone_at > 1 with --adam (the backbone's optimiser here is SGD)")
@@ -379,6 +383,7 @@ class IncrementalRunner:
         #      backbone, constant inputs): after one eager pass its launch sequence is captured into a hipGraph and
         #      replayed - every epoch still executes all 22 convolutions, only the host-side launches are saved.
         graph, eager_done, replays = None, 0, 0
+        need_forward = True
         # what THIS rank forwards per epoch: everything, or its row slice of all_x (features all-gathered afterwards)
         if self.dp is None:
             x_loc, out_loc = all_x, feats
@@ -392,7 +397,10 @@ class IncrementalRunner:
             k = min(self.epochs_per_sync, max_e - done)
             executed = 0
             for e in range(k):
-                if not self.reuse_features or (done == 1 and e == 0):
+                # reuse_features: ONE eval-mode forward of every row through the backbone as it is from now on (frozen) - the first
+                # pass through here, whether epoch 1 or the pre-freeze epochs 1 .. K-1 came before - then the features are reused
+                if not self.reuse_features or need_forward:
+                    need_forward = False
                     if x_loc.shape[0] == 0:
                         pass                                                    # more ranks than rows: nothing to forward here
                     elif graph is not None:

@@ -254,6 +254,25 @@ def test_feature_reuse_is_results_identical():
     assert np.array_equal(outs[0]["classifier_weight"], outs[1]["classifier_weight"])
 
 
+def test_feature_reuse_after_pre_freeze_epochs_is_results_identical():
+    """freeze_backbone_at = 3 with the opt-in feature reuse: the ONE eval-mode forward the reuse keeps must come AFTER the last
+    backbone update of the pre-freeze epochs (round-4 advisor finding: with K - 1 >= 2 pre-freeze epochs no forward ran at all and
+    the classifier steps of the frozen epochs trained on the support features of the backbone before its last SGD step)."""
+    from subreg_hip.incremental import few_shot_finetune_incremental_test
+    g = np.load(os.path.join(GOLDEN, "loop_hw32_freeze3.npz"))
+    assert int(g["opt.freeze_backbone_at"]) >= 3
+    outs = []
+    for reuse in (False, True):
+        net, opt, meta, base_loader, bsl, inits, picks = build_case(g, "f32")
+        few_shot_finetune_incremental_test(net, {}, None, meta, base_loader, opt, base_support_loader=bsl, novel_inits=inits,
+                                           memory_picks=picks, reuse_features=reuse, verbose=False)
+        outs.append(net.last_run)
+    assert outs[0]["epochs"] == outs[1]["epochs"] and outs[0]["test_acc"] == outs[1]["test_acc"]
+    for la, lb in zip(outs[0]["loss"], outs[1]["loss"]):
+        assert np.array_equal(np.asarray(la), np.asarray(lb))
+    assert np.array_equal(outs[0]["classifier_weight"], outs[1]["classifier_weight"])
+
+
 def test_module_surface_runs_reference_loop_body():
     """The drop-in modules under the reference's own loop statements (language_eval.py:242-326), torch autograd + SGD,
     give the same numbers as the fused loop: 1 session, 4 epochs."""

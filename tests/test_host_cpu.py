@@ -142,6 +142,28 @@ def test_layer1_plane_swizzle_emulation():
     assert sorted(t for t, extra in by_tile.items() if extra > 0) == [2, 5, 7], by_tile   # pixels 84 and 168 fall in tiles 2 and 5 (7: its padding rows)
 
 
+def test_m0_is_touched_only_by_the_lds_dma_statements(built):
+    """The LDS-DMA helpers declare M0 clobbered instead of saving / restoring it (csrc/subreg_common.h): sound only while the
+    compiler never keeps a value of its own in M0.  The Makefile checks every kernel file's ISA on every build
+    (tools/check_isa.py over the .s files -save-temps leaves in build/); this test re-runs that check on the library the suite
+    loads, and proves the checker itself fires on an offending line."""
+    import subprocess
+    import sys
+    import tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bdir = os.path.join(repo, "subspace-reg_amd", "build")
+    import glob
+    if not glob.glob(os.path.join(bdir, "*-gfx950.s")):
+        _lib.build()                                         # (a library built elsewhere: rebuild here to get the ISA files)
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "check_isa.py"), bdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "x-hip-amdgcn-amd-amdhsa-gfx950.s"), "w") as f:
+            f.write("\ts_mov_b32 m0, s4\n\t;;#ASMSTART\n\ts_mov_b32 m0, s5\n\t;;#ASMEND\n\tv_movrels_b32 v1, v2\n")
+        r = subprocess.run([sys.executable, os.path.join(repo, "tools", "check_isa.py"), td], capture_output=True, text=True)
+        assert r.returncode == 1 and "2 line(s)" in r.stdout, r.stdout
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(REPO, "subspace-reg_amd", "subreg_hip")
     for fn in os.listdir(pkg):
