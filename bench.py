@@ -557,10 +557,12 @@ def main():
     fwd_ms = sum(e0.elapsed_time(e1) for rr in runners for (e0, e1, _n) in rr.fwd_events)
     n_fwd = sum(len(rr.fwd_events) for rr in runners)
     achieved = imgs * FLOP_PER_IMAGE / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
-    traffic = None
+    traffic, traffic_head = None, None
     tpath = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(tpath):
-        traffic = (json.load(open(tpath)).get(args.dtype) or {}).get("bytes_per_image")   # HBM bytes per image forwarded
+        tj = json.load(open(tpath)).get(args.dtype) or {}
+        traffic = tj.get("bytes_per_image")                        # HBM bytes per image forwarded (FETCH_SIZE / WRITE_SIZE passes)
+        traffic_head = tj.get("head")                              # the commit those counter passes were recorded on
     # `value` = K episodes / time, as the contract says; step i is session i mod 8, so a K that is not a multiple of 8 over-weights
     # the cheap early sessions (session s forwards 125 (s + 2) images per epoch).  The session-balanced figure beside it is
     # images/s over the mean image count of the 8 sessions of a run (incl. each run's initial base evaluation): it does not move
@@ -577,7 +579,7 @@ def main():
                    "feature_reuse": bool(args.reuse_features), "backbone": "ResNet18 (RFS ResNet-12 family, 8.1219 GFLOP/img)",
                    "n_ranks_seen": dist.get_world_size() if world > 1 else 1},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": traffic,
+                     "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": traffic, "traffic_recorded_at": traffic_head,
                      "kernel": "conv_fwd_kernel family over %d backbone forwards (%.1f ms each)" % (n_fwd, fwd_ms / max(n_fwd, 1))},
         "images_per_s": imgs * world / dt,
         "episodes_per_s_balanced": imgs * world / dt / mean_imgs,   # session-balanced: invariant in --steps

@@ -60,5 +60,16 @@ bash $R/tools/pmc_layers.sh > $O/pmc_raw.txt 2>&1
 python3 $R/tools/dp_pretrain_check.py 2>&1 | grep -v "amdgpu.ids\|Gloo\|socket.cpp" > $O/dp_pretrain_check.txt
 python3 $R/tools/dp_check.py 2>&1 | grep -v "amdgpu.ids\|Gloo\|socket.cpp" > $O/dp_check.txt
 python3 $R/tools/rccl_smoke.py 2>&1 | grep -v "amdgpu.ids" > $O/rccl_single_rank_smoke.txt
+# --- a step that died must not pass as evidence: a file with a Python traceback (or an empty one) is replaced by the previous run's
+#     file, the run is reported as FAILED and exits non-zero
+bad=0
+for f in $O/*; do
+  if [ ! -s "$f" ] || grep -q "Traceback (most recent call last)" "$f"; then
+    bad=$((bad+1)); echo "record_evidence: FAILED STEP -> $(basename $f)"; head -c 600 "$f"
+    if [ -f "$FINAL/$(basename $f)" ]; then cp "$FINAL/$(basename $f)" "$f.previous"; fi
+    mv "$f" "$f.FAILED"
+  fi
+done
 rm -rf $FINAL && mv $O $FINAL
+if [ $bad -gt 0 ]; then echo "evidence INCOMPLETE: $bad step(s) failed"; exit 1; fi
 echo evidence done
