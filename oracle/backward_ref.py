@@ -13,16 +13,17 @@ from . import resnet_ref as rr
 from .loop_ref import cross_entropy
 
 
-def conv_backward(x, w_oihw, dy):
-    """x [B,H,W,C], w [O,C,k,k], dy [B,H,W,O] -> (dx, dw) in float64."""
+def conv_backward(x, w_oihw, dy, dtype=np.float64):
+    """x [B,H,W,C], w [O,C,k,k], dy [B,H,W,O] -> (dx, dw) in float64 (dtype = np.float32: the BLAS calls in single precision -
+    half the time at the pretraining batch; for comparisons gated at 5e-2, never for the pinned CPU tests)."""
     B, H, W, C = x.shape
     O, _, k, _ = w_oihw.shape
-    x, dy, w = x.astype(np.float64), dy.astype(np.float64), w_oihw.astype(np.float64)
+    x, dy, w = x.astype(dtype), dy.astype(dtype), w_oihw.astype(dtype)
     dw = np.zeros_like(w)
     if k == 1:
         dw[:, :, 0, 0] = dy.reshape(-1, O).T @ x.reshape(-1, C)
         return (dy.reshape(-1, O) @ w[:, :, 0, 0]).reshape(B, H, W, C), dw
-    xp = np.zeros((B, H + 2, W + 2, C))
+    xp = np.zeros((B, H + 2, W + 2, C), dtype)
     xp[:, 1:-1, 1:-1] = x
     dxp = np.zeros_like(xp)
     d2 = dy.reshape(-1, O)
@@ -160,7 +161,7 @@ def sgd_momentum_step(p, g, buf, lr, momentum, weight_decay):
     return p - lr * buf, buf
 
 
-def backward_from_stash(sd, stash, x_nchw, labels, n_blocks=(1, 1, 2, 2), round_fn=None):
+def backward_from_stash(sd, stash, x_nchw, labels, n_blocks=(1, 1, 2, 2), round_fn=None, conv_dtype=np.float64):
     """The backward half of `train_step` started from a GIVEN forward stash instead of its own forward (same autograd rules,
     models/resnet_language.py:268-301 / train_supervised.py:229-244): every decision the backward takes from forward values -
     LeakyReLU side, MaxPool argmax, keep masks, BatchNorm batch statistics - comes from `stash`, so an implementation whose
@@ -199,7 +200,8 @@ def backward_from_stash(sd, stash, x_nchw, labels, n_blocks=(1, 1, 2, 2), round_
 
         def conv_back(slot, cname, bname, dy, inp, act):
             draw, dg, db = bn_bwd(dy, st["raw" + slot], st["mean" + slot], st["invstd" + slot], sd[bname + ".weight"], act)
-            dinp, dw = conv_backward(inp, r(sd[cname + ".weight"].astype(f64)), draw)
+            dinp, dw = conv_backward(inp, r(sd[cname + ".weight"].astype(f64)), draw, conv_dtype)
+            dinp, dw = dinp.astype(f64), dw.astype(f64)
             grads[cname + ".weight"], grads[bname + ".weight"], grads[bname + ".bias"] = dw, dg, db
             return dinp
         d_t2 = r(conv_back("3", name + ".conv3", name + ".bn3", dv, st["act2"].astype(f64), None))

@@ -268,9 +268,12 @@ def test_feature_reuse_after_pre_freeze_epochs_is_results_identical():
                                            memory_picks=picks, reuse_features=reuse, verbose=False)
         outs.append(net.last_run)
     assert outs[0]["epochs"] == outs[1]["epochs"] and outs[0]["test_acc"] == outs[1]["test_acc"]
+    # (not bitwise: the two runs fine-tune the backbone separately, and the float atomics of the first-layer / 1x1 dW kernels leave
+    # their last bits run-dependent - measured 5e-6 ... 1.4e-5 relative on the losses of the frozen epochs.  The stale-feature bug
+    # moved them in the third digit.)
     for la, lb in zip(outs[0]["loss"], outs[1]["loss"]):
-        assert np.array_equal(np.asarray(la), np.asarray(lb))
-    assert np.array_equal(outs[0]["classifier_weight"], outs[1]["classifier_weight"])
+        np.testing.assert_allclose(np.asarray(la), np.asarray(lb), rtol=1e-4, atol=0)
+    np.testing.assert_allclose(outs[0]["classifier_weight"], outs[1]["classifier_weight"], rtol=0, atol=2e-5)
 
 
 def test_module_surface_runs_reference_loop_body():

@@ -257,11 +257,19 @@ def _train_net(dtype):
     return net
 
 
+# (image size, golden file): the two small cases, and the batch train_supervised.py really runs (configs.py:124: 64 images of
+# 84x84 - what bench.py's pretraining leg times: there the HIP path selects its split-K workspace, the dW split targets and the
+# two-stream schedule, none of which the 6- and 8-image cases reach)
+TRAIN_CASES = [(32, "train_step.npz"), (84, "train_step.npz"), (84, "train_step_b64.npz")]
+TRAIN_IDS = ["hw32_B8", "hw84_B6", "hw84_B64"]
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("hw", [32, 84])
-def test_train_step_against_reference_autograd(hw, dtype):
+@pytest.mark.parametrize("case", TRAIN_CASES, ids=TRAIN_IDS)
+def test_train_step_against_reference_autograd(case, dtype):
     from subreg_hip.train import SGD
-    g = np.load(os.path.join(GOLDEN, "train_step.npz"))
+    hw, fname = case
+    g = np.load(os.path.join(GOLDEN, fname))
     key = "hw%d" % hw
     net = _train_net(dtype)
     x = torch.from_numpy(syn.make_images(72, int(g[key + ".B"]), hw)).cuda()
@@ -292,12 +300,16 @@ def test_train_step_against_reference_autograd(hw, dtype):
             if f32:
                 assert l2 < 1.5e-2, ("l2", name, l2)
                 if name.startswith(exact_prefixes):
-                    _cmp("grad " + name, got, want, 1e-3 * max(float(np.abs(want).max()), 1e-6), 2e-3)
+                    # (B = 64: a gradient element is a sum over 64 x H x W terms that largely cancel - the mean gradient is ~8x
+                    # smaller than at B = 6 while the fp32 summation-order noise is not: measured 2.1e-3 of the tensor's maximum
+                    # on layer4.0.bn1.weight against the reference's own fp32 autograd)
+                    big = int(g[key + ".B"]) > 16
+                    _cmp("grad " + name, got, want, (4e-3 if big else 1e-3) * max(float(np.abs(want).max()), 1e-6), 2e-3)
             # (bf16: the element-wise gate is test_bf16_backward_from_its_own_forward_stash - every tensor within 5e-2 of the
             # oracle's backward over the SAME forward stash.  Against the fp32 reference a one-ulp forward difference flips a
             # MaxPool argmax / LeakyReLU side now and then and re-routes gradient discretely, so here only the loss and the
             # gradient norms above are compared.)
-    if not f32:
+    if not f32 and int(g[key + ".B"]) <= 16:
         # whole step, forward flips INCLUDED: bf16 against the oracle that ROUNDS WHERE THE HIP PATH STORES (oracle/torch_ref.py::train_step_grads: packed input, raw
         # conv outputs, activations, block outputs and the gradients with respect to them in bf16; fp32 accumulation; pinned in
         # its fp32 mode by tests/test_oracle_golden.py).  What is left between the two is the accumulation order (an ulp in a
@@ -601,8 +613,11 @@ def _hip_stash_as_oracle_input(net, B, hw):
     return out
 
 
-@pytest.mark.parametrize("hw", [32, 84])
-def test_bf16_backward_from_its_own_forward_stash(hw):
+# (84, 64): the batch bench.py's pretraining leg times (configs.py:124).  B = 128 (its second timed batch) runs the same kernel
+# selection as 64 and costs 9 minutes of NumPy oracle on the GPU box's host: not in the suite (SUBREG_TEST_B128=1 adds it).
+@pytest.mark.parametrize("case", [(32, 0), (84, 0), (84, 64)] + ([(84, 128)] if os.environ.get("SUBREG_TEST_B128") == "1" else []),
+                         ids=["hw32_B8", "hw84_B6", "hw84_B64"] + (["hw84_B128"] if os.environ.get("SUBREG_TEST_B128") == "1" else []))
+def test_bf16_backward_from_its_own_forward_stash(case):
     """bf16 is the dtype of BASELINE.json configs[2] / [4]: pin its BACKWARD kernels tightly.  The bf16 forward's own stash
     (raw conv outputs, activations, batch statistics, block outputs, keep masks - exactly what the HIP backward reads) goes into
     the oracle's backward (oracle/backward_ref.py::backward_from_stash, pinned on CPU against train_step and the reference's
@@ -610,13 +625,17 @@ def test_bf16_backward_from_its_own_forward_stash(hw):
     LeakyReLU side or a MaxPool argmax between the two (that is what kept the whole-step bf16 gate at cosine 0.9), so every
     conv weight gradient (dW kernels), BatchNorm affine gradient (BN backward), and through them every dX / block-tail kernel
     must agree to 5e-2 relative L2 per tensor (measured 0.5-2e-2)."""
+    hw, B = case
     g = np.load(os.path.join(GOLDEN, "train_step.npz"))
     key = "hw%d" % hw
-    B = int(g[key + ".B"])
+    if B == 0:
+        B, labels = int(g[key + ".B"]), g[key + ".labels"]
+    else:                                  # the timed batches of bench.py's pretraining leg (84x84, 64 and 128 images)
+        labels = np.random.RandomState(73).randint(0, 60, B)
     net = _train_net("bf16")
     x_np = syn.make_images(72, B, hw)
     x = torch.from_numpy(x_np).cuda()
-    y = torch.from_numpy(g[key + ".labels"]).cuda()
+    y = torch.from_numpy(labels).cuda()
     net.train()
     loss = torch.nn.CrossEntropyLoss()(net(x), y)
     loss.backward()
@@ -624,7 +643,7 @@ def test_bf16_backward_from_its_own_forward_stash(hw):
     stash = _hip_stash_as_oracle_input(net, B, hw)
     sd = {k: v.detach().float().cpu().numpy() for k, v in net.state_dict().items() if v.dtype.is_floating_point}
     rb = lambda a: _round_bf16(np.asarray(a, np.float32)).astype(np.float64)      # noqa: E731
-    loss_o, go = br.backward_from_stash(sd, stash, _round_bf16(x_np), g[key + ".labels"], round_fn=rb)
+    loss_o, go = br.backward_from_stash(sd, stash, _round_bf16(x_np), labels, round_fn=rb, conv_dtype=np.float32 if B > 16 else np.float64)
     _cmp("loss", loss.item(), loss_o, 1e-3, 1e-3)
     worst = ("", 0.0)
     for name, p in net.named_parameters():

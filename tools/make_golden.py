@@ -544,10 +544,13 @@ TRAIN_SLICES = {"layer1.0.conv1.weight": None, "layer1.0.downsample.0.weight": N
                 "layer4.1.conv3.weight": 2, "classifier.weight": None}
 
 
-def gen_train_step():
+def gen_train_step(cases=((84, 6), (32, 8)), fname="train_step.npz"):
+    """cases: (image size, batch).  train_step.npz holds the two small cases; train_step_b64.npz (`train64`) the batch
+    train_supervised.py really runs (configs.py:124: batch_size 64, 84x84) - the one bench.py's pretraining leg times, where the
+    HIP path selects its split-K workspace, the dW split targets and the two-stream schedule."""
     opt = ref_opt()
     out = {}
-    for hw, B in ((84, 6), (32, 8)):
+    for hw, B in cases:
         sd = syn.make_state_dict(71)
         net = ref_net(sd, opt)
         x = syn.make_images(72, B, hw)
@@ -576,13 +579,13 @@ def gen_train_step():
         o.step()
         out[key + ".after_step.classifier.weight"] = t2n(net.classifier.weight)
         out[key + ".after_step.layer1.0.conv1.weight"] = t2n(dict(net.named_parameters())["layer1.0.conv1.weight"])
-    np.savez_compressed(os.path.join(GOLD, "train_step.npz"), **out)
-    print("train_step.npz", sum(v.nbytes for v in out.values()) / 1e6, "MB")
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
+    print(fname, sum(v.nbytes for v in out.values()) / 1e6, "MB")
 
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["blocks", "backbone", "reg", "train", "loop32", "adam", "bias", "semantic", "episodes", "loop84"]
+    what = sys.argv[1:] or ["blocks", "backbone", "reg", "train", "train64", "loop32", "adam", "bias", "semantic", "episodes", "loop84"]
     if "blocks" in what:
         gen_blocks()
     if "backbone" in what:
@@ -591,6 +594,8 @@ def main():
         gen_reg()
     if "train" in what:
         gen_train_step()
+    if "train64" in what:
+        gen_train_step(cases=((84, 64),), fname="train_step_b64.npz")
     if "loop32" in what:
         gen_loop("hw32_noM", 32, 2, False, 40, seed=1, max_novel_epochs=4)
         gen_loop("hw32_M", 32, 3, True, 40, seed=2, max_novel_epochs=3)
