@@ -220,6 +220,10 @@ class ResNet(nn.Module):
                 torch._foreach_add_([m.num_batches_tracked for m in self._bns], 1)      # one launch, not one per BatchNorm
             return feat
         hb = self.hip_backbone()
+        if not self.training and not return_stages:
+            # eval mode over a backbone without gradients: the unchanged reference loop calls this with the same shapes every epoch
+            # (support set, every query set) - cached hipGraph per shape, see HipBackbone.forward_graphed
+            return hb.forward_graphed(x.float())
         out = hb.forward(x.float(), train=self.training, masks=self.mask_source, return_stages=return_stages)
         if self.training:
             torch._foreach_add_([m.num_batches_tracked for m in self._bns], 1)

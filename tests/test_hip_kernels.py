@@ -612,6 +612,35 @@ def test_backbone_golden(hw, dtype):
          5e-4 if dtype == "f32" else a, 5e-4 if dtype == "f32" else r)
 
 
+def test_graphed_eval_forward_equals_eager_and_follows_weight_updates():
+    """HipBackbone.forward_graphed (what ResNet.forward runs in eval mode: the unchanged reference loop calls it with the same shapes
+    every epoch) replays a cached hipGraph from the third call of a shape on.  It must return what the eager forward returns,
+    for whatever input is passed, and re-capture when a weight tensor changes (refresh() sees tensor._version) or a larger
+    shape moves the workspaces."""
+    from subreg_hip.backbone import HipBackbone
+    sd = syn.make_state_dict(3)
+    params = {k: _t(v) for k, v in sd.items() if v.dtype != np.int64}
+    hb = HipBackbone(params, (1, 1, 2, 2), "bf16")
+    xs = [_t(syn.make_images(5 + i, 6, 84)) for i in range(3)]
+    want = [hb.forward(x).clone() for x in xs]
+    for rep in range(3):                                   # eager, capture + replay, replay
+        for x, w in zip(xs, want):
+            got = hb.forward_graphed(x)
+            assert torch.equal(got, w), (rep, (got - w).abs().max().item())
+    assert hb._graphs[tuple(xs[0].shape)]["graph"] is not None
+    with torch.no_grad():
+        params["layer2.0.conv2.weight"].mul_(1.25)         # in-place update: version bump -> re-pack -> cached graph dropped
+    want2 = hb.forward(xs[0]).clone()
+    assert not torch.equal(want2, want[0])
+    for rep in range(3):
+        assert torch.equal(hb.forward_graphed(xs[0]), want2), rep
+    big = _t(syn.make_images(9, 40, 84))                   # a larger shape re-allocates the workspaces under the cached graph
+    want_big = hb.forward(big).clone()
+    for rep in range(3):
+        assert torch.equal(hb.forward_graphed(big), want_big)
+        assert torch.equal(hb.forward_graphed(xs[0]), want2)
+
+
 def test_workspace_capacity_is_not_monotone_in_batch():
     """A train-mode forward at B=64 followed by B=55 (84x84, bf16): the smaller batch needs MORE BN-partial floats (layer 2
     switches to 128-row tiles below 56 images).  The workspace must grow, and the result must equal a fresh backbone's."""
