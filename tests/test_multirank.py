@@ -112,12 +112,18 @@ def _shard_worker(rank, world, port, q):
     local[:hi - lo] = fwd(x[lo:hi])
     buf = torch.zeros(world * per, 2)
     full = sh.gather(local, 7, out=buf)
-    lin = torch.nn.Linear(4, 3)
+    # a module with fp32 parameters / buffers AND int64 counters (BatchNorm.num_batches_tracked): one flat collective per dtype
+    lin = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
     with torch.no_grad():
-        lin.weight.fill_(float(rank + 1))
-    sweep.broadcast_module(lin, 0)
+        lin[0].weight.fill_(float(rank + 1))
+        lin[1].running_var.fill_(0.5 + rank)
+        lin[1].num_batches_tracked.fill_(7 + rank)
+    w_id = lin[0].weight.data_ptr()
+    n_coll = sweep.broadcast_module(lin, 0)
+    ok_b = (n_coll == 2 and lin[0].weight.data_ptr() == w_id and float(lin[1].running_var[0]) == 0.5
+            and int(lin[1].num_batches_tracked) == 7 and lin[1].num_batches_tracked.dtype == torch.int64)
     if rank == 1:
-        q.put(((lo, hi, per), torch.equal(full, fwd(x)), full.data_ptr() == buf.data_ptr(), float(lin.weight[0, 0])))
+        q.put(((lo, hi, per), torch.equal(full, fwd(x)), full.data_ptr() == buf.data_ptr(), float(lin[0].weight[0, 0]) if ok_b else -1.0))
     dist.destroy_process_group()
 
 

@@ -47,10 +47,7 @@ def main():
     net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in syn.make_state_dict(3, randomize_bn=False).items()})
     net = net.to(dev)
     before = {k: v.clone() for k, v in net.state_dict().items()}
-    n_b = 0
-    for _name, t in sorted(net.state_dict().items()):                    # what sweep.broadcast_module does for a group > 1
-        dist.broadcast(t, 0, group=grp)
-        n_b += 1
+    n_b = sweep.broadcast_module(net, 0, grp, force=True)                # ONE flat RCCL broadcast per dtype (fp32 + the int64 counters)
     assert all(torch.equal(before[k], v) for k, v in net.state_dict().items())
     local = torch.randn(350, 640, device=dev)
     out = torch.empty(350, 640, device=dev)
