@@ -22,6 +22,16 @@ for b in 256 700 1125; do python3 $R/tools/bench_conv.py --batch $b 2>&1 | $G > 
 python3 $R/tools/bench_conv.py --batch 700 --unfused --only L1 2>&1 | $G > $O/conv_l1_unfused_b700.txt
 python3 $R/tools/bench_conv.py --batch 700 --im2col --only L1 2>&1 | $G > $O/conv_l1_im2col_b700.txt
 python3 $R/tools/bench_conv.py --batch 256 --dtype f32 2>&1 | $G > $O/conv_layers_f32.txt
+# --- round 5: the one-wave-per-SIMD kernel (conv_wide.hip) forced on every wide layer, its in-kernel stamps (library variant built with
+#     -DSUBREG_WIDE_DIAG=3: `make variant NAME=wd3 EXTRA=-DSUBREG_WIDE_DIAG=3` in subspace-reg_amd/), and the probes behind DESIGN 4.3
+python3 $R/tools/bench_conv.py --batch 700 --kernel wide 2>&1 | $G > $O/conv_layers_b700_wide.txt
+if [ -f $R/subspace-reg_amd/subreg_hip/libsubreg_wd3.so ]; then
+  SUBREG_LIB=$R/subspace-reg_amd/subreg_hip/libsubreg_wd3.so python3 $R/tools/diag_conv.py --batch 700 --kernel wide 2>&1 | $G > $O/wide_stamps_b700.txt
+fi
+for p in dma_issue dma_slot mfma_shape; do
+  [ -x $R/tools/probes/$p ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-inline-asm $R/tools/probes/$p.hip -o $R/tools/probes/$p
+  $R/tools/probes/$p > $O/probe_$p.txt 2>&1
+done
 # --- whole forward, A/B of this round's layer-1 changes within one box
 for v in "" SUBREG_NO_FUSED12=1 SUBREG_IM2COL_FIRST=1; do
   echo "== ${v:-production}" >> $O/forward_ab_layer1.txt
