@@ -136,8 +136,8 @@ __device__ __forceinline__ void dma16_if(int ok, const char* base_in, unsigned v
 // WM x WN waves of (32 MI) x 160 output tiles; POOL: window-major rows + 2x2 max; AROWS: patch rows per LDS buffer.
 // MI = 3 (96 rows, 240 accumulator registers): hipcc (ROCm 7.2) keeps MFMA accumulators in the 256 AGPRs only - with the 320 of a
 // 128-row tile it parks 64 of them in VGPRs and copies them in and out around every MFMA (11 k v_accvgpr instructions, 1.8 KB of scratch).
-template <int MI, int WM, int WN, bool POOL, int AROWS>
-__global__ __launch_bounds__(WM* WN * 64, 1) void conv_wide_kernel(const ConvArgs a) {
+template <int MI, int WM, int WN, bool POOL, int AROWS, int MINW>
+__global__ __launch_bounds__(WM* WN * 64, MINW) void conv_wide_kernel(const ConvArgs a) {
     constexpr bool SWAPC = !POOL;
     constexpr int NW = WM * WN, MJ = 5, TM = WM * MI * 32, TN = WN * 160;
     constexpr int ROWB = 64, RPP = 16, SLOTS = 4, ELEM = 2, TAPS = 9, CENTER = 4;
@@ -600,11 +600,11 @@ int worst_patch_rows_w(const ConvGeom& g, int TM) {
     return worst;
 }
 
-template <int MI, int WM, int WN, bool POOL, int AROWS>
+template <int MI, int WM, int WN, bool POOL, int AROWS, int MINW>
 int launch_wide(const ConvArgs& a, hipStream_t stream) {
     constexpr int TM = WM * MI * 32, TN = WN * 160;
     const size_t lds = 3 * (size_t)TN * 64 + 2 * (size_t)(AROWS + 1) * 64 + TN * sizeof(float);
-    auto kern = conv_wide_kernel<MI, WM, WN, POOL, AROWS>;
+    auto kern = conv_wide_kernel<MI, WM, WN, POOL, AROWS, MINW>;
     static std::atomic<unsigned long long> lds_set{0};
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set)) return rc;
     dim3 grid(((a.g.M + TM - 1) / TM) * (a.Cout / TN));
@@ -612,8 +612,15 @@ int launch_wide(const ConvArgs& a, hipStream_t stream) {
     return launch_status();
 }
 
-constexpr int WIDE_MI = 3, WIDE_TM = 4 * WIDE_MI * 32;              // 384-row tiles
-constexpr int AR_LIN = 480, AR_POOL = 544;                           // patch rows: 384 + 2 (W + 1) at W <= 42; pooled window-major tiles
+// Two tilings of the same kernel body (SUBREG_WIDE_MI picks; measurements):
+//   MI = 3: 96 x 160 wave tiles, 384 x 160 tiles, ONE workgroup per CU (a wave owns its SIMD's 512 registers)
+//   MI = 2: 64 x 160 wave tiles, 256 x 160 tiles, TWO workgroups per CU (256 registers per wave: 160 accumulators + two fragment
+//           sets) - the general kernel's tile under this kernel's loop (reads a k-step ahead, weights 1.5 steps ahead, unconditional
+//           slots), with a second workgroup to cover prologue, epilogue and the step's waits
+int wide_mi() { static const int v = [] { const char* e = getenv("SUBREG_WIDE_MI"); return e && *e ? atoi(e) : 2; }(); return v == 3 ? 3 : 2; }
+int wide_tm() { return 4 * wide_mi() * 32; }
+constexpr int AR_LIN3 = 480, AR_POOL3 = 544;                         // patch rows: 384 + 2 (W + 1) at W <= 42; pooled window-major tiles
+constexpr int AR_LIN2 = 352, AR_POOL2 = 384;                         // 256 + 2 (W + 1); pooled
 
 }  // namespace
 
@@ -626,22 +633,31 @@ bool conv_wide_supported(const ConvArgs& a, bool pool) {
         (long long)a.g.taps * a.Cin * a.Cout * 2 >= (1LL << 32))
         return false;
     if (a.g.npix < 16) return false;                                   // (a patch piece's tail rows re-read valid rows)
-    const int worst = pool ? worst_patch_rows_w<true>(a.g, WIDE_TM) : worst_patch_rows_w<false>(a.g, WIDE_TM);
-    return worst <= (pool ? AR_POOL : AR_LIN);
+    const int worst = pool ? worst_patch_rows_w<true>(a.g, wide_tm()) : worst_patch_rows_w<false>(a.g, wide_tm());
+    return worst <= (wide_mi() == 3 ? (pool ? AR_POOL3 : AR_LIN3) : (pool ? AR_POOL2 : AR_LIN2));
 }
 
-// Measured rule (profiles/r05_*): the kernel runs ONE 384 x 160 tile per CU and round, so it wants whole rounds.
+// Measured rule (profiles/r05_wide2_vs_general.txt: both kernels per layer at ten batch sizes, one box).  The 256-row / two-workgroup
+// variant (MI = 2) is the general kernel's tile under this file's loop; it is faster wherever the general kernel ALSO runs 256-row
+// tiles or nearly so - the 42x42 maps (layer 2: -3 ... -14 % on conv2 / conv3 at every batch from 125 to 1000 images; conv1, K = 576,
+// only from ~460 images up) and the pooled 21x21 conv (layer 3.0's conv3: -2 ... -5 % from 250 images up) - and slower on the small
+// maps, where the general kernel's 128-row tiles and its two-waves-per-tile form fill the chip better.
 bool conv_wide_preferred(const ConvArgs& a, bool pool) {
     static const int mode = [] { const char* e = getenv("SUBREG_WIDE"); return e && *e ? atoi(e) : -1; }();   // 0 never, 1 always, -1 rule
     if (mode == 0) return false;
     if (!conv_wide_supported(a, pool)) return false;
     if (mode == 1) return true;
-    return false;                                                      // (until the kernel beats conv_fwd.hip on a layer: forced by flag / SUBREG_WIDE=1 only)
+    if (wide_mi() != 2) return false;                                  // (the rule was measured for the 256-row variant)
+    if (a.g.M < 200000) return false;                                  // (not measured below ~115 images of 42x42)
+    if (a.g.W >= 42) return a.Cin >= 160 || a.g.M >= 800000;
+    if (pool && a.g.W == 21) return a.g.M >= 100000;
+    return false;
 }
 
 int conv_wide(const ConvArgs& a, bool pool, hipStream_t stream) {
     if (!conv_wide_supported(a, pool)) return SUBREG_EUNSUPPORTED;
-    return pool ? launch_wide<WIDE_MI, 4, 1, true, AR_POOL>(a, stream) : launch_wide<WIDE_MI, 4, 1, false, AR_LIN>(a, stream);
+    if (wide_mi() == 2) return pool ? launch_wide<2, 4, 1, true, AR_POOL2, 2>(a, stream) : launch_wide<2, 4, 1, false, AR_LIN2, 2>(a, stream);
+    return pool ? launch_wide<3, 4, 1, true, AR_POOL3, 1>(a, stream) : launch_wide<3, 4, 1, false, AR_LIN3, 1>(a, stream);
 }
 
 }  // namespace subreg
