@@ -24,11 +24,19 @@ python3 $R/tools/bench_conv.py --batch 700 --im2col --only L1 2>&1 | $G > $O/con
 python3 $R/tools/bench_conv.py --batch 256 --dtype f32 2>&1 | $G > $O/conv_layers_f32.txt
 # --- round 5: the one-wave-per-SIMD kernel (conv_wide.hip) forced on every wide layer, its in-kernel stamps (library variant built with
 #     -DSUBREG_WIDE_DIAG=3: `make variant NAME=wd3 EXTRA=-DSUBREG_WIDE_DIAG=3` in subspace-reg_amd/), and the probes behind DESIGN 4.3
-python3 $R/tools/bench_conv.py --batch 700 --kernel wide 2>&1 | $G > $O/conv_layers_b700_wide.txt
-if [ -f $R/subspace-reg_amd/subreg_hip/libsubreg_wd3.so ]; then
-  SUBREG_LIB=$R/subspace-reg_amd/subreg_hip/libsubreg_wd3.so python3 $R/tools/diag_conv.py --batch 700 --kernel wide 2>&1 | $G > $O/wide_stamps_b700.txt
-fi
-for p in dma_issue dma_slot mfma_shape; do
+for mi in 2 3; do
+  echo "== SUBREG_WIDE_MI=$mi (2: 256 x 160 tiles, two workgroups per CU; 3: 384 x 160 tiles, one)" >> $O/conv_layers_b700_wide.txt
+  SUBREG_WIDE_MI=$mi python3 $R/tools/bench_conv.py --batch 700 --kernel wide 2>&1 | $G >> $O/conv_layers_b700_wide.txt
+  if [ -f $R/subspace-reg_amd/subreg_hip/libsubreg_wd3.so ]; then
+    echo "== SUBREG_WIDE_MI=$mi" >> $O/wide_stamps_b700.txt
+    SUBREG_WIDE_MI=$mi SUBREG_LIB=$R/subspace-reg_amd/subreg_hip/libsubreg_wd3.so python3 $R/tools/diag_conv.py --batch 700 --kernel wide 2>&1 | $G >> $O/wide_stamps_b700.txt
+  fi
+done
+for v in SUBREG_WIDE=0 SUBREG_WIDE=-1 SUBREG_WIDE=0 SUBREG_WIDE=-1; do
+  echo "== $v  (0: conv_fwd.hip everywhere; -1: the dispatcher's rule)" >> $O/forward_ab_wide_rule.txt
+  env $v python3 $R/tools/bench_forward.py --lanes 2 --batches 250,500,750,1125 2>&1 | $G >> $O/forward_ab_wide_rule.txt
+done
+for p in dma_issue dma_slot mfma_shape mfma_shape_bare mfma_energy; do
   [ -x $R/tools/probes/$p ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-inline-asm $R/tools/probes/$p.hip -o $R/tools/probes/$p
   $R/tools/probes/$p > $O/probe_$p.txt 2>&1
 done
