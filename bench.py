@@ -340,7 +340,19 @@ def pretrain_leg(args):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         tf = B * 24.339e9 / dt / 1e12
-        out["batches"][str(B)] = {"ms_per_step": dt * 1e3, "images_per_s": B / dt,
+        # kernel launches of ONE step, counted live by the profiler's kernel records (library kernels and torch's alike); None when
+        # the profiler is not usable on this box (profiles/r05_train_timeline_two_streams.txt holds the rocprofv3 count)
+        launches = None
+        try:
+            from torch.profiler import profile, ProfilerActivity
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                step()
+                torch.cuda.synchronize()
+            launches = sum(1 for e in prof.events() if str(getattr(e, "device_type", "")).endswith("CUDA")
+                           and "memcpy" not in e.name.lower() and "memset" not in e.name.lower()) or None
+        except Exception:
+            launches = None
+        out["batches"][str(B)] = {"ms_per_step": dt * 1e3, "images_per_s": B / dt, "launches_per_step": launches,
                                   "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                                                "frac": tf / PEAK_TFLOPS[args.dtype]}}
         del net, sgd, x, y

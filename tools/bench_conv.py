@@ -51,7 +51,17 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="conv1 (from the image) and conv2 of layer 1 as two launches")
     ap.add_argument("--kernel", default="auto", choices=["auto", "general", "wide"],
                     help="wide layers (Cout % 160 == 0): the dispatcher's rule, conv_fwd.hip forced, conv_wide.hip forced")
+    ap.add_argument("--data", default="normal", choices=["normal", "zeros", "narrow", "half"],
+                    help="operand values of the general layers (power experiment): N(0, 1) activations and N(0, 1/K) weights; all zeros; "
+                         "the probes' distribution (random sign, magnitude uniform in [1, 2)); normal with a random half of the activations zero")
     a = ap.parse_args()
+
+    def shaped(t):
+        if a.data == "zeros":
+            return torch.zeros_like(t)
+        if a.data == "narrow":
+            return ((torch.rand_like(t.float()) + 1.0) * torch.where(torch.rand_like(t.float()) < 0.5, -1.0, 1.0)).to(t.dtype)
+        return t
     lib = _lib.load()
     dev = torch.device("cuda:0")
     dt = _lib.dtype_code(a.dtype)
@@ -111,8 +121,10 @@ def main():
             tot_f += flops * count
             print("%-24s M=%8d K=%5d N=%4d  %8.1f us  %7.1f TFLOP/s  %5.1f%% of peak" % (name, mrows, kk, Cout, us, tf, 100 * tf / peak))
             continue
-        x = torch.randn(npix, Cin, device=dev).to(td)
-        w = (torch.randn(Cout, k * k, Cin, device=dev) / (Cin * k * k) ** 0.5).to(td)
+        x = shaped(torch.randn(npix, Cin, device=dev).to(td))
+        if a.data == "half":
+            x = x * (torch.rand(npix, Cin, device=dev) < 0.5).to(td)
+        w = shaped((torch.randn(Cout, k * k, Cin, device=dev) / (Cin * k * k) ** 0.5).to(td))
         shift = torch.randn(Cout, device=dev)
         Ho = H // 2 if pool else H
         y = torch.empty(B * Ho * Ho, Cout, device=dev, dtype=td)
@@ -120,8 +132,8 @@ def main():
         c2 = 0
         if cin2 >= 0:
             c2 = Cout if cin2 == 0 else cin2
-            x2 = torch.randn(npix, c2, device=dev).to(td)
-            w2 = (torch.eye(Cout, device=dev) if cin2 == 0 else torch.randn(Cout, c2, device=dev) / c2 ** 0.5).to(td).contiguous()
+            x2 = shaped(torch.randn(npix, c2, device=dev).to(td))
+            w2 = shaped((torch.eye(Cout, device=dev) if cin2 == 0 else torch.randn(Cout, c2, device=dev) / c2 ** 0.5).to(td)).contiguous()
         flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0)
         if Cout % 160 == 0 and a.dtype == "bf16":
             flags |= {"auto": 0, "general": _lib.CONV_KERNEL_GENERAL, "wide": _lib.CONV_KERNEL_WIDE}[a.kernel]
