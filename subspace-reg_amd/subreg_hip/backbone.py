@@ -208,6 +208,7 @@ class HipBackbone:
         self._ws_token += 1
         self._ws = self._col = self._stats = None
         self._train_stash = None
+        self.__dict__.pop("_train_stashes", None)
         for i in range(4):
             self._desc.ws[i] = None
         self._desc.col = self._desc.stats = None

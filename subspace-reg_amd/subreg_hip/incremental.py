@@ -96,9 +96,6 @@ class IncrementalRunner:
         if self.freeze_at < 1:
             raise ValueError("freeze_backbone_at must be >= 1 (the reference's loop counts epochs from 1)")
         self.backbone_frozen = self.freeze_at == 1
-        if not self.backbone_frozen and row_shard is not None and row_shard.size > 1:
-            raise NotImplementedError("freeze_backbone_at > 1 together with a row-sharded seed (the helpers would need the gradient "
-                                      "all-reduce of pretrain.GradientSync inside the session loop)")
         self.lib = _lib.load()
         self.net, self.opt = net, opt
         self.meta_valloader, self.base_val_loader, self.base_support_loader = meta_valloader, base_val_loader, base_support_loader
@@ -330,14 +327,17 @@ class IncrementalRunner:
             #      optimiser goes on applying weight decay and momentum to the backbone after epoch K; that legacy behaviour is
             #      NOT emulated here (it is an artefact of the old default, not something language_eval.py asks for), and the
             #      golden loop_hw32_freeze3.npz does not pin it.
-            from .train import SGD as _BackboneSGD
+            #      --adam: get_optim's Adam(lr, weight_decay=0.0005) (eval/util.py:92-97) - element-wise, so the backbone's own
+            #      Adam beside the fused step's Adam on the classifier is the reference's single optimiser.
+            #      Replay memory (sessions after one that ended before the freeze): the reference forwards the memory batch a second
+            #      time through the network (:252-258) - two gradient-carrying forwards (train mode in epoch 1: two batch-statistics
+            #      passes, two running-stat updates), each with its own stash; their backward passes accumulate.
+            from .train import SGD as _BackboneSGD, Adam as _BackboneAdam
             if getattr(opt, "adam", False):
-                raise NotImplementedError("freeze_backbone_at > 1 with --adam (the backbone's optimiser here is SGD)")
-            if Bm:
-                raise NotImplementedError("a backbone that is still trainable in a session with replay memory (two train-mode "
-                                          "forwards per step share one stash)")
-            opt_bb = _BackboneSGD(trainable, lr=opt.learning_rate, momentum=opt.momentum, weight_decay=opt.weight_decay)
-            dfeat = torch.empty(Bs, D, dtype=torch.float32, device=dev)
+                opt_bb = _BackboneAdam(trainable, lr=opt.learning_rate, weight_decay=0.0005)
+            else:
+                opt_bb = _BackboneSGD(trainable, lr=opt.learning_rate, momentum=opt.momentum, weight_decay=opt.weight_decay)
+            dfeat = torch.empty(Bs + Bm, D, dtype=torch.float32, device=dev)
             while True:
                 st = ses.state.cpu()
                 epoch_next = int(st[0]) + 1
@@ -345,16 +345,32 @@ class IncrementalRunner:
                     break
                 with torch.enable_grad():
                     feat = net.features(sx)                                    # BackboneTrainFn: train mode in epoch 1, eval after
+                    feat_m = net.features(mem_x) if Bm else None
                 feats[:Bs].copy_(feat.detach())
-                self.images_forwarded += Bs
+                if Bm:
+                    feats[Bs:Bs + Bm].copy_(feat_m.detach())
+                self.images_forwarded += Bs + Bm
                 w_used = W.clone()
                 _lib.check(lib.subreg_finetune_step(C.byref(d), s()), "finetune_step")
                 _lib.check(lib.subreg_linear_bwd(_lib.ptr(ses.dlogits), _lib.ptr(feats), _lib.ptr(w_used), None, None, _lib.ptr(dfeat),
-                                                 Bs, N, D, s()), "linear_bwd")
-                feat.backward(dfeat)
+                                                 Bs + Bm, N, D, s()), "linear_bwd")
+                if Bm:
+                    import warnings
+                    with warnings.catch_warnings():     # (the second backward accumulates into the first one's gradients: by design here)
+                        warnings.filterwarnings("ignore", message="subreg_hip: backward.. found existing .grad", category=RuntimeWarning)
+                        torch.autograd.backward([feat, feat_m], [dfeat[:Bs], dfeat[Bs:]])
+                else:
+                    feat.backward(dfeat)
                 opt_bb.step()
                 opt_bb.zero_grad()
                 net.eval()                                                     # validate() flips the mode for good, :19
+                if self.dp is not None:
+                    # a row-sharded seed: every rank of the group made this whole-network step itself, from the same inputs (the
+                    # support set is not sharded).  The weight-gradient kernels sum with float atomics, so two ranks may differ in
+                    # the last bit - and must not, they take the stop decisions together: the leader's network is THE network
+                    # (one flat-buffer broadcast per pre-freeze epoch; the query forwards below are sharded again)
+                    from . import sweep as _sweep
+                    _sweep.broadcast_module(net, self.dp.leader, group=self.dp.group)
                 hb.refresh(force=True)                                         # weights (and in epoch 1 the running statistics) moved
                 self._forward_eval(all_x[Bs + Bm:], out=feats[Bs + Bm:])
                 for i in range(len(hb.nbt)):

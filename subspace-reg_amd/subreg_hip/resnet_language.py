@@ -211,13 +211,26 @@ class ResNet(nn.Module):
             # pretraining path (train_supervised.py:229-244) and whole-network fine-tuning before freeze_backbone_at
             # (eval/language_eval.py:242-295): forward with a stash, backward on the HIP kernels.  In eval mode (the fine-tuning
             # loop after its first validate()) BatchNorm uses and keeps its running statistics and there is no dropout
-            if return_stages:
-                raise NotImplementedError("is_feat=True with a grad-requiring backbone: stage outputs are not kept for the backward")
             from .train import BackboneTrainFn
             names, params = zip(*[(n, p) for n, p in self.named_parameters() if not n.startswith("classifier")])
             feat = BackboneTrainFn.apply(x, hb, self.mask_source if self.training else "eval", names, *params)
             if self.training:
                 torch._foreach_add_([m.num_batches_tracked for m in self._bns], 1)      # one launch, not one per BatchNorm
+            if return_stages:
+                # is_feat=True (models/resnet_language.py:170-192): the block outputs are in the stash (each is the next block's
+                # input for the backward).  They are handed out as COPIES without a grad_fn: the backward of this path starts at
+                # `feat`; a loss on the stage features themselves (the reference's distill/ code, out of scope) gets no gradient
+                if not getattr(self, "_warned_stage_grad", False):
+                    import warnings
+                    self._warned_stage_grad = True
+                    warnings.warn("subreg_hip: is_feat=True with a grad-requiring backbone returns the stage features detached "
+                                  "(gradients flow through the pooled feature / the logits only)", RuntimeWarning, stacklevel=3)
+                B, _, h, w = x.shape
+                stages, stash = [], hb._train_stash
+                for bi, (_n, _ci, cout, stride, _ds, _db) in enumerate(hb.blocks):
+                    h, w = h // stride, w // stride
+                    stages.append(stash.named[(bi, "out")][:B * h * w * cout].view(B, h, w, cout).permute(0, 3, 1, 2).float().contiguous())
+                return feat, stages
             return feat
         hb = self.hip_backbone()
         if not self.training and not return_stages:

@@ -59,6 +59,7 @@ class RowShard:
         self.size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo"   # CPU tests / single-GPU checks
+        self.leader = dist.get_global_rank(group, 0) if (dist.is_initialized() and group is not None) else 0   # global rank of group rank 0
 
     def rows(self, n):
         """(lo, hi, per): this rank forwards rows [lo, hi) of n; every rank's slot in the gathered buffer has `per` rows."""

@@ -31,6 +31,9 @@ class TrainStash:
             self.keep.append(t)
             return t
 
+        # the packed input images (layer1.0's conv1 / shortcut read them in the forward AND for their weight gradients): per stash,
+        # not in the backbone's workspace - a second forward before this one's backward (replay memory) must not overwrite them
+        self.col = buf(B * H * W * 32)
         h, w, cmax, amax, pmax = H, W, 0, B * H * W * 32, 0
         gw_need, gw_down_need, gw_users, grad_slots = 0, 0, [], []
         self.grads = {}                      # state_dict key -> fp32 gradient tensor
@@ -177,6 +180,28 @@ def conv_weight_versions(hb):
     return tuple((hb.params[c + ".weight"].data_ptr(), hb.params[c + ".weight"]._version) for _bi, _slot, c, *_r in hb._convs())
 
 
+def _take_stash(hb, B, H, W):
+    """The stash of one gradient-carrying forward.  A stash is busy from its forward until its backward; a step with two forwards
+    before the backward (support, then replay memory: eval/language_eval.py:252-258) therefore gets two.  At most two per shape and
+    four in all are kept: a forward whose backward never comes (a loss that is only looked at) must not pile stashes up - the least
+    recently used one is then taken over, which is what every forward did before."""
+    pool = hb.__dict__.setdefault("_train_stashes", [])
+    same = [st for st in pool if st.shape == (B, H, W)]
+    stash = next((st for st in same if not st.in_flight), None)
+    if stash is None and len(same) >= 2:
+        stash = min(same, key=lambda st: st.tick)
+    if stash is None:
+        idle = sorted((st for st in pool if not st.in_flight), key=lambda st: st.tick)
+        while len(pool) >= 4 and idle:
+            pool.remove(idle.pop(0))
+        stash = TrainStash(hb, B, H, W)
+        pool.append(stash)
+    hb._stash_tick = getattr(hb, "_stash_tick", 0) + 1
+    stash.tick, stash.in_flight = hb._stash_tick, True
+    hb._train_stash = stash                  # the most recent one (is_feat, tests)
+    return stash
+
+
 class BackboneTrainFn(torch.autograd.Function):
     """feat = backbone(x) with a stash; backward -> gradients of every backbone parameter (`names` order).  masks is a MaskSource /
     None for a TRAIN-mode forward (batch statistics, running-stat update, dropout / DropBlock), or the string "eval" for an
@@ -190,16 +215,16 @@ class BackboneTrainFn(torch.autograd.Function):
         eval_mode = isinstance(masks, str) and masks == "eval"
         for i in range(len(hb.nbt)):             # BasicBlock's own forward counter (resnet_language.py:269: every call, either mode)
             hb.nbt[i] += 1
-        stash = getattr(hb, "_train_stash", None)
-        if stash is None or stash.shape != (B, H, W):
-            stash = TrainStash(hb, B, H, W)
-        hb._train_stash = stash
+        stash = _take_stash(hb, B, H, W)
         hb._ensure_workspace(B, H, W)
         stash.desc.eval_mode = 1 if eval_mode else 0
         if eval_mode:
             hb._clear_masks()
         else:
             hb._prepare_masks(B, H, W, masks)
+        # the keep masks belong to THIS forward: another forward before this one's backward (replay memory) prepares its own
+        stash.mask_state = (list(hb._keep), getattr(hb, "_mask_scale_dev", None), getattr(hb, "_mask_counts", None),
+                            [(hb._blk[bi].keep_mask, hb._blk[bi].mask_scale, hb._blk[bi].mask_scale_dev) for bi in range(len(hb.blocks))])
         # weights moved since the last step: every conv's raw forward copy and dX copy in ONE launch (the eval-mode folded
         # copies are not needed here and are rebuilt by the next eval-mode forward) - unless the optimiser's fused step
         # (SGD.step -> subreg_sgd_pack_train) already wrote them for exactly these weights
@@ -208,8 +233,12 @@ class BackboneTrainFn(torch.autograd.Function):
             _lib.check(hb.lib.subreg_backbone_pack_train(C.byref(hb._desc), C.byref(stash.desc), _lib.stream_ptr()), "backbone_pack_train")
         stash.opt_packed = None
         feat = torch.empty(B, hb.out_dim, dtype=torch.float32, device=x.device)
-        _lib.check(hb.lib.subreg_backbone_forward_stash(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(x), B, H, W,
-                                                        _lib.ptr(feat), _lib.stream_ptr()), "backbone_forward_stash")
+        col_keep, hb._desc.col = hb._desc.col, stash.col.data_ptr()
+        try:
+            _lib.check(hb.lib.subreg_backbone_forward_stash(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(x), B, H, W,
+                                                            _lib.ptr(feat), _lib.stream_ptr()), "backbone_forward_stash")
+        finally:
+            hb._desc.col = col_keep
         hb._fold_versions = None             # running statistics moved
         ctx.hb, ctx.stash, ctx.names, ctx.bhw = hb, stash, names, (B, H, W)
         ctx.param_objs = params              # the Parameter objects themselves: backward assigns their .grad (see there)
@@ -243,19 +272,25 @@ class BackboneTrainFn(torch.autograd.Function):
             raise RuntimeError("subreg_hip: gradient accumulation over several backward passes is not supported together with the "
                                "data-parallel stage hook (the flat gradient buffer is being all-reduced in place): call "
                                "zero_grad() (set_to_none=True) before every backward")
-        if hook is None:
-            _lib.check(hb.lib.subreg_backbone_backward(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(dfeat), B, H, W,
-                                                       _lib.stream_ptr()), "backbone_backward")
-        else:
-            # data parallel: the backward is issued stage by stage (last blocks first); as soon as a stage's launches are queued
-            # its gradient range goes to the hook (pretrain.GradientSync: asynchronous all-reduce on RCCL's stream, which waits
-            # for exactly those launches) while this stream continues with the earlier blocks
-            nb = len(hb.blocks)
-            for first, last in backward_stages(nb):
-                _lib.check(hb.lib.subreg_backbone_backward_blocks(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(dfeat), B, H, W,
-                                                                  first, last, _lib.stream_ptr()), "backbone_backward_blocks")
-                lo, hi = stash.block_ranges[first][0], stash.block_ranges[last][1]
-                hook(stash.flat_grads[lo:hi])
+        for bi, (km, ms, msd) in enumerate(stash.mask_state[3]):
+            hb._blk[bi].keep_mask, hb._blk[bi].mask_scale, hb._blk[bi].mask_scale_dev = km, ms, msd
+        col_keep, hb._desc.col = hb._desc.col, stash.col.data_ptr()
+        try:
+            if hook is None:
+                _lib.check(hb.lib.subreg_backbone_backward(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(dfeat), B, H, W,
+                                                           _lib.stream_ptr()), "backbone_backward")
+            else:
+                # data parallel: the backward is issued stage by stage (last blocks first); as soon as a stage's launches are queued
+                # its gradient range goes to the hook (pretrain.GradientSync: asynchronous all-reduce on RCCL's stream, which waits
+                # for exactly those launches) while this stream continues with the earlier blocks
+                nb = len(hb.blocks)
+                for first, last in backward_stages(nb):
+                    _lib.check(hb.lib.subreg_backbone_backward_blocks(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(dfeat), B, H, W,
+                                                                      first, last, _lib.stream_ptr()), "backbone_backward_blocks")
+                    lo, hi = stash.block_ranges[first][0], stash.block_ranges[last][1]
+                    hook(stash.flat_grads[lo:hi])
+        finally:
+            hb._desc.col = col_keep
         # Every parameter gradient is a view of the stash's ONE flat buffer (valid until the next backward of this model
         # overwrites it, i.e. for the optimiser step that follows).  The views are assigned to `.grad` here, directly:
         # handing them to autograd as return values makes AccumulateGrad copy each of the 66 tensors (a returned view is never
@@ -268,6 +303,7 @@ class BackboneTrainFn(torch.autograd.Function):
             if not p.requires_grad:
                 continue
             p.grad = views[n] if n not in old else old[n] + views[n]   # accumulate like autograd does (out of place)
+        stash.in_flight = False
         return (None, None, None, None) + (None,) * len(ctx.names)
 
 

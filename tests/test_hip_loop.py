@@ -107,7 +107,8 @@ def build_case(g, dtype, embed_dir=None):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("tag", ["hw32_noM", "hw32_M", "hw32_stop", "hw84_M", "hw32_sem", "hw32_map", "hw84_noM_s8", "hw84_noM_disc",
-                                 "hw84_stop", "hw84_sem", "hw84_map", "hw32_adam", "hw32_bias", "hw32_freeze3"])
+                                 "hw84_stop", "hw84_sem", "hw84_map", "hw32_adam", "hw32_bias", "hw32_freeze3",
+                                 "hw32_freeze3_adam", "hw32_freeze5_M"])
 def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
     """hw84_noM_s8 is the bench-scale case (BASELINE.json configs[1]: 8 sessions, -M, 84x84, 1000-image base batch) with 6
     epochs per session, so the per-epoch hipGraph is captured and replayed and up to 1125 images go through one launch
@@ -120,7 +121,10 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
     with the reference's own word vectors.  hw32_adam: `--adam` (eval/util.py:92-97, torch.optim.Adam instead of SGD), +M, 3 sessions.
     hw32_bias: a classifier WITH bias (backbone pretrained without --no_linear_bias), +M, 3 sessions, no --lmbd_reg_novel.
     hw32_freeze3: freeze_backbone_at = 3 (language_eval.py:243, eval/util.py:62-69): epochs 1-2 of the first session fine-tune
-    the WHOLE network (train mode, then eval mode), the backbone freezes at epoch 3; the golden pins what the backbone became."""
+    the WHOLE network (train mode, then eval mode), the backbone freezes at epoch 3; the golden pins what the backbone became.
+    hw32_freeze3_adam: the same under --adam (ONE Adam over net.parameters() steps the backbone too).  hw32_freeze5_M: the backbone
+    never freezes (3 epochs per session, freeze_backbone_at = 5) and sessions 2-3 replay memory: two gradient-carrying forwards per
+    step (support, memory; language_eval.py:252-258), train mode in epoch 1."""
     from subreg_hip.incremental import few_shot_finetune_incremental_test
     g = np.load(os.path.join(GOLDEN, "loop_%s.npz" % tag))
     net, opt, meta, base_loader, bsl, inits, picks = build_case(g, dtype, str(tmp_path / "word_embeds"))
@@ -206,19 +210,28 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
             moved = float(np.linalg.norm((got - sd0[name]).astype(np.float64)))
             want_moved = float(g[k])
             assert want_moved > 0
-            assert abs(moved - want_moved) <= (2e-3 if f32 else 0.25) * want_moved, (name, moved, want_moved)
+            many_steps = tag in ("hw32_freeze3_adam", "hw32_freeze5_M")         # (see `loose` below)
+            assert abs(moved - want_moved) <= ((1e-2 if many_steps else 2e-3) if f32 else 0.25) * want_moved, (name, moved, want_moved)
             want = g["final." + name]
             # f32: element-wise on the update itself (the weights moved by ~1e-5 per element: compare the DIFFERENCE to the start)
             d_got, d_want = (got[:want.shape[0]] - sd0[name][:want.shape[0]]).astype(np.float64), (want - sd0[name][:want.shape[0]]).astype(np.float64)
             l2 = float(np.linalg.norm(d_got - d_want) / max(np.linalg.norm(d_want), 1e-30))
-            assert l2 < (1e-2 if f32 else 0.5), ("backbone update", name, l2)
+            # hw32_freeze3 (two SGD steps): 1e-2.  Adam moves an element whose gradient is within rounding noise of zero by +-lr
+            # either way, and hw32_freeze5_M makes nine whole-network steps over three sessions, each fed by the previous one's
+            # LeakyReLU / MaxPool decisions: measured 2.6e-2 / 2.7e-2 on layer1.0.conv1.weight in f32 with every loss within 7e-6
+            # of the reference's (the joint two-forward backward itself is pinned at 2e-5 by test_hip_train.py)
+            loose = tag in ("hw32_freeze3_adam", "hw32_freeze5_M")
+            assert l2 < ((5e-2 if loose else 1e-2) if f32 else (0.7 if loose else 0.5)), ("backbone update", name, l2)
     if f32:
         _cmp("novel avg", novel_avg, g["novel_avg"], 1e-5, 1e-6)
         _cmp("base avg", base_avg, g["base_avg"], 1e-5, 1e-6)
         sd = net.state_dict()
+        # (running statistics taken over a backbone that was itself trained for several steps: the weights' 1e-2 relative update
+        #  noise shows up as a few 1e-5 on the deepest layer's means)
+        st_atol = 1e-4 if tag in ("hw32_freeze3_adam", "hw32_freeze5_M") else 1e-5
         for k in ("layer1.0.bn1", "layer4.1.bn3"):
-            _cmp(k + ".running_mean", sd[k + ".running_mean"].cpu().numpy(), g[k + ".running_mean"], 1e-5, 1e-4)
-            _cmp(k + ".running_var", sd[k + ".running_var"].cpu().numpy(), g[k + ".running_var"], 1e-5, 1e-4)
+            _cmp(k + ".running_mean", sd[k + ".running_mean"].cpu().numpy(), g[k + ".running_mean"], st_atol, 1e-4)
+            _cmp(k + ".running_var", sd[k + ".running_var"].cpu().numpy(), g[k + ".running_var"], st_atol, 1e-4)
     else:
         _cmp("novel avg", novel_avg, g["novel_avg"], (2 if not data_dependent_stop else 3) * one_image, 0)
         _cmp("base avg", base_avg, g["base_avg"],                                                       # <= 1 base image / 0.5 pt

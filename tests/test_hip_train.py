@@ -713,3 +713,65 @@ def test_eval_mode_backbone_gradients_against_oracle(dtype):
     with torch.no_grad():
         ref_logits = net(torch.from_numpy(x).cuda())
     _cmp("logits", logits.detach().cpu().numpy(), ref_logits.cpu().numpy(), 1e-4 if f32 else 5e-2, 1e-4 if f32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_is_feat_with_a_trainable_backbone_returns_the_stage_features(dtype):
+    """forward(x, is_feat=True) (models/resnet_language.py:170-192) while the backbone requires gradients: the four stage outputs
+    come from the stash of the gradient-carrying forward (detached copies, announced once by a RuntimeWarning), the logits still
+    back-propagate into every parameter.  Model in eval mode, so the no-grad eval forward is the comparison."""
+    import warnings
+    net = _train_net(dtype).eval()
+    x = torch.from_numpy(syn.make_images(93, 4, 32)).cuda()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        feats, logits = net(x, is_feat=True)
+    assert any("detached" in str(w.message) for w in rec)
+    with torch.no_grad():
+        feats_ref, logits_ref = net(x, is_feat=True)
+    f32 = dtype == "f32"
+    assert len(feats) == len(feats_ref) == 5
+    for i, (a_, b_) in enumerate(zip(feats, feats_ref)):
+        assert a_.shape == b_.shape and (i == 4 or not a_.requires_grad)
+        scale = max(1.0, float(b_.abs().max()))
+        _cmp("stage %d" % i, a_.detach().cpu().numpy(), b_.cpu().numpy(), (2e-4 if f32 else 6e-2) * scale, 2e-4 if f32 else 3e-2)
+    _cmp("logits", logits.detach().cpu().numpy(), logits_ref.cpu().numpy(), 1e-4 if f32 else 5e-2, 1e-4 if f32 else 2e-2)
+    logits.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_two_forwards_before_the_backward_keep_their_own_stash_masks_and_input(mode):
+    """eval/language_eval.py:252-258 with a trainable backbone and replay memory: net(support) and net(memory) both run BEFORE
+    loss.backward().  Each forward owns its stash, its keep masks and its packed input; the gradients of the joint backward must
+    equal the sum of two separate forward -> backward rounds over the same batches and masks (same batch sizes on purpose: the
+    case in which the second forward used to overwrite the first one's stash)."""
+    import warnings
+    xa = torch.from_numpy(syn.make_images(75, 6, 32)).cuda()
+    xb = torch.from_numpy(syn.make_images(76, 6, 32)).cuda()
+    ga = torch.from_numpy(np.random.RandomState(77).randn(6, 60).astype(np.float32)).cuda()
+    gb = torch.from_numpy(np.random.RandomState(78).randn(6, 60).astype(np.float32)).cuda()
+
+    def make():
+        net = _train_net("f32")
+        net.mask_source = MaskSource(74)
+        return net.train() if mode == "train" else net.eval()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        net = make()                                              # joint: A, B, then both backward passes
+        oa, ob = net(xa), net(xb)
+        assert net.hip_backbone()._train_stashes[0] is not net.hip_backbone()._train_stashes[1]
+        torch.autograd.backward([oa, ob], [ga, gb])
+        joint = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+        stats = {k: v.clone() for k, v in net.state_dict().items() if "running" in k}
+        ref = make()                                              # sequential: A forward + backward, then B (accumulating)
+        ref(xa).backward(ga)
+        ref(xb).backward(gb)
+    for n, p in ref.named_parameters():
+        a, b = joint[n].double().flatten(), p.grad.double().flatten()
+        l2 = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        assert l2 < 2e-5, (n, l2)                                 # (dW sums are atomic: not bit-identical)
+    for k, v in ref.state_dict().items():
+        if "running" in k:
+            assert torch.allclose(stats[k], v, rtol=1e-6, atol=1e-7), k

@@ -216,6 +216,22 @@ def test_row_sharded_sweep_path_two_ranks_on_device():
 
 
 @pytest.mark.gpu
+def test_row_sharded_seed_with_pre_freeze_epochs_two_ranks_on_device():
+    """freeze_backbone_at = 3 on a row-sharded seed (eval/language_eval.py:242-295, eval/util.py:62-69): the two whole-network
+    epochs run on both ranks, the leader's network is re-broadcast after each step (one flat buffer), the query forwards stay
+    sharded.  Against the single-process run: same epochs and accuracies, losses and classifier rows within 1e-4 (the
+    weight-gradient kernels' float atomics make that run itself not bit-reproducible)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(repo, "tools", "dp_check.py"), "hw32_freeze3"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "single-process run: True" in p.stdout
+
+
+@pytest.mark.gpu
 def test_pretrain_gradient_sync_two_ranks_on_device():
     """BASELINE.json configs[4], 'data-parallel RCCL allreduce': pretrain.GradientSync with TWO processes on the device
     (tools/dp_pretrain_check.py) - uneven shards 4 + 3 of a global batch, loss pre-scaled by n_local / n_global, the staged

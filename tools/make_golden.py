@@ -609,6 +609,17 @@ def main():
         # freeze_backbone_at = 3 (language_eval.py:243-249, eval/util.py:62-69): epochs 1-2 of the first session fine-tune the WHOLE
         # network (epoch 1 in train mode, epoch 2 in eval mode: validate() leaves the model there), the backbone freezes at epoch 3
         gen_loop("hw32_freeze3", 32, 2, False, 40, seed=15, max_novel_epochs=6, freeze_backbone_at=3)
+    if "freeze_opts" in what:
+        # the same with --adam: get_optim's ONE torch.optim.Adam(lr, weight_decay=0.0005) over net.parameters() (eval/util.py:92-97)
+        # also steps the backbone in epochs 1-2.  lr 2e-5: Adam moves EVERY element by ~lr per step whatever its gradient; at the
+        # loop's default 0.002 the backbone of this random-weight fixture is destroyed in one step (loss 6.5 -> 35 -> 340) and the run
+        # pins nothing but chaos
+        gen_loop("hw32_freeze3_adam", 32, 2, False, 40, seed=17, max_novel_epochs=6, freeze_backbone_at=3, adam=True, learning_rate=2e-5)
+        # a backbone that NEVER freezes (every session ends at epoch 3 < freeze_backbone_at = 5) with replay memory: from session 2
+        # on every step makes TWO gradient-carrying forwards (support, then memory: language_eval.py:252-258), train mode in epoch 1
+        # lr 2e-4: at the loop's default 0.002 whole-network SGD on this random-weight fixture amplifies a 1e-7 difference tenfold per
+        # step (loss 5.7 -> 4.1 in two steps), and by session 3 two correct fp32 implementations differ by 1e-3
+        gen_loop("hw32_freeze5_M", 32, 3, True, 40, seed=18, max_novel_epochs=3, freeze_backbone_at=5, learning_rate=2e-4)
     if "bias" in what:
         # classifier WITH bias (a backbone pretrained without --no_linear_bias; eval_incremental.py:96-103 reads it off the
         # checkpoint), +M, three sessions.  --lmbd_reg_novel must be absent: with a bias the reference's reglossnovel
