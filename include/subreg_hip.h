@@ -42,7 +42,9 @@ extern "C" {
 #define SUBREG_CONV_POOL2 2     /* nn.MaxPool2d(2) floor mode, :256,290 */
 #define SUBREG_CONV_RAW_STATS 4 /* train mode: raw conv output + per-channel (sum,sumsq) partials */
 /* kernel selection of subreg_conv_fwd for Cout % 160 == 0 (default: a measured rule): force the general kernel (conv_fwd.hip) or the
- * one-wave-per-SIMD kernel (conv_wide.hip; SUBREG_EUNSUPPORTED where it does not take the problem).  Parity tests and A/B runs. */
+ * one-wave-per-SIMD kernel (conv_wide.hip; SUBREG_EUNSUPPORTED where it does not take the problem).  Parity tests and A/B runs.
+ * subreg_conv12_first_fused takes the same two flags: the 8-wave kernel (the default) or the one-wave-per-SIMD one
+ * (conv64_resident.hip::conv64_fused_first_kernel / conv64_wide_fused_kernel). */
 #define SUBREG_CONV_KERNEL_GENERAL 256
 #define SUBREG_CONV_KERNEL_WIDE 512
 

@@ -58,6 +58,10 @@ namespace subreg {
 #define R64_CUT 0       // conv64_fused_first_kernel, timing experiments only (WRONG results): leave one component out -
                         // 1 conv2's MFMAs, 2 conv2's A-fragment reads, 3 conv1, 4 the epilogue, 5 image DMA + patch conversion
 #endif
+#ifndef R64WF_CUT
+#define R64WF_CUT 0     // conv64_wide_fused_kernel, timing experiments only (WRONG results): 1 no conv1 fillers, 2 no row-tile epilogue fillers, 3 no roll copy,
+                        // 4 no conv1 MFMAs (reads, LeakyReLU and stores stay), 5 no conv1 LeakyReLU / stores (reads and MFMAs stay)
+#endif
 #ifndef R64_DIAG
 #define R64_DIAG 0      // 1: per-wave s_memtime stamps of the tile loop's phases into r64_diag (measurement builds only)
 #endif
@@ -1470,6 +1474,457 @@ __global__ __launch_bounds__(256, 1) void conv64_wide_kernel(const Conv64Args a)
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// conv1 -> conv2 of layer1.0 with ONE wave per SIMD: conv64_wide_kernel's filler structure with conv64_fused_first_kernel's
+// data flow.  The 8-wave fused kernel spends 36 % of a tile with the matrix pipe idle: a conv1 wave beside a partner in its
+// conv2 chunks gets neither the matrix pipe nor the VALU port (profiles/r04_l1_fused_stamps.txt).  Here a wave's conv1 work for the
+// NEXT tile is a filler between its own conv2 MFMAs: per half-phase (72 + 2 MFMAs of one 32-row tile) one 32-pixel group of
+// conv1 - 6 pixel-fragment reads (ds_read_b64 from the bf16 patch), 6 weight-fragment reads, 6 MFMAs in two half-groups, 16
+// LeakyReLU pairs, 8 ds_write_b64 into the next tile's planes - beside the LDS-free epilogue of the row tile finished a phase
+// earlier.  conv1's accumulators (2 x 16 registers) take the registers the pending row tile's epilogue has just freed.
+// All filler LDS operations are asm statements counted into the fragment ring's hand-made lgkmcnt waits (fill_lds below);
+// a filler read issued in slot r is complete after the ring wait of slot r + RD (LDS returns in order).
+// Tiles: contiguous ranges per workgroup (rolling conv1: 3 new image rows per tile, the two shared rows copied from the tile
+// above); the first tile of an image computes its two extra rows in a plain loop.
+constexpr int R64_WF_LDS = 4 * (5 * R64_P * R64_ROWB) + 7 * 1024 + 2 * 7 * (96 + 4) * 8 + 6 * 64 * 16 + (4096 + 256) + 2048;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_read8(unsigned lds_addr) {
+    u32x2 d;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(lds_addr), "n"(OFF));
+    return d;
+}
+__device__ __forceinline__ void lds_write8(unsigned lds_addr, unsigned lo, unsigned hi) {
+    const u32x2 v = {lo, hi};
+    asm volatile("ds_write_b64 %0, %1" : : "v"(lds_addr), "v"(v) : "memory");
+}
+// filler LDS operations of slot f of a half-phase (conv64_wide_fused_kernel's schedule: one per slot at most)
+__host__ __device__ constexpr int r64wf_fill_lds(int f) {
+    return ((f >= 0 && f < 12) || (f >= 19 && f < 35 && ((f - 19) & 1) == 0) ? 1 : 0) + (f >= 28 && f < 34 && ((f - 28) & 1) == 0 ? 1 : 0);
+}
+__host__ __device__ constexpr int r64wf_fill_window(int f, int rd) {
+    int n = 0;
+    for (int j = f - rd + 1; j <= f; ++j) n += r64wf_fill_lds(j);
+    return n;
+}
+
+template <bool ACT>
+__global__ __launch_bounds__(256, 1) void conv64_wide_fused_kernel(const Conv64FusedArgs a) {
+    constexpr int P = R64_P, BLOCKS = 5, PROWS = BLOCKS * P, PLANE = PROWS * R64_ROWB, NW = 4;
+    constexpr int XROWS = BLOCKS + 2;
+    constexpr int XF_BASE = 4 * PLANE, XF_BYTES = XROWS * 1024;
+    constexpr int X4_BASE = XF_BASE + XF_BYTES, X4_ROW = (96 + 4) * 8, X4_BUF = XROWS * X4_ROW, X4_BYTES = 2 * X4_BUF;
+    constexpr int WF_BASE = X4_BASE + X4_BYTES, WF_BYTES = 6 * 64 * 16;
+    constexpr int SCR_BASE = WF_BASE + WF_BYTES, SCR_BYTES = 4096 + 256;      // set-up scratch; afterwards the dump for the stores of pixels beyond the tile
+    constexpr int ZR_BASE = SCR_BASE + SCR_BYTES, ZR_BYTES = 2048;          // zeros: what conv1 reads for a row outside the image (its output is then LeakyReLU(0) = 0: conv2's padding)
+    static_assert(ZR_BASE + ZR_BYTES == R64_WF_LDS && R64_WF_LDS <= 160 * 1024 && 2 * X4_ROW + 16 + 8 <= ZR_BYTES, "LDS budget");
+    static_assert(PLANE + 2 * P * R64_ROWB < 65536 && 5 * 1024 + 1024 < 65536, "immediate offsets");
+    constexpr int RD = 8, NF = 36;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int W = a.W, W4 = W >> 2;
+
+    const int nwg = gridDim.x;
+    const int per = a.ntiles / nwg, extra = a.ntiles - per * nwg;
+    const int t_begin = blockIdx.x * per + min((int)blockIdx.x, extra), t_end = t_begin + per + ((int)blockIdx.x < extra ? 1 : 0);
+    if (t_begin >= t_end) return;
+
+    // ---- conv2's resident weights (conv64_wide_kernel)
+    constexpr int NWA = 48;
+    u32x4 bw[72];
+    static_for<0, 3>([&](auto bc) {
+        constexpr int b0 = decltype(bc)::value * 24;
+        static_for<b0, b0 + 24>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value, h = idx & 1, s = (idx >> 1) & 1, t = (idx >> 2) % 9, c = idx / 36;
+            bw[idx] = *reinterpret_cast<const u32x4*>(a.w + (size_t)(32 * h + lr) * R64_ROWB + lh * 16 + (size_t)((t * 2 + c) * 64) * R64_ROWB + s * 32);
+        });
+        static_for<b0, b0 + 24>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value;
+            if constexpr (idx < NWA) {
+                u32x4 v = bw[idx];
+                asm volatile("" : "+a"(v));
+                bw[idx] = v;
+            }
+        });
+    });
+    u32x4 bias_a[2], ones_b;
+    {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float sh = a.shift[32 * h + lr];
+            const __bf16 hi = (__bf16)sh, lo = (__bf16)(sh - (float)hi);
+            const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+            bias_a[h] = u32x4{lh == 0 ? pk : 0u, 0u, 0u, 0u};
+        }
+        ones_b = u32x4{lh == 0 ? 0x3f803f80u : 0u, 0u, 0u, 0u};
+    }
+    // ---- LDS: planes and fp32 patch zero; bf16 patch = (0, 0, 0, 1) everywhere; conv1's A fragments (conv64_fused_first_kernel)
+    for (int o = tid * 16; o < X4_BASE; o += NW * 64 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
+    for (int o = tid * 8; o < X4_BYTES; o += NW * 64 * 8) *reinterpret_cast<uint2*>(smem + X4_BASE + o) = make_uint2(0u, 0x3F800000u);
+    {
+        __bf16* const wl = reinterpret_cast<__bf16*>(smem + SCR_BASE);
+        float* const sh1 = reinterpret_cast<float*>(smem + SCR_BASE + 4096);
+        reinterpret_cast<uint4*>(wl)[tid] = reinterpret_cast<const uint4*>(a.w1)[tid];
+        if (tid < 64) sh1[tid] = a.shift1[tid];
+        __syncthreads();
+        for (int fi = wid; fi < 6; fi += NW) {
+            const int i = fi / 3, s = fi % 3;
+            const float shv = sh1[32 * i + lr];
+            const __bf16 sh_hi = (__bf16)shv, sh_lo = (__bf16)(shv - (float)sh_hi);
+            unsigned short e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int tap = 4 * s + 2 * lh + (j >> 2), c = j & 3;
+                const bool ok = c < 3 && tap < 9;
+                const unsigned short v = __builtin_bit_cast(unsigned short, wl[(32 * i + lr) * 32 + (ok ? 3 * tap + c : 0)]);
+                e[j] = ok ? v : (unsigned short)0;
+                if (c == 3 && tap == 4) e[j] = __builtin_bit_cast(unsigned short, sh_hi);
+                if (c == 3 && tap == 3) e[j] = __builtin_bit_cast(unsigned short, sh_lo);
+            }
+            *reinterpret_cast<uint4*>(smem + WF_BASE + (fi * 64 + lane) * 16) =
+                make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16));
+        }
+    }
+    for (int o = tid * 8; o < ZR_BYTES; o += NW * 64 * 8) *reinterpret_cast<uint2*>(smem + ZR_BASE + o) = make_uint2(0u, 0u);
+    __syncthreads();
+
+    struct Geom { int b, k_img; };
+    auto tile_geom = [&](int t, Geom& g) {
+        const int bb = (int)fdiv((unsigned)t, a.d_tpi);
+        g.b = __builtin_amdgcn_readfirstlane(bb);
+        g.k_img = __builtin_amdgcn_readfirstlane(t - bb * a.tpi);
+    };
+    // ---- fp32 patch rows by LDS-DMA (wave w: rows w and w + 4), converted by the wave that fetched them
+    int vm_issued = 0;
+    const size_t plane_px = (size_t)a.H * W;
+    // lane l brings floats 4 l .. 4 l + 3 of a row's [c][x] block (3 W floats; the lanes beyond it repeat the last one: never converted)
+    const int dq_f = 4 * lane < 3 * W ? 4 * lane : 3 * W - 4, dq_c = dq_f / W, dq_x = dq_f - dq_c * W;
+    const unsigned dq_voff = (unsigned)(((size_t)dq_c * plane_px + (size_t)dq_x) * 4);                  // < 3 H W floats
+    const unsigned zq_voff = (unsigned)(lane & 7) * 16u;
+    auto dma_patch = [&](const Geom& g) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = wid + NW * rr;
+            if (r < XROWS) {
+                const int h = a.R * g.k_img - 2 + r;                     // wave-uniform
+                const bool ok = h >= 0 && h < a.H;
+                const char* base = ok ? reinterpret_cast<const char*>(a.img + ((size_t)g.b * 3 * plane_px + (size_t)h * W))
+                                      : reinterpret_cast<const char*>(r64_zero_line);
+                dma16(base, ok ? dq_voff : zq_voff, lds_base + XF_BASE + r * 1024);
+                ++vm_issued;
+            }
+        }
+    };
+    auto convert_rows = [&](int buf) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = wid + NW * rr;
+            if (r < XROWS && lane < W4) {
+                const char* const xr = smem + XF_BASE + r * 1024;
+                const float4 v0 = *reinterpret_cast<const float4*>(xr + (0 * W + 4 * lane) * 4);
+                const float4 v1 = *reinterpret_cast<const float4*>(xr + (1 * W + 4 * lane) * 4);
+                const float4 v2 = *reinterpret_cast<const float4*>(xr + (2 * W + 4 * lane) * 4);
+                const unsigned one = 0x3F800000u;
+                uint4* dst = reinterpret_cast<uint4*>(smem + X4_BASE + buf * X4_BUF + r * X4_ROW + (4 * lane + 2) * 8);
+                dst[0] = make_uint4(r64_pack(v0.x, v1.x), (r64_pack(v2.x, 0.f) & 0xffffu) | one, r64_pack(v0.y, v1.y), (r64_pack(v2.y, 0.f) & 0xffffu) | one);
+                dst[1] = make_uint4(r64_pack(v0.z, v1.z), (r64_pack(v2.z, 0.f) & 0xffffu) | one, r64_pack(v0.w, v1.w), (r64_pack(v2.w, 0.f) & 0xffffu) | one);
+            }
+        }
+    };
+    // ---- conv1, plain form (prologue; blocks 0-1 of a tile that starts an image): 32-pixel groups of blocks rb0 .. rb0 + nblk - 1
+    int toff[3][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int tap = 4 * s + 2 * lh + u;
+            tap = tap < 9 ? tap : 8;
+            toff[s][u] = (tap / 3) * X4_ROW + (tap % 3) * 8;
+        }
+    auto lrelu_pk = [&](float x0, float x1) -> unsigned {
+        float y0, y1;
+        asm("v_max_f32 %0, %1, %2" : "=v"(y0) : "v"(x0), "v"(x0 * 0.1f));
+        asm("v_max_f32 %0, %1, %2" : "=v"(y1) : "v"(x1), "v"(x1 * 0.1f));
+        return r64_pack(y0, y1);
+    };
+    // (acc1: two accumulators that are FREE where this runs - between tiles the row tile 0 pair; a fresh pair would make hipcc park the
+    //  pending row tile 1 in VGPRs at every loop head)
+    auto conv1_plain = [&](int k_img, int pp, int buf, int rb0, int nblk, f32x16 (&acc1)[2]) {
+        const int npx = nblk * W;
+        for (int g0 = wid * 32; g0 < npx; g0 += NW * 32) {
+            const int p = g0 + lr;
+            const bool valid = p < npx;
+            const int rbl = valid ? (int)fdiv((unsigned)p, a.d_w) : 0, x = valid ? p - rbl * W : 0, rb = rb0 + rbl;
+            const int h = a.R * k_img - 1 + rb;
+            const bool inside = h >= 0 && h < a.H;
+            const char* const base = smem + X4_BASE + buf * X4_BUF + rb * X4_ROW + (x + 1) * 8;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const uint2 t0 = *reinterpret_cast<const uint2*>(base + toff[s][0]);
+                const uint2 t1 = *reinterpret_cast<const uint2*>(base + toff[s][1]);
+                const uint4 xf = make_uint4(t0.x, t0.y, t1.x, t1.y);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const uint4 wfr = *reinterpret_cast<const uint4*>(smem + WF_BASE + ((i * 3 + s) * 64 + lane) * 16);
+                    acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfr), __builtin_bit_cast(bf16x8, xf), acc1[i], 0, 0, 0);
+                }
+            }
+            const int row = rb * P + 1 + x;
+            const unsigned rbase = (unsigned)row * R64_ROWB + 8u * lh;
+            const int sw = swz<4>(row);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned d0 = lrelu_pk(acc1[i][4 * q], acc1[i][4 * q + 1]), d1 = lrelu_pk(acc1[i][4 * q + 2], acc1[i][4 * q + 3]);
+                    d0 = inside ? d0 : 0u; d1 = inside ? d1 : 0u;
+                    if (valid) *reinterpret_cast<uint2*>(smem + (2 * pp + i) * PLANE + rbase + 16u * (unsigned)(q ^ sw)) = make_uint2(d0, d1);
+                }
+        }
+    };
+    // ---- conv1, filler form: this wave's two groups of blocks 2 .. 4 (group wid in phase 0, wid + 4 in phase 1); everything that does
+    //      not depend on the tile is computed here
+    unsigned c1_src[2], c1_dst[2];
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        const int p = 32 * (wid + NW * gi) + lr;
+        const bool valid = p < 3 * W;
+        const int rbl = valid ? (int)fdiv((unsigned)p, a.d_w) : 0, x = valid ? p - rbl * W : 0, rb = 2 + rbl;
+        const int row = rb * P + 1 + x;
+        c1_src[gi] = lds_base + X4_BASE + (unsigned)(rb * X4_ROW + (x + 1) * 8) + ((unsigned)rb << 27);     // (block index rb in bits 27..29: see c1_keep)
+        // stores: slot q of the row goes to byte 16 (q ^ swz(row)); pixels beyond the tile write into the dump
+        c1_dst[gi] = valid ? (unsigned)row * R64_ROWB + 8u * lh + 16u * (unsigned)swz<4>(row) : 0x80000000u + (unsigned)lane * 64u + 8u * lh;
+    }
+    const unsigned wf_addr = lds_base + WF_BASE + (unsigned)lane * 16u;
+    // roll copy: 2 planes x 2 blocks = 1536 slots of 16 bytes, six per thread (three per half-phase): offsets inside a plane pair
+    unsigned cp_off[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        constexpr int SPAN = 2 * P * R64_ROWB;
+        const int o = (tid + k * NW * 64) * 16, c = o >= SPAN ? 1 : 0;
+        cp_off[k] = (unsigned)(c * PLANE + (o - c * SPAN));
+    }
+
+    // ---- conv2's per-lane A addresses (conv64_wide_kernel)
+    unsigned areg[2][3][2];
+    int a_set = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = wid * 64 + i * 32 + lr, jv = j < a.R * W ? j : 0;
+        const int ir = (int)fdiv((unsigned)jv, a.d_w), w = jv - ir * W;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int row = ir * P + w + dx;
+            const unsigned ad = lds_base + (unsigned)row * R64_ROWB + 16u * (lh ^ swz<4>(row));
+            areg[i][dx][0] = ad;
+            areg[i][dx][1] = ad ^ 32u;
+        }
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[1][h][r] = 0.f;
+    struct Pend { char* y; int nv; };
+    auto lrelu1 = [&](float x) {
+        if (!ACT) return x;
+        float y;
+        asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(x * 0.1f));
+        return y;
+    };
+    float ex[8];
+    unsigned epk[4];
+    const unsigned st_lane = (unsigned)lr * 128u + (unsigned)lh * 16u;
+    auto epi_step = [&](auto oc, auto vc, const Pend& pe) {
+        constexpr int O = decltype(oc)::value, v = decltype(vc)::value, h = v >> 4, r = v & 15, e = r & 7;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        // ONE v_accvgpr_read per value (left alone hipcc reads it again for the max).  The compiler hoists the 32 reads of a pending row
+        // tile to the loop head; pinning them to their slots (asm volatile v_accvgpr_read) costs more: phases 3.9 k cycles against 3.5 k
+        float xv = acc[O][h][r];
+        asm("" : "+v"(xv));
+        ex[e] = lrelu1(xv);
+        if constexpr (e & 1) epk[e >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ex[e - 1], ex[e]}, bf16x2));
+        if constexpr (e == 7) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(epk[0], epk[2], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(epk[1], epk[3], false, false);
+            const u32x4 vec = {s0[0], s1[0], s0[1], s1[1]};
+            if (pe.nv > 0) {
+                if (lr < pe.nv) *reinterpret_cast<u32x4*>(pe.y + (h * 64 + (r >> 3) * 32) + st_lane) = vec;
+                ++vm_issued;
+            }
+        }
+    };
+
+    // per-tile values of the conv1 fillers: byte offset of the next tile's bf16 patch buffer, its plane pair's base, and per group the
+    // mask that zeroes rows outside the image (conv2's zero padding is NOT conv1 of zeros)
+    struct C1Tile { unsigned psrc[2], pbase, dump, cp_src, cp_dst; };
+    // one half-phase: row tile I over all of K from the plane pair at areg | fillers: the pending row tile's epilogue (two registers per
+    // slot, slots 0-15), conv1 group I of the next tile (reads slots 0-11, MFMAs slots 14-19, LeakyReLU + stores slots 19-34)
+    auto phase = [&](auto ic, const Pend& pe, const C1Tile& c1) {
+        constexpr int I = decltype(ic)::value, O = 1 - I;
+        u32x4 ring[RD];
+        auto rd = [&](auto jc) {
+            constexpr int j = decltype(jc)::value, c = j / 18, tt = (j % 18) >> 1, s = j & 1, dy = tt / 3, dx = tt % 3;
+            ring[j % RD] = lds_read16<c * PLANE + dy * P * R64_ROWB>(areg[I][dx][s]);
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        static_for<0, RD - 1>(rd);
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[I][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bias_a[0]), __builtin_bit_cast(bf16x8, ones_b), zero16, 0, 0, 0);
+        acc[I][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bias_a[1]), __builtin_bit_cast(bf16x8, ones_b), zero16, 0, 0, 0);
+        u32x2 px[6];
+        u32x4 wf[6];
+        // conv1's accumulators ARE the pending row tile's: acc[O][i] is free once its epilogue steps (slots 8 i .. 8 i + 7) have read it, and
+        // is given back (everything stored) before the next half-phase starts accumulating into it
+        f32x16 (&c1a)[2] = acc[O];
+        if (R64WF_CUT == 4) { c1a[0] = zero16; c1a[1] = zero16; }
+        u32x4 cp[3];                                                   // roll copy: three 16-byte slots per thread and half-phase
+        const unsigned psrc = c1.psrc[I];
+        const bool dumped = (c1_dst[I] & 0x80000000u) != 0;
+        unsigned pdst[2];
+        pdst[0] = dumped ? c1.dump + (c1_dst[I] & 0x7fffffffu) : c1.pbase + c1_dst[I];
+        pdst[1] = pdst[0] + (dumped ? 0u : (unsigned)PLANE);           // channel chunk 1 lives one plane further on
+        static_for<0, NF>([&](auto fc) {
+            constexpr int f = decltype(fc)::value, c = f / 18, tt = (f % 18) >> 1, s = f & 1;
+            if constexpr (f + RD - 1 < NF) rd(std::integral_constant<int, f + RD - 1>{});
+            // ---- fillers (LDS operations: exactly r64wf_fill_lds(f) of them, before the ring wait)
+            if constexpr (f < 16 && R64WF_CUT != 2) {
+                epi_step(std::integral_constant<int, O>{}, std::integral_constant<int, 2 * f>{}, pe);
+                epi_step(std::integral_constant<int, O>{}, std::integral_constant<int, 2 * f + 1>{}, pe);
+            }
+            if constexpr (f < 6) px[f] = lds_read8<0>(psrc + (unsigned)toff[f >> 1][f & 1]);
+            if constexpr (f >= 6 && f < 12) wf[f - 6] = lds_read16<(f - 6) * 1024>(wf_addr);
+            if constexpr (f >= 19 && f < 35 && ((f - 19) & 1) == 0 && R64WF_CUT != 1 && R64WF_CUT != 5) {
+                constexpr int e = (f - 19) >> 1, i = e >> 2, q = e & 3;
+                float v0 = c1a[i][4 * q], v1 = c1a[i][4 * q + 1], v2 = c1a[i][4 * q + 2], v3 = c1a[i][4 * q + 3];
+                asm("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+                const unsigned d0 = lrelu_pk(v0, v1), d1 = lrelu_pk(v2, v3);
+                lds_write8(pdst[i] ^ (16u * q), d0, d1);
+            }
+            if constexpr (f >= 28 && f < 34 && ((f - 28) & 1) == 0 && R64WF_CUT != 3) cp[(f - 28) >> 1] = lds_read16<0>(cp_off[I * 3 + ((f - 28) >> 1)] + c1.cp_src);
+            // ---- fragment f
+            constexpr int ring_younger = NF - 1 - f < RD - 1 ? NF - 1 - f : RD - 1;
+            constexpr int younger = ring_younger + r64wf_fill_window(f, RD);
+            static_assert(younger <= 15, "lgkmcnt is a 4-bit counter");
+            u32x4 fr = ring[f % RD];
+            fr = lds_wait<younger>(fr);
+            if constexpr (f >= 14 && f < 20 && R64WF_CUT != 1 && R64WF_CUT != 4) {   // conv1 MFMA (i, s): its operands were read >= RD slots ago
+                constexpr int m = f - 14, i = m / 3, sx = m % 3;
+                u32x4 xf = {px[2 * sx][0], px[2 * sx][1], px[2 * sx + 1][0], px[2 * sx + 1][1]};
+                u32x4 wv = wf[i * 3 + sx];
+                asm volatile("" : "+v"(xf), "+v"(wv));
+                if constexpr (sx == 0) c1a[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, xf), zero16, 0, 0, 0);
+                else c1a[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, xf), c1a[i], 0, 0, 0);
+            }
+            acc[I][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw[((c * 9 + tt) * 2 + s) * 2 + 0]), __builtin_bit_cast(bf16x8, fr), acc[I][0], 0, 0, 0);
+            acc[I][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw[((c * 9 + tt) * 2 + s) * 2 + 1]), __builtin_bit_cast(bf16x8, fr), acc[I][1], 0, 0, 0);
+        });
+        // the roll copy's three slots: read in the phase's last slots, written here (nothing else is in flight)
+        if (R64WF_CUT != 3) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cp[0]), "+v"(cp[1]), "+v"(cp[2]));
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                asm volatile("ds_write_b128 %0, %1" : : "v"(cp_off[I * 3 + k] + c1.cp_dst), "v"(cp[k]) : "memory");
+        }
+    };
+
+    // ---- prologue: the first tile's planes (all five rows, plain conv1), the second tile's patch
+    Geom cur, nxt, nx2;
+    int t = t_begin;
+    tile_geom(t, cur);
+    dma_patch(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    convert_rows(0);
+    __syncthreads();
+    conv1_plain(cur.k_img, 0, 0, 0, BLOCKS, acc[0]);
+    tile_geom(t + 1 < t_end ? t + 1 : t, nxt);
+    dma_patch(nxt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    convert_rows(1);
+    __syncthreads();
+
+#if R64_DIAG
+    unsigned long long dq = __builtin_amdgcn_s_memtime(), dt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long d_c0 = dq, d_r0 = __builtin_amdgcn_s_memrealtime();
+#define R64F_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dt[k] += n_ - dq; dq = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define R64F_STAMP(k) do { } while (0)
+#endif
+    Pend pend = {a.y, 0};
+    for (int it = 0; t < t_end; ++it, ++t) {
+        const int set = it & 1;
+        if (set != a_set) {
+            const unsigned delta = (unsigned)((set - a_set) * 2 * PLANE);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) areg[i][dx][s] += delta;
+            a_set = set;
+        }
+        const bool more = t + 1 < t_end;
+        tile_geom(t + 2 < t_end ? t + 2 : t_end - 1, nx2);
+        dma_patch(nx2);                                               // the fp32 patch of tile t + 2 lands while this tile computes
+        const int vm_mark = vm_issued;
+        const int rows_left = a.H - cur.k_img * a.R, nvalid = (rows_left < a.R ? rows_left : a.R) * W;
+        char* const ytile = a.y + (((long long)cur.b * a.H + (long long)cur.k_img * a.R) * W + wid * 64) * 128;
+#if R64_DIAG
+        dt[0] += 1;
+#endif
+        // ---- rows the next tile shares with this one (its blocks 0, 1 = this pair's blocks 3, 4), or - a new image - computed
+        const bool roll = more && nxt.b == cur.b && nxt.k_img == cur.k_img + 1;
+        // roll: 2 planes x 2 blocks = 1536 slots of 16 bytes, six per thread, copied by the half-phases (three each); a tile that starts an
+        // image computes the two rows instead and the copy moves a block onto itself (harmless: same bytes)
+        if (!roll) conv1_plain(nxt.k_img, set ^ 1, set ^ 1, 0, 2, acc[0]);
+        C1Tile c1;
+        c1.cp_dst = lds_base + (unsigned)(2 * (set ^ 1) * PLANE);
+        c1.cp_src = roll ? lds_base + (unsigned)(2 * set * PLANE + 3 * P * R64_ROWB) : c1.cp_dst;
+        c1.pbase = c1.cp_dst;
+        c1.dump = lds_base + SCR_BASE;
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int h = a.R * nxt.k_img - 1 + (int)(c1_src[gi] >> 27);
+            c1.psrc[gi] = (h >= 0 && h < a.H) ? (c1_src[gi] & 0x07ffffffu) + (unsigned)((set ^ 1) * X4_BUF) : lds_base + ZR_BASE;
+        }
+        R64F_STAMP(1);
+        phase(std::integral_constant<int, 0>{}, pend, c1);
+        R64F_STAMP(2);
+        pend.y = ytile;
+        pend.nv = nvalid - wid * 64;
+        phase(std::integral_constant<int, 1>{}, pend, c1);
+        R64F_STAMP(3);
+        pend.y = ytile + 32 * 128;
+        pend.nv = nvalid - wid * 64 - 32;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's plane writes are done
+        vm_wait(vm_issued - vm_mark);                                  // its patch rows of tile t + 2 have landed (stores may stay in flight)
+        R64F_STAMP(4);
+        convert_rows(set);                                            // patch of t + 2 -> the buffer tile t's patch had
+        __syncthreads();
+        R64F_STAMP(5);
+        cur = nxt; nxt = nx2;
+    }
+    static_for<0, 32>([&](auto vc) { epi_step(std::integral_constant<int, 1>{}, vc, pend); });
+#if R64_DIAG
+    if (lane == 0 && blockIdx.x * 8 + wid < 4096) {
+        float* d = r64_diag + (size_t)(blockIdx.x * 8 + wid) * 12;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d[q] = (float)dt[q];
+        d[8] = d[9] = d[10] = 0.f;
+        d[11] = (float)(__builtin_amdgcn_s_memtime() - d_c0) / (float)(__builtin_amdgcn_s_memrealtime() - d_r0) * 0.1f;
+    }
+#endif
+}
+
 template <int BLOCKS, bool ACT>
 static int launch_r64_wide(const Conv64Args& a, hipStream_t stream) {
     constexpr int PLANE = BLOCKS * R64_P * R64_ROWB;
@@ -1514,7 +1969,7 @@ bool conv64_fused_first_supported(int B, int H, int W) {
     return W % 4 == 0 && W >= 80 && W + 1 <= R64_PF && W <= 96 && H >= 2 && 256 / W == 3 && (long long)B * H * W < (1LL << 26);
 }
 int conv64_fused_first(const float* img, const void* w1, const float* shift1, const void* w2, const float* shift2, void* y, int B, int H,
-                       int W, int act, hipStream_t stream) {
+                       int W, int act, hipStream_t stream, int kernel) {
     if (!conv64_fused_first_supported(B, H, W) || ((size_t)img & 15)) return SUBREG_EUNSUPPORTED;
     Conv64FusedArgs a;
     a.img = img; a.w1 = (const char*)w1; a.shift1 = shift1; a.w = (const char*)w2; a.shift = shift2; a.y = (char*)y;
@@ -1524,6 +1979,24 @@ int conv64_fused_first(const float* img, const void* w1, const float* shift1, co
     a.ntiles = B * a.tpi;
     a.d_w = make_fastdiv(W);
     a.d_tpi = make_fastdiv(a.tpi);
+    // the one-wave-per-SIMD form (conv64_wide_fused_kernel): on request (SUBREG_CONV_KERNEL_WIDE in the flags, or SUBREG_L1_WIDE_FUSED=1 for
+    // whole runs).  Measured equal to the 8-wave form at batch 700 (478-481 us against 474-479; profiles/r05_l1_wide_fused.txt), so the
+    // rule keeps the 8-wave kernel
+    static const bool wide_env = [] { const char* e = getenv("SUBREG_L1_WIDE_FUSED"); return e && e[0] == '1'; }();
+    if (kernel == 2 || (kernel == 0 && wide_env)) {
+        auto kern = act ? conv64_wide_fused_kernel<true> : conv64_wide_fused_kernel<false>;
+        static std::atomic<unsigned long long> lds_set_w[2] = {{0}, {0}};
+        if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), R64_WF_LDS, lds_set_w[act ? 1 : 0])) return rc;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        int grid = cus < a.ntiles ? cus : a.ntiles;
+        grid = (grid + 7) / 8 * 8;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), R64_WF_LDS, stream, a);
+        return launch_status();
+    }
     constexpr size_t lds = R64_FUSED_LDS;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static std::atomic<unsigned long long> lds_set{0};

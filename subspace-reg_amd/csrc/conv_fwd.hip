@@ -1064,7 +1064,7 @@ bool conv_first_supported(int B, int H, int W);                    // conv_first
 
 namespace subreg {
 int conv64_fused_first(const float* img, const void* w1, const float* shift1, const void* w2, const float* shift2, void* y, int B, int H,
-                       int W, int act, hipStream_t stream);          // conv64_resident.hip
+                       int W, int act, hipStream_t stream, int kernel);   // conv64_resident.hip; kernel: 0 rule, 1 the 8-wave form, 2 one wave per SIMD
 }
 
 extern "C" int subreg_conv12_first_fused(const float* x_nchw, const void* w1_packed, const float* shift1, const void* w2_packed,
@@ -1073,7 +1073,7 @@ extern "C" int subreg_conv12_first_fused(const float* x_nchw, const void* w1_pac
     static const bool on = [] { const char* e = getenv("SUBREG_NO_FUSED12"); return !(e && e[0] == '1'); }();   // A/B switch
     if (!on || dtype != SUBREG_BF16 || (flags & (SUBREG_CONV_POOL2 | SUBREG_CONV_RAW_STATS))) return SUBREG_EUNSUPPORTED;
     return conv64_fused_first(x_nchw, w1_packed, shift1, w2_packed, shift2, y, B, H, W, (flags & SUBREG_CONV_LRELU) ? 1 : 0,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, (flags & SUBREG_CONV_KERNEL_WIDE) ? 2 : (flags & SUBREG_CONV_KERNEL_GENERAL) ? 1 : 0);
 }
 
 extern "C" int subreg_layer1_direct_supported(int B, int H, int W, int dtype) {

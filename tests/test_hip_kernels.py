@@ -227,14 +227,18 @@ def test_layer1_conv3_with_the_shortcut_fed_from_the_image(shape):
     assert d <= 2.0 ** -7 * float(np.abs(want).max()), d            # same products, another accumulation order: <= 1 bf16 ulp
 
 
+@pytest.mark.parametrize("kernel", ["8wave", "wide"])
 @pytest.mark.parametrize("shape", [(2, 84, 84), (41, 84, 84), (3, 83, 84), (2, 10, 80), (1, 85, 84), (563, 84, 84)])
-def test_layer1_conv1_conv2_fused_from_the_image(shape):
+def test_layer1_conv1_conv2_fused_from_the_image(shape, kernel):
     """conv1 + BN + LeakyReLU + conv2 + BN + LeakyReLU of layer1.0 (models/resnet_language.py:249-253) in ONE launch, the
-    64-channel intermediate kept in LDS (conv64_resident.hip::conv64_fused_first_kernel), against the oracle (which rounds the
-    intermediate to bf16 where the kernel does) and against the two-launch route: last tiles of 1 and 2 rows (83 / 85 rows),
-    several tiles per workgroup (41 images), a map narrower than 84."""
+    64-channel intermediate kept in LDS (conv64_resident.hip::conv64_fused_first_kernel, and its one-wave-per-SIMD form
+    conv64_wide_fused_kernel behind SUBREG_CONV_KERNEL_WIDE), against the oracle (which rounds the intermediate to bf16 where the
+    kernels do) and against the two-launch route: last tiles of 1 and 2 rows (83 / 85 rows), several tiles per workgroup (41
+    images: every workgroup crosses image boundaries, i.e. both the rolling and the from-scratch conv1 of the wide kernel), a map
+    narrower than 84."""
     B, H, W = shape
     lib = _lib.load()
+    kflag = _lib.CONV_KERNEL_WIDE if kernel == "wide" else _lib.CONV_KERNEL_GENERAL
     rs = np.random.RandomState(B * 7 + H + W)
     x = rs.standard_normal((B, 3, H, W)).astype(np.float32)
     w1 = (rs.standard_normal((64, 3, 3, 3)) * (1.4 / np.sqrt(27))).astype(np.float32)
@@ -244,7 +248,7 @@ def test_layer1_conv1_conv2_fused_from_the_image(shape):
     xd, w1d, w2d, sh1d, sh2d = _t(x), _pack_w_first(w1, sc1), _pack_w(w2, "bf16"), _t(sh1), _t(sh2)
     y = torch.full((B * H * W * 64,), float("nan"), dtype=torch.bfloat16, device=_dev())
     _lib.check(lib.subreg_conv12_first_fused(_lib.ptr(xd), _lib.ptr(w1d), _lib.ptr(sh1d), _lib.ptr(w2d), _lib.ptr(sh2d), _lib.ptr(y), B, H, W,
-                                             _lib.CONV_LRELU, _lib.BF16, _lib.stream_ptr()), "conv12_first_fused")
+                                             _lib.CONV_LRELU | kflag, _lib.BF16, _lib.stream_ptr()), "conv12_first_fused")
     wmax = 4.0
     if B <= 64:                    # (the 563-image case - every workgroup walks ~15 tiles, as in the benchmark - is checked against
         w1q = _round_bf16(w1 * sc1[:, None, None, None])         # the two-launch route only: the NumPy oracle would need minutes)

@@ -92,7 +92,8 @@ def main():
                 sh2 = torch.randn(64, device=dev)
                 out = torch.empty(npix, 64, device=dev, dtype=td)
                 run = lambda: _lib.check(lib.subreg_conv12_first_fused(_lib.ptr(img), _lib.ptr(w1), _lib.ptr(shift), _lib.ptr(w2), _lib.ptr(sh2),   # noqa: E731
-                                                                       _lib.ptr(out), B, H, H, _lib.CONV_LRELU, dt, _lib.stream_ptr()))
+                                                                       _lib.ptr(out), B, H, H,
+                                                                       _lib.CONV_LRELU | (_lib.CONV_KERNEL_WIDE if a.kernel == "wide" else 0), dt, _lib.stream_ptr()))
                 flops, mrows, kk = 2.0 * npix * 64 * (27 + 576), npix, 603
             elif Cin == 3:
                 out = torch.empty(npix, 64, device=dev, dtype=td)

@@ -32,6 +32,13 @@ def fused(lib, raw, dev, B):
     d = out.reshape(-1, 8, 12)
     d = d[d[:, 0, 0] > 0]
     names = ["conv1 (first)", "chunk 0", "chunk 1", "epilogue", "conv1 (after)", "DMA wait + barrier", "convert + barrier"]
+    if os.environ.get("SUBREG_L1_WIDE_FUSED") == "1":       # conv64_wide_fused_kernel: four waves, its own phases
+        g = d[:, 0:4, :].reshape(-1, 12)
+        per = np.median(g[:, 1:6] / g[:, :1], axis=0)
+        wn = ["roll copy + tile set-up", "phase 0 (row tile 0 + conv1 group)", "phase 1", "LDS / DMA wait", "patch conversion + barrier"]
+        print("wide fused conv1+conv2 B=%d: tiles/wave %.1f, clock %.2f GHz, cycles per tile %.0f = " % (B, np.median(g[:, 0]), np.median(g[:, 11]), per.sum()) +
+              ", ".join("%s %.0f" % (n, v) for n, v in zip(wn, per)))
+        return
     for grp, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
         g = d[:, sl, :].reshape(-1, 12)
         per = np.median(g[:, 1:8] / g[:, :1], axis=0)
