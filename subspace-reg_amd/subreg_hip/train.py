@@ -241,6 +241,7 @@ class BackboneTrainFn(torch.autograd.Function):
             hb._desc.col = col_keep
         hb._fold_versions = None             # running statistics moved
         ctx.hb, ctx.stash, ctx.names, ctx.bhw = hb, stash, names, (B, H, W)
+        ctx.stash_tick = stash.tick          # backward refuses a stash that a later forward has taken over (see _take_stash)
         ctx.param_objs = params              # the Parameter objects themselves: backward assigns their .grad (see there)
         return feat
 
@@ -248,6 +249,9 @@ class BackboneTrainFn(torch.autograd.Function):
     def backward(ctx, dfeat):
         hb, stash = ctx.hb, ctx.stash
         B, H, W = ctx.bhw
+        if stash.tick != ctx.stash_tick:
+            raise RuntimeError("subreg_hip: this forward's stash was taken over by a later forward of the same shape (more than two "
+                               "gradient-carrying forwards of one shape were pending): call backward() before forwarding again")
         dfeat = dfeat.contiguous().float()
         hook = getattr(hb, "grad_stage_hook", None)
         # Gradients that are already there (a second backward without zero_grad(), or zero_grad(set_to_none=False)) must be

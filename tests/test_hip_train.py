@@ -775,3 +775,17 @@ def test_two_forwards_before_the_backward_keep_their_own_stash_masks_and_input(m
     for k, v in ref.state_dict().items():
         if "running" in k:
             assert torch.allclose(stats[k], v, rtol=1e-6, atol=1e-7), k
+
+
+def test_a_stash_taken_over_by_later_forwards_makes_its_backward_fail_loudly():
+    """At most two stashes per shape are kept (a forward whose backward never comes must not pile up buffers): the third pending
+    forward of one shape takes over the oldest stash, and THAT forward's backward must raise instead of differentiating through
+    another batch's activations."""
+    net = _train_net("f32").eval()
+    x = torch.from_numpy(syn.make_images(79, 3, 32)).cuda()
+    outs = [net(x) for _ in range(3)]
+    assert len([st for st in net.hip_backbone()._train_stashes if st.shape == (3, 32, 32)]) == 2
+    outs[2].sum().backward()
+    outs[1].sum().backward()
+    with pytest.raises(RuntimeError, match="taken over"):
+        outs[0].sum().backward()
