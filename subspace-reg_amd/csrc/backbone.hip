@@ -143,6 +143,12 @@ extern "C" int subreg_backbone_forward(const subreg_backbone_desc* d, const floa
 
     if (!direct) TRY(subreg_pack_input(x_nchw, d->col, B, H, W, dt, stream));
     const void* cur = direct ? nullptr : d->col;
+    // K split over workgroups for the small maps of an eval-mode forward (the third free workspace slot holds the partial sums):
+    // SUBREG_EVAL_SPLITK=1.  Measured (tools/bench_splitk.py, profiles/r05_eval_splitk.txt): layer 4.1's convolutions 1.3x at 125 images,
+    // 1.9x at 63, nothing above ~160 - and another summation order, which moves a near-chance bf16 golden (loop_hw32_bias) from two
+    // flipped query images to three; off by default for that reason.
+    static const bool eval_splitk = [] { const char* e = getenv("SUBREG_EVAL_SPLITK"); return e && e[0] == '1'; }();
+    const long long slot_floats = eval_splitk ? subreg_backbone_ws_bytes(d, B, H, W) / 4 : 0;   // what the caller sized every workspace slot for
     int cur_slot = -1;                 // workspace slot holding `cur` (-1: the im2col buffer)
     int h = H, w = W;
     for (int i = 0; i < d->n_blocks; ++i) {
@@ -173,19 +179,26 @@ extern "C" int subreg_backbone_forward(const subreg_backbone_desc* d, const floa
             if (fused != SUBREG_OK) {
                 if (fused != SUBREG_EUNSUPPORTED) return fused;
                 if (img_in) TRY(subreg_conv_first_fwd(x_nchw, b.conv1.w_folded, A, b.conv1.shift, B, h, w, b.conv1.cout, SUBREG_CONV_LRELU, dt, stream));
-                else TRY(subreg_conv_fwd(cur, b.conv1.w_folded, A, nullptr, b.conv1.shift, nullptr, nullptr, nullptr, nullptr, 0, B, h, w,
-                                         b.conv1.cin, b.conv1.cout, b.conv1.ksize, SUBREG_CONV_LRELU, dt, stream));
-                TRY(subreg_conv_fwd(A, b.conv2.w_folded, Bf, nullptr, b.conv2.shift, nullptr, nullptr, nullptr, nullptr, 0, B, h, w,
-                                    b.conv2.cin, b.conv2.cout, b.conv2.ksize, SUBREG_CONV_LRELU, dt, stream));
+                // (the third free slot is the K-split workspace of the small maps: 5x5 below ~160 images, see splitk_plan in conv_fwd.hip)
+                else TRY(subreg_conv_fwd_ws(cur, b.conv1.w_folded, A, nullptr, b.conv1.shift, nullptr, nullptr, nullptr, nullptr, 0, B, h, w,
+                                            b.conv1.cin, b.conv1.cout, b.conv1.ksize, SUBREG_CONV_LRELU, dt, eval_splitk ? (float*)C : nullptr,
+                                            slot_floats, stream));
+                TRY(subreg_conv_fwd_ws(A, b.conv2.w_folded, Bf, nullptr, b.conv2.shift, nullptr, nullptr, nullptr, nullptr, 0, B, h, w,
+                                       b.conv2.cin, b.conv2.cout, b.conv2.ksize, SUBREG_CONV_LRELU, dt, eval_splitk ? (float*)C : nullptr,
+                                       slot_floats, stream));
             }
             const void* w2 = b.down.w ? b.down.w_folded : b.w_identity;
             const int cin2 = b.down.w ? b.down.cin : b.conv3.cout;
             SUBREG_CHECK_ARG(w2 != nullptr);
             if (img_in) TRY(subreg_conv_fwd_image_shortcut(Bf, b.conv3.w_folded, A, b.shift3, x_nchw, w2, B, h, w, b.conv3.cin,
                                                            b.conv3.cout, SUBREG_CONV_LRELU | pflag, dt, stream));
+            else if (eval_splitk && !b.down.w && !pool && subreg_conv_splitk_floats(B, h, w, b.conv3.cin, b.conv3.cout, b.conv3.ksize, dt) > 0)
+                // identity shortcut on a map small enough for the K split: the block input is added in the reduce pass instead of
+                // riding along as a second GEMM
+                TRY(subreg_conv_fwd_ws(Bf, b.conv3.w_folded, A, nullptr, b.shift3, cur, nullptr, nullptr, nullptr, 0, B, h, w, b.conv3.cin,
+                                       b.conv3.cout, b.conv3.ksize, SUBREG_CONV_LRELU, dt, (float*)C, slot_floats, stream));
             else TRY(subreg_conv_fwd(Bf, b.conv3.w_folded, A, nullptr, b.shift3, nullptr, nullptr, cur, w2, cin2, B, h, w,
                                      b.conv3.cin, b.conv3.cout, b.conv3.ksize, SUBREG_CONV_LRELU | pflag, dt, stream));
-            (void)C;
             out_slot = fs[0];
         } else {
             TRY(conv_train(d, b.conv1, cur, A, B, h, w, stream));

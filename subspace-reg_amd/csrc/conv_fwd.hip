@@ -899,7 +899,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
 // 32-row groups (m-tile x 4 + wave) the 128-row-tile kernel writes, so subreg_conv_stats_rows and the finalize pass are unchanged.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ksplit, int M, int Cout,
                                                             __bf16* __restrict__ y, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, int act, int raw,
+                                                            const float* __restrict__ shift, const __bf16* __restrict__ res, int act, int raw,
                                                             float* __restrict__ stats) {
     __shared__ float r1[32][33], r2[32][33];
     const int cq = threadIdx.x & 7, row = threadIdx.x >> 3;
@@ -915,9 +915,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         }
         float o[4] = {v.x, v.y, v.z, v.w};
         if (!raw) {
+            float r[4] = {0.f, 0.f, 0.f, 0.f};
+            if (res) {                                                // the block's identity shortcut (eval mode): + x before the activation
+                const uint2 rv = *reinterpret_cast<const uint2*>(res + (size_t)m * Cout + n);
+                r[0] = __builtin_bit_cast(float, rv.x << 16); r[1] = __builtin_bit_cast(float, rv.x & 0xffff0000u);
+                r[2] = __builtin_bit_cast(float, rv.y << 16); r[3] = __builtin_bit_cast(float, rv.y & 0xffff0000u);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                o[k] = o[k] * (scale ? scale[n + k] : 1.f) + (shift ? shift[n + k] : 0.f);
+                o[k] = o[k] * (scale ? scale[n + k] : 1.f) + (shift ? shift[n + k] : 0.f) + r[k];
                 if (act) o[k] = fmaxf(o[k], o[k] * 0.1f);
             }
         }
@@ -1099,9 +1105,12 @@ static int splitk_plan(int dtype, int B, int H, int W, int Cin, int Cout, int ks
     if (!on || dtype != SUBREG_BF16 || ksize != 3 || Cout % 160 != 0 || Cin % 32 != 0) return 1;
     const long long M = (long long)B * H * W;
     if (M * Cout >= (1LL << 31) || wide_takes_256_rows((int)M, Cout, W)) return 1;
+    // SUBREG_SPLITK_MAXBLOCKS / SUBREG_SPLITK_SLOTS: the rule's two numbers (measurements)
+    static const int max_blocks = [] { const char* e = getenv("SUBREG_SPLITK_MAXBLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+    static const int slots = [] { const char* e = getenv("SUBREG_SPLITK_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
     const long long blocks = ((M + 127) / 128) * (Cout / 160);
-    if (blocks > 128) return 1;
-    long long ks = 256 / blocks;
+    if (blocks > max_blocks) return 1;
+    long long ks = slots / blocks;
     if (ks > Cin / 64) ks = Cin / 64;
     if (ks > 8) ks = 8;
     return ks >= 2 ? (int)ks : 1;
@@ -1156,7 +1165,7 @@ static int conv_fwd_impl(const void* x, const void* w, void* y, const float* sca
     a.part = nullptr; a.ksplit = 1;
     hipStream_t s = (hipStream_t)stream;
     const bool wide = (Cout % 160 == 0);
-    if (ws && !pool && !residual && !x2) {
+    if (ws && !pool && !x2 && !(raw && residual)) {
         // small-M 3x3 layers with a caller-provided workspace: K split over workgroups + reduce pass (see conv_fwd_kernel)
         const int ks = splitk_plan(dtype, B, H, W, Cin, Cout, ksize);
         if (ks > 1 && ws_floats >= (long long)ks * a.g.M * Cout) {
@@ -1165,7 +1174,8 @@ static int conv_fwd_impl(const void* x, const void* w, void* y, const float* sca
             if (rc == SUBREG_OK) {
                 const int srows = raw ? stats_rows_for(dtype, a.g.M, Cout, W) : (a.g.M + 31) / 32;
                 hipLaunchKernelGGL(splitk_reduce_kernel, dim3(Cout / 32, srows), dim3(256), 0, s, ws, ks, a.g.M, Cout, (__bf16*)y,
-                                   raw ? nullptr : scale, raw ? nullptr : shift, raw ? 0 : a.act, raw ? 1 : 0, stats_partial);
+                                   raw ? nullptr : scale, raw ? nullptr : shift, raw ? nullptr : (const __bf16*)residual, raw ? 0 : a.act,
+                                   raw ? 1 : 0, stats_partial);
                 return launch_status();
             }
             if (rc != SUBREG_EUNSUPPORTED) return rc;
