@@ -577,6 +577,26 @@ def test_conv_split_k_with_workspace(shape):
                                       B, H, W, Cin, Cout, 3, _lib.CONV_LRELU, dt, _lib.ptr(ws), need, _lib.stream_ptr()))
     a, r = _tol("bf16", np.abs(want).max())
     _cmp("scale/shift/act (split)", y.float().cpu().numpy().reshape(M, Cout), want, a, r)
+    # ... and with a residual added before the activation (eval mode, conv3 of a block with an identity shortcut, SUBREG_EVAL_SPLITK=1)
+    if Cin == Cout:
+        want = rr.leaky_relu(flat + sh + rr._nhwc(x).astype(np.float64).reshape(M, Cout))
+        y = torch.full((M * Cout,), float("nan"), dtype=torch.bfloat16, device=_dev())
+        _lib.check(lib.subreg_conv_fwd_ws(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), None, _lib.ptr(shd), _lib.ptr(xd), None, None, None, 0,
+                                          B, H, W, Cin, Cout, 3, _lib.CONV_LRELU, dt, _lib.ptr(ws), need, _lib.stream_ptr()))
+        a, r = _tol("bf16", np.abs(want).max())
+        _cmp("shift/residual/act (split)", y.float().cpu().numpy().reshape(M, Cout), want, a, r)
+
+
+def test_eval_forward_with_the_k_split_switched_on():
+    """SUBREG_EVAL_SPLITK=1 (off by default: profiles/r05_eval_splitk.txt): the eval forward of the small maps through
+    subreg_conv_fwd_ws + reduce pass, the identity shortcut added there - the backbone goldens of the reference in a fresh process
+    (the switch is read once)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SUBREG_EVAL_SPLITK="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "test_backbone_golden", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert p.returncode == 0 and "4 passed" in p.stdout, p.stdout[-1500:] + p.stderr[-500:]
 
 
 # ---------------------------------------------------------------- backbone against the reference's golden vectors
