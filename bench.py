@@ -639,6 +639,20 @@ def main():
         "episodes_per_s_balanced": imgs * world / dt / mean_imgs,   # session-balanced: invariant in --steps
         "epochs_per_s": args.steps * world * args.epochs / dt,     # fine-tune epochs (forward + step + validation) per second, SURVEY.md 8d
     }
+    # context, RECORDED (not measured by this run): the reference's own route on this GPU - the same network as plain PyTorch-ROCm
+    # modules through MIOpen, tools/torch_rocm_baseline.py.  `vs_baseline` stays null: BASELINE.md holds no published number.
+    rpath = os.path.join(REPO, "profiles", "torch_rocm_baseline.json")
+    if os.path.exists(rpath) and args.dtype == "bf16":
+        try:
+            rj = json.load(open(rpath))
+            out["reference_route_on_this_gpu"] = {
+                "recorded": True, "recorded_at": rj.get("recorded_at"), "file": rj.get("file"),
+                "episodes_per_s_fp32": rj.get("episodes_per_s_fp32"), "episodes_per_s_bf16_autocast": rj.get("episodes_per_s_bf16_autocast"),
+                "this_line_over_fp32": out["episodes_per_s_balanced"] / world / rj["episodes_per_s_fp32"],
+                "this_line_over_bf16_autocast": out["episodes_per_s_balanced"] / world / rj["episodes_per_s_bf16_autocast"],
+                "what": rj.get("what")}
+        except Exception:                                          # noqa: BLE001
+            pass
     session_seconds = {s_: float(np.mean(v)) for s_, v in session_sec.items()}
     del runners, r
     if rank == 0:                                              # the headline is on record before any extra leg starts
