@@ -6,6 +6,7 @@ subreg_hip or oracle/).  The architecture is restated from SURVEY.md section 3 (
 640, blocks 1 / 1 / 2 / 2, three bias-free 3x3 convs per block + BN + LeakyReLU(0.1), 1x1 conv + BN shortcut in the first block of a
 layer, MaxPool2d(2) after it, global average pool, Linear(640, n_cls, bias=False)); random weights, synthetic 84x84 images.
   python tools/torch_rocm_baseline.py"""
+import sys
 import time
 
 import torch
@@ -61,13 +62,18 @@ def timed(fn, iters, warm):
 
 def main():
     dev = torch.device("cuda:0")
-    # (MIOpen in its default immediate mode: the find mode (cudnn.benchmark) compiles candidates for > 20 minutes on a fresh box)
+    # MIOpen in its default immediate mode, or - `--find`, what the reference asks for (eval_incremental.py:114 cudnn.benchmark = True) -
+    # in find mode, which on a fresh box without a performance database compiles and times candidate kernels for minutes PER SHAPE
+    # (`--quick`: the batch-700 eval forward only)
+    find, quick = "--find" in sys.argv, "--quick" in sys.argv
+    torch.backends.cudnn.benchmark = find
+    print("MIOpen mode:", "find (cudnn.benchmark = True)" if find else "immediate (default)", flush=True)
     print("torch", torch.__version__, "| 8.1219 GFLOP per 84x84 image forward, 24.339 per training image; 69875 image-forwards per episode (bench.py)")
     for mode, dt in (("fp32 (what the reference runs)", None), ("bf16 autocast, channels_last", torch.bfloat16)):
         net = Net().to(dev).eval()
         if dt is not None:
             net = net.to(memory_format=torch.channels_last)
-        for B in (125, 700, 1125):
+        for B in ((700,) if quick else (125, 700, 1125)):
             x = torch.randn(B, 3, 84, 84, device=dev)
             if dt is not None:
                 x = x.contiguous(memory_format=torch.channels_last)
@@ -75,9 +81,15 @@ def main():
             def fwd():
                 with torch.no_grad(), torch.autocast("cuda", dtype=dt, enabled=dt is not None):
                     return net.features(x)
+            t0 = time.perf_counter()
+            fwd()
+            torch.cuda.synchronize()
+            print("  (first call, incl. MIOpen's kernel selection: %.0f s)" % (time.perf_counter() - t0), flush=True)
             t = timed(fwd, 10, 4)
             print("eval forward  %-32s B=%4d  %8.2f ms  %8.0f img/s  %7.1f TFLOP/s  -> %.3f episodes/s at 100 epochs" %
                   (mode, B, t * 1e3, B / t, B * 8.1219e9 / t * 1e-12, B / t / 69875.0))
+        if quick:
+            continue
         net.train()
         opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
         crit = nn.CrossEntropyLoss()
