@@ -64,8 +64,8 @@ def main():
     dev = torch.device("cuda:0")
     # MIOpen in its default immediate mode, or - `--find`, what the reference asks for (eval_incremental.py:114 cudnn.benchmark = True) -
     # in find mode, which on a fresh box without a performance database compiles and times candidate kernels for minutes PER SHAPE
-    # (`--quick`: the batch-700 eval forward only)
-    find, quick = "--find" in sys.argv, "--quick" in sys.argv
+    # (`--quick`: the batch-700 eval forward only; `--train-only`: the 64-image training step only)
+    find, quick, train_only = "--find" in sys.argv, "--quick" in sys.argv, "--train-only" in sys.argv
     torch.backends.cudnn.benchmark = find
     print("MIOpen mode:", "find (cudnn.benchmark = True)" if find else "immediate (default)", flush=True)
     print("torch", torch.__version__, "| 8.1219 GFLOP per 84x84 image forward, 24.339 per training image; 69875 image-forwards per episode (bench.py)")
@@ -73,7 +73,7 @@ def main():
         net = Net().to(dev).eval()
         if dt is not None:
             net = net.to(memory_format=torch.channels_last)
-        for B in ((700,) if quick else (125, 700, 1125)):
+        for B in (() if train_only else (700,) if quick else (125, 700, 1125)):
             x = torch.randn(B, 3, 84, 84, device=dev)
             if dt is not None:
                 x = x.contiguous(memory_format=torch.channels_last)
@@ -93,7 +93,7 @@ def main():
         net.train()
         opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
         crit = nn.CrossEntropyLoss()
-        for B in (64, 128):
+        for B in ((64,) if train_only else (64, 128)):
             x = torch.randn(B, 3, 84, 84, device=dev)
             if dt is not None:
                 x = x.contiguous(memory_format=torch.channels_last)
@@ -105,6 +105,10 @@ def main():
                 opt.zero_grad()
                 loss.backward()
                 opt.step()
+            t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            print("  (first step, incl. MIOpen's kernel selection: %.0f s)" % (time.perf_counter() - t0), flush=True)
             t = timed(step, 10, 4)
             print("train step    %-32s B=%4d  %8.2f ms  %8.0f img/s  %7.1f TFLOP/s" % (mode, B, t * 1e3, B / t, B * 24.339e9 / t * 1e-12))
         del net, opt
