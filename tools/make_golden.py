@@ -356,7 +356,7 @@ def gen_semantic():
 
 
 def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False, mapping_seed=None, signal=3.0, proto_grid=0,
-             hard_queries=0, centre=False, base_norm=0.5, **optkw):
+             hard_queries=0, centre=False, base_norm=0.5, save=True, **optkw):
     opt = ref_opt(set_seed=seed, neval_episodes=n_sessions, memory_replay=1 if memory else 0, **optkw)
     sd = syn.make_state_dict(21 + seed)
     with_bias = bool(getattr(opt, "linear_bias", False))
@@ -437,7 +437,10 @@ def gen_loop(tag, hw, n_sessions, memory, n_base_batch, seed=1, real_names=False
                                                                     vis=False, base_support_loader=bsl)
     finally:
         le.validate, np.random.choice, torch.Tensor.backward, le.eval_base = orig_validate, orig_choice, orig_backward, orig_eval_base
-    print(tag, "reference loop took %.1f s" % (time.time() - t0))
+    took = time.time() - t0
+    print(tag, "reference loop took %.1f s" % took)
+    if not save:                                 # (timing runs: `timeref`)
+        return took, [len(l) for l in rec["loss"]]
     out = dict(hw=np.array(hw), n_sessions=np.array(n_sessions), memory=np.array(int(memory)), seed=np.array(seed),
                n_base_batch=np.array(n_base_batch), signal=np.array(signal), sd_seed=np.array(21 + seed),
                mask_seed=np.array(61 + seed), base_classifier=wcls,
@@ -609,6 +612,16 @@ def main():
         # freeze_backbone_at = 3 (language_eval.py:243-249, eval/util.py:62-69): epochs 1-2 of the first session fine-tune the WHOLE
         # network (epoch 1 in train mode, epoch 2 in eval mode: validate() leaves the model there), the backbone freezes at epoch 3
         gen_loop("hw32_freeze3", 32, 2, False, 40, seed=15, max_novel_epochs=6, freeze_backbone_at=3)
+    if "timeref" in what:
+        # the REFERENCE's own loop on this container's CPU cores, config 1 (one -M session of a miniImageNet-shaped
+        # 5-way 5-shot run, 84x84, 125 support + 125 query images, 1000-image base evaluation), E fixed: 5 (smoke) and 100 (headline)
+        import json
+        res = {"threads": torch.get_num_threads(), "cores": os.cpu_count()}
+        for E in (5, 100):
+            took, epochs = gen_loop("timeref_E%d" % E, 84, 1, False, 1000, seed=1, max_novel_epochs=E, stable_epochs=E + 1, save=False)
+            imgs = E * 250 + 2 * 1000                   # per epoch: support + one query set; base evaluation before and after the session
+            res["E%d" % E] = {"wall_s": round(took, 1), "epochs": epochs, "episodes_per_s": 1.0 / took, "images_per_s": imgs / took}
+            print(json.dumps(res), flush=True)
     if "freeze_opts" in what:
         # the same with --adam: get_optim's ONE torch.optim.Adam(lr, weight_decay=0.0005) over net.parameters() (eval/util.py:92-97)
         # also steps the backbone in epochs 1-2.  lr 2e-5: Adam moves EVERY element by ~lr per step whatever its gradient; at the
