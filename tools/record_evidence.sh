@@ -36,10 +36,16 @@ for v in SUBREG_WIDE=0 SUBREG_WIDE=-1 SUBREG_WIDE=0 SUBREG_WIDE=-1; do
   echo "== $v  (0: conv_fwd.hip everywhere; -1: the dispatcher's rule)" >> $O/forward_ab_wide_rule.txt
   env $v python3 $R/tools/bench_forward.py --lanes 2 --batches 250,500,750,1125 2>&1 | $G >> $O/forward_ab_wide_rule.txt
 done
-for p in dma_issue dma_slot mfma_shape mfma_shape_bare mfma_energy; do
+for p in dma_issue dma_slot mfma_shape mfma_shape_bare mfma_energy mfma_operand; do
   [ -x $R/tools/probes/$p ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-inline-asm $R/tools/probes/$p.hip -o $R/tools/probes/$p
   $R/tools/probes/$p > $O/probe_$p.txt 2>&1
 done
+# --- context: the vendor's libraries on this box, operand values, the eval K split, layer 1's two fused kernels
+python3 $R/tools/probes/vendor_ceiling.py 2>&1 | $G > $O/vendor_ceiling.txt
+for d in normal zeros narrow half; do echo "== data $d" >> $O/conv_operand_values_b700.txt; python3 $R/tools/bench_conv.py --batch 700 --kernel general --data $d 2>&1 | $G >> $O/conv_operand_values_b700.txt; done
+python3 $R/tools/bench_splitk.py 63 125 250 2>&1 | $G > $O/eval_splitk.txt
+for k in auto wide auto wide; do python3 $R/tools/bench_conv.py --batch 700 --only L1.conv1 --kernel $k 2>&1 | $G | sed "s/^/kernel=$k  /" >> $O/l1_wide_fused.txt; done
+# (tools/torch_rocm_baseline.py - the reference's route through MIOpen - is NOT part of this script: its find mode takes ~10 minutes per table)
 # --- whole forward, A/B of this round's layer-1 changes within one box
 for v in "" SUBREG_NO_FUSED12=1 SUBREG_IM2COL_FIRST=1; do
   echo "== ${v:-production}" >> $O/forward_ab_layer1.txt
