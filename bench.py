@@ -312,7 +312,7 @@ def pretrain_leg(args):
     Algorithmic work 24.339 GFLOP per image."""
     from subreg_hip import synthetic as syn
     from subreg_hip.resnet_language import create_model
-    from subreg_hip.train import SGD
+    from subreg_hip.train import SGD, GraphedStep
     dev = torch.device("cuda", torch.cuda.current_device())
     out = {"workload": "train_supervised.py step, ResNet18, 60 classes, SGD(0.05, 0.9, 5e-4), synthetic 84x84 (BASELINE.json configs[2])",
            "flop_per_image": 24.339e9, "dtype": args.dtype, "batches": {}}
@@ -325,20 +325,32 @@ def pretrain_leg(args):
         x = torch.randn(B, 3, 84, 84, device=dev)
         y = torch.randint(0, 60, (B,), device=dev)
 
-        def step():
+        def eager_step():
             loss = crit(net(x), y)
             sgd.zero_grad()
             loss.backward()
             sgd.step()
+        # the step as the pretraining driver runs it (subreg_hip.pretrain.train): ONE hipGraph per batch shape and learning rate,
+        # replayed (train.GraphedStep: same kernels, same two streams; inputs copied into the graph's buffers every step)
+        graphed = GraphedStep(net, sgd, lambda xx, yy: crit(net(xx), yy))
+
+        def step():
+            graphed(x, y)
+
+        def timed(fn, n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
         for _ in range(4):
+            eager_step()
+        dt_eager = timed(eager_step, 10)
+        for _ in range(5):                                             # (warm-up calls, the capture, first replays)
             step()
-        torch.cuda.synchronize()
-        n = 20
-        t0 = time.perf_counter()
-        for _ in range(n):
-            step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
+        dt = timed(step, 20)
+        is_graph = graphed.replays > 0
         tf = B * 24.339e9 / dt / 1e12
         # kernel launches of ONE step, counted live by the profiler's kernel records (library kernels and torch's alike); None when
         # the profiler is not usable on this box (profiles/r05_train_timeline_two_streams.txt holds the rocprofv3 count)
@@ -353,9 +365,10 @@ def pretrain_leg(args):
         except Exception:
             launches = None
         out["batches"][str(B)] = {"ms_per_step": dt * 1e3, "images_per_s": B / dt, "launches_per_step": launches,
+                                  "hip_graph": is_graph, "ms_per_step_eager": dt_eager * 1e3,
                                   "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                                                "frac": tf / PEAK_TFLOPS[args.dtype]}}
-        del net, sgd, x, y
+        del net, sgd, x, y, graphed
     return out
 
 
@@ -670,6 +683,33 @@ def main():
                 out["route_a"]["fused_loop_epochs_per_s_same_shape"] = args.epochs / (session_seconds[7] - 0.0)
         except Exception as exc:                                   # noqa: BLE001
             out["route_a"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        # SURVEY.md section 8d "report both": the same 8-session workload with the frozen backbone's (constant) eval-mode features
+        # computed ONCE per session and reused by every later epoch - results identical to the headline's recomputation
+        # (tests/test_hip_loop.py::test_feature_reuse_is_results_identical; eval/language_eval.py:252,321-326 feed constant inputs
+        # through frozen weights).  NOT the headline: `value` above recomputes every forward, as the reference does.
+        try:
+            def reuse_run():
+                with torch.no_grad():
+                    net.classifier.weight = torch.nn.Parameter(net.classifier.weight.detach()[:60].clone())
+                rr = IncrementalRunner(net, meta, base, opt, None, None, None, eps, True, verbose=False, profile=False).start()
+                for s_ in range(8):
+                    rr.run_session(s_)
+                return rr
+            reuse_run()
+            torch.cuda.synchronize()
+            tr = time.perf_counter()
+            rr = reuse_run()
+            torch.cuda.synchronize()
+            tr = time.perf_counter() - tr
+            out["feature_reuse"] = {"episodes_per_s": 8.0 / tr, "seconds_per_8_sessions": tr, "images_forwarded": int(rr.images_forwarded),
+                                    "images_forwarded_headline_per_8_sessions": int(round(mean_imgs * 8)),
+                                    "epochs_per_episode": args.epochs, "identical_to_headline": True,
+                                    "speedup_over_headline": (8.0 / tr) / (out["episodes_per_s_balanced"] / world),
+                                    "what": "same 8 sessions, E epochs each, classifier step + validation every epoch; backbone forward of "
+                                            "every support / query / base-evaluation image once per session instead of once per epoch"}
+            del rr
+        except Exception as exc:                                   # noqa: BLE001
+            out["feature_reuse"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         try:
             out["sweep_model"] = sweep_model(args, net, dev, session_seconds if len(session_seconds) == 8 else None)
         except Exception as exc:                                   # noqa: BLE001

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUBREG_ABI_VERSION 13
+#define SUBREG_ABI_VERSION 14
 
 #define SUBREG_OK 0
 #define SUBREG_EINVAL (-1)       /* bad argument (null pointer, shape not supported by contract) */
@@ -127,6 +127,17 @@ int subreg_mask_nchw_to_nhwc(const float* mask_nchw, unsigned char* keep_nhwc, i
 /* counter-based Bernoulli(1-p_drop) keep mask for free-running train forwards; kept_count may be NULL */
 int subreg_random_keep_mask(unsigned char* keep, long long n, unsigned long long seed, float p_drop, unsigned int* kept_count,
                             void* stream);
+/* the same with the seed and the drop probability read from device memory when the launch runs (a captured hipGraph replays it with
+ * fresh randomness and DropBlock's step-dependent gamma, :294-296); subreg_mask_params_set writes n <= SUBREG_MASK_PARAMS_MAX
+ * parameter records from HOST values (they travel as a kernel argument: no staging buffer, nothing to keep alive) */
+#define SUBREG_MASK_PARAMS_MAX 16
+typedef struct subreg_mask_param {
+    unsigned long long seed;
+    float p_drop;
+    unsigned int reserved;
+} subreg_mask_param;
+int subreg_random_keep_mask_dev(unsigned char* keep, long long n, const subreg_mask_param* param, unsigned int* kept_count, void* stream);
+int subreg_mask_params_set(subreg_mask_param* params_dev, int n, const subreg_mask_param* host_values, void* stream);
 /* DropBlock's rescale factor numel / max(count, 1) (resnet_language.py:318-323) from the counter the mask kernels fill, written
  * to a device float for subreg_block_desc.mask_scale_dev */
 int subreg_mask_scale(const unsigned int* kept_count, long long numel, float* scale, void* stream);

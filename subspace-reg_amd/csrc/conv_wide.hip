@@ -586,6 +586,461 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv_wide_kernel(const Conv
     }
 }
 
+// ---------------------------------------------------------------------------- round 6: the 256-row tiling on v_mfma_f32_16x16x32_bf16
+// Why (profiles/r06_probe_mfma_shape.txt; MI355X_MICROARCH.md, DVFS give-back item 7): with inline-asm MFMAs at 98-99 % matrix-pipe duty
+// on random bf16 data, same 64 x 160 wave tile, every SIMD busy, the 16x16x32 shape delivers 1.13-1.14 x the FLOP/s of 32x32x16
+// (with all 14 fragments re-read from LDS every K = 32: 0.78-0.80 against 0.68-0.70 of 2.5 PFLOP/s) - the chip holds a higher clock
+// on it.  This kernel is conv_wide_kernel<MI = 2> (64 x 160 wave tiles, 256 x 160 tiles, two workgroups per CU, the same LDS image
+// up to the swizzle, the same staging slots, waits and barrier) with the step re-cut for that shape:
+//   a step (32-channel chunk, tap) = ONE k-step = 4 A fragments (16 rows each) x 10 B fragments (16 channels each) = 40 MFMAs,
+//   issued B-major (a0..a3 x b_g) except for the first and the last column pair, which run A-major: a fragment a_i is then dead a
+//   quarter of a pair before the step ends and the NEXT step's a'_i is read into the same registers (see the step's schedule at
+//   `pair0` below).  Register budget (160 accumulators of 256): ONE A set (16), a B ring of four (16) read two groups = 128
+//   matrix-pipe cycles ahead.  (A first cut with the A fragments double-buffered a step ahead needed 20 registers more and hipcc
+//   spilled four of the tap-address registers INSIDE the loop - scratch reloads count in vmcnt and drained the LDS-DMAs.)
+//   MID (vmcnt wait, barrier) sits between groups 4 and 5, the DMA slots S2 W0 W1 S3 in front of groups 5, 6, 7 and the last pair.
+// LDS swizzle of this shape: conv_index.h::swz_tr<4, 16> (lane l reads row l % 16 at logical slot l / 16).
+namespace {
+__device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+}  // namespace
+
+template <bool POOL, int AROWS>
+__global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
+    constexpr bool SWAPC = !POOL;
+    constexpr int NW = 4, NA = 4, NB = 10, TM = 256, TN = 160, TR = 16;
+    constexpr int ROWB = 64, RPP = 16, SLOTS = 4, ELEM = 2, TAPS = 9, CENTER = 4;
+    constexpr int BTAP = TN * ROWB, NWB = 3;
+    constexpr int ABUF = (AROWS + 1) * ROWB;
+    constexpr int A_BASE = NWB * BTAP;
+    constexpr int WPT = TN / RPP, WPW = (WPT + NW - 1) / NW;
+    constexpr int NPP = 6;
+    constexpr int PLAST = (AROWS / RPP - 1 + NPP - 1) / NPP;
+    static_assert(WPT == 10 && WPW == 3, "slot table of conv_wide_kernel");
+    static_assert(PLAST <= 6, "S3 exists in steps 0 .. 6; everything has landed at MID(8)");
+    static_assert(AROWS % RPP == 0 && ABUF < 65536, "patch buffer: whole pieces, 16-bit row addresses");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using T = __bf16;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lh = lane >> 4;             // row (column) within an MFMA tile, 8-channel k-slot (A, B) / row quad (C)
+    const ConvGeom g = a.g;
+    constexpr bool STAMPS = SUBREG_WIDE_DIAG == 3;
+    unsigned long long t_begin = 0, t_loop = 0, t_wait = 0, t_bar = 0, r_begin = 0;
+    if (STAMPS) { t_begin = __builtin_amdgcn_s_memtime(); r_begin = __builtin_amdgcn_s_memrealtime(); }
+    const int ntn = a.Cout / TN;
+    int vtile;
+    {
+        const int nwg = gridDim.x, lid = blockIdx.x, q8 = nwg / 8, r8 = nwg % 8, xcd = lid % 8, slot = lid / 8;
+        vtile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int mtile = vtile / ntn;
+    const int m0 = mtile * TM;
+    const int n0 = (vtile % ntn) * TN;
+
+    int plo, phi;
+    patch_range<POOL>(g, m0, TM, &plo, &phi);
+    const int prow = phi - plo;
+    const int apieces = (prow + RPP - 1) / RPP;
+
+    float* const s_shift = reinterpret_cast<float*>(smem + A_BASE + 2 * ABUF);
+    if constexpr (POOL) {
+        for (int t = tid; t < TN; t += NW * 64) s_shift[t] = a.shift[n0 + t];
+    }
+    if (tid < 2 * (ROWB / 16)) {
+        const int b = tid / (ROWB / 16), q = tid % (ROWB / 16);
+        *reinterpret_cast<uint4*>(smem + A_BASE + b * ABUF + AROWS * ROWB + q * 16) = make_uint4(0, 0, 0, 0);
+    }
+
+    f32x4 acc[NA][NB];
+    const int prl = lane / SLOTS, psl = lane % SLOTS;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned xrow0 = (unsigned)a.Cin * ELEM, xrow1 = (unsigned)a.Cin2 * ELEM;
+    const unsigned porg0 = (unsigned)plo * xrow0, porg1 = (unsigned)plo * xrow1;
+    const unsigned swzo = (unsigned)((psl ^ swz_tr<SLOTS, TR>(prl)) << 4);     // (a piece is 16 rows: the swizzle of a piece row does not depend on the piece)
+    auto rfl = [](unsigned v) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    auto patch_piece = [&](const char* src, unsigned uoff, unsigned xrow, int q, int buf) {
+        int row = q * RPP + prl;
+        row = row < prow ? row : prow - 1;
+        dma16(src, uoff + (unsigned)row * xrow + swzo, lds_base + A_BASE + buf * ABUF + q * 1024);
+    };
+    // per-lane source offset of this wave's weight piece `wid`; pieces wid + 4, wid + 8 are 4096, 8192 bytes further (64 rows each)
+    const unsigned wvoff0 = (unsigned)(n0 + wid * RPP + prl) * ROWB + swzo;
+    const int s2w = __builtin_amdgcn_readfirstlane(wid < 2 ? 1 : 0);
+    const unsigned s2m = (unsigned)__builtin_amdgcn_readfirstlane(wid < 2 ? -1 : 0);
+    const unsigned long long s2mask = ((unsigned long long)s2m << 32) | s2m;
+    const int p2 = wid, p3 = wid < 2 ? wid : wid + 2;
+    auto stage_weights = [&](const char* wsrc, unsigned soff, int slot) {
+#pragma unroll
+        for (int k = 0; k < WPW; ++k) {
+            const int i = wid + NW * k;
+            if (i < WPT) dma16(wsrc, wvoff0 + rfl(soff + (unsigned)k * 4096u), lds_base + slot * BTAP + i * 1024);
+        }
+    };
+    const int nch0 = a.Cin / 32, nch1 = a.x2 ? a.Cin2 / 32 : 0;
+    const unsigned wtile = (unsigned)a.Cout * ROWB, wtap = (unsigned)nch0 * wtile;
+    for (int q = wid; q < apieces; q += NW) patch_piece(a.x, porg0, xrow0, q, 0);
+    stage_weights(a.w, 0, 0);
+    stage_weights(a.w, wtap, 1);
+
+    // per-lane LDS offsets (within a patch buffer) of this lane's four A rows for every tap, as 16-bit halves
+    constexpr int NAP = (NA * TAPS + 1) / 2;
+    unsigned apk[NAP];
+    {
+#pragma unroll
+        for (int k = 0; k < NAP; ++k) apk[k] = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + wid * 64 + i * TR + lr;
+            const bool mv = m < g.M;
+            const Pix px = row_to_pixel<POOL>(g, mv ? m : 0);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                const bool ok = mv && tap_valid(g, px.h, px.w, dy, dx);
+                const int row = px.p + dy * g.W + dx - plo;
+                const unsigned ad = ok ? row * ROWB + 16 * (lh ^ swz_tr<SLOTS, TR>(row)) : AROWS * ROWB + 16 * lh;
+                apk[(i * TAPS + t) >> 1] |= ad << (16 * ((i * TAPS + t) & 1));
+            }
+        }
+    }
+    auto aaddr = [&](int i, int t) -> int {
+        const int idx = i * TAPS + t;
+        return (idx & 1) ? (int)(apk[idx >> 1] >> 16) : (int)(apk[idx >> 1] & 0xffffu);
+    };
+    const int baddr0 = lr * ROWB + 16 * (lh ^ swz_tr<SLOTS, TR>(lr));    // B tile j: + j * 16 rows (a multiple of the swizzle period)
+
+    // accumulators: zero, or (swapped operands: lane = pixel, registers = four consecutive channels) the BN shift of the register's channel
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if constexpr (SWAPC) {
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n0 + j * TR + 4 * lh);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) acc[i][j] = sh;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto mma_ab = [&](const uint4& xa, const uint4& wb, f32x4& c) {
+        if constexpr (SWAPC) mma16(wb, xa, c); else mma16(xa, wb, c);
+    };
+    int after_last_is_center = 0;
+    auto rd_a = [&](int i, int aoff, int tap) -> uint4 {
+        const int ad = tap >= 0 ? aaddr(i, tap)
+                                : (int)vsel(after_last_is_center ? ~0ull : 0ull, (unsigned)aaddr(i, CENTER), (unsigned)aaddr(i, 0));
+        return *reinterpret_cast<const uint4*>(smem + aoff + ad);
+    };
+    auto rd_b = [&](int j, int boff) -> uint4 { return *reinterpret_cast<const uint4*>(smem + boff + j * (TR * ROWB) + baddr0); };
+
+    uint4 fa[NA], ring[4];
+    // One step on the fragments in registers (RO = 0 or 2: b_j of this step sits in ring slot (j + RO) % 4):
+    //   P0   a0b0 a0b1 a1b0 a1b1 | a2b0 a2b1 a3b0 a3b1      reads: b2 in front, b3 in the middle
+    //   G2 .. G7   a0..a3 x b_G                             reads: b_{G+2} in front of each           (MID between G4 and G5)
+    //   P8   a0b8 a0b9 | a1b8 a1b9 | a2b8 a2b9 | a3b8 a3b9  reads (NEXT): b'_0 b'_1 in front, a'_i behind a_i's last MFMA, INTO a_i's registers
+    // so ONE A set serves: a fragment of the next step lands >= 6 MFMAs (96 matrix-pipe cycles) before its first use, every B fragment
+    // >= 8 (128).  The next step's b'_0 / b'_1 go to the slots of b6 / b7, i.e. the next step runs with RO ^ 2.
+    // DMA slots: in front of G5, G6, G7 and P8.
+    auto pair0 = [&](auto ro_tag, int boff) {
+        constexpr int RO = decltype(ro_tag)::value;
+        if constexpr (SUBREG_WIDE_DIAG != 2) {
+            ring[(2 + RO) & 3] = rd_b(2, boff);
+            mma_ab(fa[0], ring[(0 + RO) & 3], acc[0][0]); mma_ab(fa[0], ring[(1 + RO) & 3], acc[0][1]);
+            mma_ab(fa[1], ring[(0 + RO) & 3], acc[1][0]); mma_ab(fa[1], ring[(1 + RO) & 3], acc[1][1]);
+            ring[(3 + RO) & 3] = rd_b(3, boff);
+            mma_ab(fa[2], ring[(0 + RO) & 3], acc[2][0]); mma_ab(fa[2], ring[(1 + RO) & 3], acc[2][1]);
+            mma_ab(fa[3], ring[(0 + RO) & 3], acc[3][0]); mma_ab(fa[3], ring[(1 + RO) & 3], acc[3][1]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto group = [&](auto g_tag, auto ro_tag, int boff, auto&& dma) {
+        constexpr int G = decltype(g_tag)::value, RO = decltype(ro_tag)::value;
+        if (SUBREG_WIDE_DIAG != 1) dma(g_tag);
+        if constexpr (SUBREG_WIDE_DIAG != 2) {
+            ring[(G + 2 + RO) & 3] = rd_b(G + 2, boff);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) mma_ab(fa[i], ring[(G + RO) & 3], acc[i][G]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NA, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto pair8 = [&](auto ro_tag, auto next_tag, int n_aoff, auto ntap_tag, int n_boff, auto&& dma) {
+        constexpr int RO = decltype(ro_tag)::value, NTAP = decltype(ntap_tag)::value;
+        constexpr bool NEXT = decltype(next_tag)::value;
+        if (SUBREG_WIDE_DIAG != 1) dma(IC<8>{});
+        if constexpr (SUBREG_WIDE_DIAG != 2) {
+            if constexpr (NEXT) {
+                ring[(2 + RO) & 3] = rd_b(0, n_boff);
+                ring[(3 + RO) & 3] = rd_b(1, n_boff);
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                mma_ab(fa[i], ring[(0 + RO) & 3], acc[i][8]);             // b8: slot (8 + RO) % 4
+                mma_ab(fa[i], ring[(1 + RO) & 3], acc[i][9]);
+                if constexpr (NEXT) fa[i] = rd_a(i, n_aoff, NTAP);
+            }
+            if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto no_dma = [](auto) {};
+    // the first step's fragments: a_0 .. a_3, b_0, b_1
+#pragma unroll
+    for (int i = 0; i < NA; ++i) fa[i] = rd_a(i, A_BASE, 0);
+    ring[0] = rd_b(0, 0);
+    ring[1] = rd_b(1, 0);
+
+    auto mid_sync = [&](bool drain_lds, int do_wait = 0) {
+        unsigned long long q0 = 0, q1 = 0;
+        if (STAMPS) q0 = __builtin_amdgcn_s_memtime();
+        if (drain_lds) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (do_wait == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (STAMPS) q1 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (STAMPS) { const unsigned long long q2 = __builtin_amdgcn_s_memtime(); t_wait += q1 - q0; t_bar += q2 - q1; }
+    };
+    if (STAMPS) t_loop = __builtin_amdgcn_s_memtime();
+
+    // ---- phase 0: the convolution chunks, nine steps each
+    const unsigned wl0 = lds_base + (unsigned)wid * 1024u;
+    for (int c = 0; c < nch0; ++c) {
+        const int aoff = A_BASE + (c & 1) * ABUF;
+        const int naoff = A_BASE + ((c + 1) & 1) * ABUF;
+        const bool last_c = c + 1 >= nch0;
+        const bool to_x2 = last_c && nch1 > 0;
+        const char* const psrc = to_x2 ? a.x2 : a.x;
+        const unsigned pxrow = to_x2 ? xrow1 : xrow0;
+        const unsigned puoff = to_x2 ? porg1 : porg0 + (unsigned)(last_c ? c : c + 1) * (32 * ELEM);
+        const unsigned plds = lds_base + A_BASE + ((c + 1) & 1) * ABUF;
+        after_last_is_center = last_c ? 1 : 0;
+        unsigned cw = (unsigned)c * wtile;
+        asm volatile("" : "+s"(cw));
+        const int lim = prow - 1 - (apieces - 1) * RPP;
+        const unsigned pv = __umul24((unsigned)prl, pxrow) + swzo;
+        const unsigned gs = (unsigned)RPP * pxrow;
+        const unsigned l2 = vsel(s2mask, wvoff0, pv);                     // (S2 as a weight piece: piece wid + 8, the 8192 goes into the scalar part)
+        auto step = [&](auto tap_tag) {
+            constexpr int TAP = decltype(tap_tag)::value;
+            constexpr int SL = TAP % NWB, RO = 2 * (TAP & 1);            // (a chunk starts with b_0, b_1 in slots 0, 1)
+            constexpr bool SAME = TAP < 8;
+            constexpr int NT = SAME ? TAP + 1 : -1;
+            const int boff = SL * BTAP, nboff = ((TAP + 1) % NWB) * BTAP, n_aoff = SAME ? aoff : naoff;
+            pair0(IC<RO>{}, boff);
+            group(IC<2>{}, IC<RO>{}, boff, no_dma);
+            group(IC<3>{}, IC<RO>{}, boff, no_dma);
+            group(IC<4>{}, IC<RO>{}, boff, no_dma);
+            mid_sync(false, (TAP >= 1 && TAP - 1 <= PLAST) ? 1 : 0);
+            constexpr int WSL = (TAP + 2) % NWB;
+            const char* wsrc = a.w;
+            unsigned woff = cw;
+            if constexpr (TAP + 2 <= 8) {
+                woff += (unsigned)(TAP + 2) * wtap;
+            } else {
+                constexpr int T2 = TAP + 2 - 9;
+                if (!last_c) woff += (unsigned)T2 * wtap + wtile;
+                else if (T2 < nch1) { wsrc = a.w2; woff = (unsigned)T2 * wtile; }
+                else woff = 0;
+            }
+            int q0 = TAP * NPP;
+            asm volatile("" : "+s"(q0));
+            auto dma = [&](auto g_tag) {
+                constexpr int gq = decltype(g_tag)::value - 5;            // slots in front of groups 5 .. 8
+                if constexpr (gq == 0) {                                  // S2
+                    int q = q0 + p2;
+                    q = q < apieces - 2 ? q : apieces - 2;
+                    const unsigned so = ssel(s2w, woff + 8192u, puoff + (unsigned)q * gs);
+                    const unsigned la = ssel(s2w, wl0 + WSL * BTAP + 8 * 1024, plds + (unsigned)q * 1024u);
+                    dma16(ssel_ptr(s2w, wsrc, psrc), l2 + so, la);
+                } else if constexpr (gq == 1 || gq == 2) {                // W0, W1
+                    dma16(wsrc, wvoff0 + rfl(woff + (unsigned)(gq - 1) * 4096u), wl0 + WSL * BTAP + (gq - 1) * 4096);
+                } else if constexpr (gq == 3 && TAP < PLAST) {            // S3: a regular patch piece
+                    int q = q0 + p3;
+                    q = q < apieces - 2 ? q : apieces - 2;
+                    dma16(psrc, pv + rfl(puoff + (unsigned)q * gs), plds + (unsigned)q * 1024u);
+                } else if constexpr (gq == 3 && TAP == PLAST) {           // S3: the last patch piece
+                    // (tail rows clamped to the patch's last row; made here, once per chunk, instead of held in a register)
+                    int prl_o = prl;
+                    asm volatile("" : "+v"(prl_o));
+                    const unsigned pv_last = __umul24((unsigned)(prl_o < lim ? prl_o : lim), pxrow) + swzo;
+                    dma16(psrc, pv_last + rfl(puoff + (unsigned)(apieces - 1) * gs), plds + (unsigned)(apieces - 1) * 1024u);
+                }
+            };
+            group(IC<5>{}, IC<RO>{}, boff, dma);
+            group(IC<6>{}, IC<RO>{}, boff, dma);
+            group(IC<7>{}, IC<RO>{}, boff, dma);
+            pair8(IC<RO>{}, std::true_type{}, n_aoff, IC<NT>{}, nboff, dma);
+        };
+        step(IC<0>{});
+        step(IC<1>{});
+        step(IC<2>{});
+        step(IC<3>{});
+        step(IC<4>{});
+        step(IC<5>{});
+        step(IC<6>{});
+        step(IC<7>{});
+        step(IC<8>{});
+        ring[0] = ring[2];                                                // step 8 (RO = 0) left b'_0, b'_1 in slots 2, 3: the next chunk
+        ring[1] = ring[3];                                                // (or the first shortcut step) starts with RO = 0 again (8 moves per 360 MFMAs)
+    }
+    // ---- phase 1: the fused shortcut GEMM's chunks, ONE step each (centre tap, RO = 0); the next chunk's patch is staged
+    //      at MID and waited for at the end of the step, where the next step's first fragments are read (not pipelined deeper)
+    for (int d = 0; d < nch1; ++d) {
+        const int s = 9 * nch0 + d;
+        const int naoff = A_BASE + ((nch0 + d + 1) & 1) * ABUF;
+        const int boff = (s % NWB) * BTAP, nboff = ((s + 1) % NWB) * BTAP;
+        const bool more = d + 1 < nch1;
+        pair0(IC<0>{}, boff);
+        group(IC<2>{}, IC<0>{}, boff, no_dma);
+        group(IC<3>{}, IC<0>{}, boff, no_dma);
+        group(IC<4>{}, IC<0>{}, boff, no_dma);
+        mid_sync(true);                                                   // (the patch buffer written below is the one step s-1 read)
+        if (SUBREG_WIDE_DIAG != 1) {
+            if (d + 2 < nch1) stage_weights(a.w2, (unsigned)(d + 2) * wtile, (s + 2) % NWB);
+            if (more) for (int q = wid; q < apieces; q += NW) patch_piece(a.x2, porg1 + (unsigned)(d + 1) * (32 * ELEM), xrow1, q, (nch0 + d + 1) & 1);
+        }
+        group(IC<5>{}, IC<0>{}, boff, no_dma);
+        group(IC<6>{}, IC<0>{}, boff, no_dma);
+        group(IC<7>{}, IC<0>{}, boff, no_dma);
+        pair8(IC<0>{}, std::false_type{}, 0, IC<0>{}, 0, no_dma);
+        if (more) {
+            mid_sync(false);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) fa[i] = rd_a(i, naoff, CENTER);
+            ring[0] = rd_b(0, nboff);
+            ring[1] = rd_b(1, nboff);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    struct EpilogueStamp {
+        float* dst;
+        unsigned long long t0;
+        __device__ ~EpilogueStamp() { if (dst) *dst = (float)(__builtin_amdgcn_s_memtime() - t0); }
+    } epi_stamp{nullptr, 0};
+    if (STAMPS && a.stats && lane == 0) {
+        const unsigned long long n = __builtin_amdgcn_s_memtime(), rn = __builtin_amdgcn_s_memrealtime();
+        float* d = a.stats + ((size_t)blockIdx.x * NW + wid) * 8;
+        d[0] = (float)(t_loop - t_begin); d[1] = (float)(n - t_loop); d[2] = 0.f; d[3] = (float)(n - t_loop) - (float)t_wait - (float)t_bar;
+        d[4] = (float)t_wait; d[5] = (float)t_bar; d[6] = (float)(rn - r_begin);
+        epi_stamp.dst = d + 7;
+        epi_stamp.t0 = n;
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    T* const y = reinterpret_cast<T*>(a.y);
+    const bool full = m0 + TM <= g.M;
+    constexpr int RS = TN * ELEM + 16, VPR = TN * ELEM / 16;
+    char* const slab = smem + wid * (32 * RS);
+    static_assert(NW * 32 * RS <= A_BASE + 2 * ABUF, "slabs reuse the staging LDS");
+    const float slope = a.act ? 0.1f : 1.f;
+    if constexpr (SWAPC) {
+        // lane = pixel (row lr of A tile i), registers 0..3 of tile (i, j) = channels 16 j + 4 lh + {0..3}
+        auto lrelu_pack = [&](const f32x4& cfr) -> uint2 {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = cfr[e] * slope;
+                asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(cfr[e]), "v"(t));
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+            return __builtin_bit_cast(uint2, o);
+        };
+        if (full) {
+            constexpr int NV = 32 * VPR;
+            char* const wbase = slab + lr * RS + 4 * lh * ELEM;
+#pragma unroll
+            for (int ib = 0; ib < NA / 2; ++ib) {                         // 32 rows at a time through the wave's slab
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        *reinterpret_cast<uint2*>(wbase + ii * TR * RS + j * TR * ELEM) = lrelu_pack(acc[2 * ib + ii][j]);
+                const int mrow0 = m0 + wid * 64 + ib * 32;
+                char* const ybase = a.y + ((size_t)mrow0 * a.Cout + n0) * ELEM;
+#pragma unroll
+                for (int v0 = 0; v0 < NV; v0 += 64) {
+                    const int v = v0 + lane;
+                    const int row = v / VPR, c16 = v % VPR;
+                    const uint4 val = *reinterpret_cast<const uint4*>(slab + row * RS + c16 * 16);
+                    *reinterpret_cast<uint4*>(ybase + (size_t)row * a.Cout * ELEM + c16 * 16) = val;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int m = m0 + wid * 64 + i * TR + lr;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int n = n0 + j * TR + 4 * lh;
+                    if (m < g.M) *reinterpret_cast<uint2*>(y + (size_t)m * a.Cout + n) = lrelu_pack(acc[i][j]);
+                }
+            }
+        }
+    } else {
+        // pixel-major: column = lane % 16 (channel of tile j), registers 0..3 = rows 4 lh + {0..3} of A tile i = ONE 2x2 window
+        if (full) {
+            constexpr int NV = 16 * VPR;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float sh = s_shift[j * TR + lr];
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const f32x4& cfr = acc[i][j];
+                    float best = fmaxf(fmaxf(cfr[0], cfr[1]), fmaxf(cfr[2], cfr[3])) + sh;
+                    best = fmaxf(best, best * slope);                     // monotone: lrelu(max) == max(lrelu)
+                    *reinterpret_cast<T*>(slab + (4 * i + lh) * RS + (j * TR + lr) * ELEM) = (T)best;
+                }
+            }
+            const int win0 = (m0 + wid * 64) >> 2;                        // first pooled pixel of this wave
+            char* const ybase = a.y + ((size_t)win0 * a.Cout + n0) * ELEM;
+#pragma unroll
+            for (int v0 = 0; v0 < NV; v0 += 64) {
+                const int v = v0 + lane;
+                const int row = v / VPR, c16 = v % VPR;
+                const uint4 val = *reinterpret_cast<const uint4*>(slab + row * RS + c16 * 16);
+                *reinterpret_cast<uint4*>(ybase + (size_t)row * a.Cout * ELEM + c16 * 16) = val;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int n = n0 + j * TR + lr;
+                const float sh = s_shift[j * TR + lr];
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int m = m0 + wid * 64 + i * TR + 4 * lh;
+                    if (m < g.M) {
+                        const f32x4& cfr = acc[i][j];
+                        float best = fmaxf(fmaxf(cfr[0], cfr[1]), fmaxf(cfr[2], cfr[3])) + sh;
+                        best = fmaxf(best, best * slope);
+                        y[(size_t)(m >> 2) * a.Cout + n] = (T)best;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------- host side
 namespace {
 
@@ -611,6 +1066,20 @@ int launch_wide(const ConvArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, a);
     return launch_status();
 }
+
+template <bool POOL, int AROWS>
+int launch_wide16(const ConvArgs& a, hipStream_t stream) {
+    constexpr int TM = 256, TN = 160;
+    const size_t lds = 3 * (size_t)TN * 64 + 2 * (size_t)(AROWS + 1) * 64 + TN * sizeof(float);
+    auto kern = conv_wide16_kernel<POOL, AROWS>;
+    static std::atomic<unsigned long long> lds_set{0};
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set)) return rc;
+    dim3 grid(((a.g.M + TM - 1) / TM) * (a.Cout / TN));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    return launch_status();
+}
+// MFMA shape of the 256-row tiling (SUBREG_WIDE_TR: 16 = conv_wide16_kernel, 32 = conv_wide_kernel<2>)
+int wide_tr() { static const int v = [] { const char* e = getenv("SUBREG_WIDE_TR"); return e && *e ? atoi(e) : 16; }(); return v == 32 ? 32 : 16; }
 
 // Two tilings of the same kernel body (SUBREG_WIDE_MI picks; measurements):
 //   MI = 3: 96 x 160 wave tiles, 384 x 160 tiles, ONE workgroup per CU (a wave owns its SIMD's 512 registers)
@@ -656,6 +1125,7 @@ bool conv_wide_preferred(const ConvArgs& a, bool pool) {
 
 int conv_wide(const ConvArgs& a, bool pool, hipStream_t stream) {
     if (!conv_wide_supported(a, pool)) return SUBREG_EUNSUPPORTED;
+    if (wide_mi() == 2 && wide_tr() == 16) return pool ? launch_wide16<true, AR_POOL2>(a, stream) : launch_wide16<false, AR_LIN2>(a, stream);
     if (wide_mi() == 2) return pool ? launch_wide<2, 4, 1, true, AR_POOL2, 2>(a, stream) : launch_wide<2, 4, 1, false, AR_LIN2, 2>(a, stream);
     return pool ? launch_wide<3, 4, 1, true, AR_POOL3, 1>(a, stream) : launch_wide<3, 4, 1, false, AR_LIN3, 1>(a, stream);
 }

@@ -550,6 +550,62 @@ extern "C" int subreg_random_keep_mask(unsigned char* keep, long long n, unsigne
     return launch_status();
 }
 
+// The same kernel with its seed and drop probability read from DEVICE memory when the launch RUNS: a captured hipGraph replays the launch with
+// fresh randomness (and DropBlock's step-dependent gamma, :294-296) after the host has refreshed *param with subreg_mask_params_set.
+__global__ __launch_bounds__(256) void random_keep_dev_kernel(unsigned char* __restrict__ out, size_t n, const subreg_mask_param* __restrict__ param,
+                                                              unsigned int* __restrict__ kept_count) {
+    const unsigned long long seed = param->seed;
+    const float p_drop = param->p_drop;
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    unsigned kept = 0;
+    if (i0 < n) {
+        unsigned char b[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float u = (mix32(seed * 0x9E3779B97F4A7C15ULL + i0 + k) & 0xFFFFFF) * (1.0f / 16777216.0f);
+            b[k] = (i0 + k < n && u >= p_drop) ? 1 : 0;
+            kept += b[k];
+        }
+        if (i0 + 16 <= n && (reinterpret_cast<size_t>(out) & 15) == 0) {
+            *reinterpret_cast<uint4*>(out + i0) = *reinterpret_cast<const uint4*>(b);
+        } else {
+            for (int k = 0; k < 16 && i0 + k < n; ++k) out[i0 + k] = b[k];
+        }
+    }
+    if (kept_count) {
+        __shared__ unsigned wsum[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = kept;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(kept_count, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    }
+}
+
+extern "C" int subreg_random_keep_mask_dev(unsigned char* keep, long long n, const subreg_mask_param* param, unsigned int* kept_count,
+                                           void* stream) {
+    SUBREG_CHECK_ARG(keep && n > 0 && param);
+    hipLaunchKernelGGL(random_keep_dev_kernel, dim3((unsigned)(((size_t)n + 4095) / 4096)), dim3(256), 0, (hipStream_t)stream, keep,
+                       (size_t)n, param, kept_count);
+    return launch_status();
+}
+
+struct MaskParamPack { subreg_mask_param v[SUBREG_MASK_PARAMS_MAX]; };
+__global__ void mask_params_set_kernel(subreg_mask_param* __restrict__ dst, int n, const MaskParamPack pack) {
+    const int i = threadIdx.x;
+    if (i < n) dst[i] = pack.v[i];
+}
+
+// host values travel as a kernel ARGUMENT (no pinned staging buffer whose reuse would have to be ordered against the stream)
+extern "C" int subreg_mask_params_set(subreg_mask_param* params_dev, int n, const subreg_mask_param* host_values, void* stream) {
+    SUBREG_CHECK_ARG(params_dev && host_values && n > 0 && n <= SUBREG_MASK_PARAMS_MAX);
+    MaskParamPack pack;
+    for (int i = 0; i < SUBREG_MASK_PARAMS_MAX; ++i) pack.v[i] = host_values[i < n ? i : n - 1];
+    for (int i = 0; i < n; ++i) SUBREG_CHECK_ARG(pack.v[i].p_drop >= 0.f && pack.v[i].p_drop < 1.f);
+    hipLaunchKernelGGL(mask_params_set_kernel, 1, 64, 0, (hipStream_t)stream, params_dev, n, pack);
+    return launch_status();
+}
+
 // DropBlock's rescale factor countM / count_ones (resnet_language.py:318-323) from the device-side counter of the mask kernels:
 // (float)(numel / max(count, 1)) in double like the host expression it replaces - without the host reading the counter
 __global__ void mask_scale_kernel(const unsigned int* __restrict__ count, double numel, float* __restrict__ scale) {

@@ -16,7 +16,7 @@ F32, BF16 = 0, 1
 CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
 CONV_KERNEL_GENERAL, CONV_KERNEL_WIDE = 256, 512   # kernel selection of subreg_conv_fwd (Cout % 160 == 0): conv_fwd.hip / conv_wide.hip
 FWD_TRAIN = 1
-ABI_VERSION = 13
+ABI_VERSION = 14
 MAX_QUERY_SETS = 32                          # SUBREG_MAX_QUERY_SETS
 
 c_void_p, c_int, c_float, c_longlong = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -55,6 +55,13 @@ class TrainDesc(C.Structure):
                 ("zero_shift", c_void_p), ("grad_out_dump", C.POINTER(c_void_p)),
                 ("side_stream", c_void_p), ("events", c_void_p * 6), ("dr_alt", c_void_p), ("bn_partial_side", c_void_p),
                 ("stats_side", c_void_p), ("splitk_ws", c_void_p), ("splitk_ws_floats", c_longlong), ("eval_mode", c_int)]
+
+
+class MaskParam(C.Structure):
+    _fields_ = [("seed", C.c_ulonglong), ("p_drop", c_float), ("reserved", C.c_uint)]
+
+
+MASK_PARAMS_MAX = 16                          # SUBREG_MASK_PARAMS_MAX
 
 
 class LoopState(C.Structure):
@@ -127,6 +134,8 @@ SIGNATURES = {
     "subreg_mask_scale": (_I, [_P, _L, _P, _P]),
     "subreg_mask_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_random_keep_mask": (_I, [_P, _L, C.c_ulonglong, _F, _P, _P]),
+    "subreg_random_keep_mask_dev": (_I, [_P, _L, _P, _P, _P]),
+    "subreg_mask_params_set": (_I, [_P, _I, _P, _P]),
     "subreg_dropblock_mask": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "subreg_avgpool": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "subreg_backbone_ws_bytes": (_L, [C.POINTER(BackboneDesc), _I, _I, _I]),

@@ -37,6 +37,8 @@ class HipBackbone:
                               # of workgroups, the other lanes' kernels fill the idle CUs (tools/bench_forward.py, graph replay,
                               # 2 lanes vs 1: +5.8 % at 250 images, +5.3 % at 500, +4.7 % at 750, +2.6 % at 1125; 3-4 lanes: less).
 
+    EVAL_LANE_MIN = int(os.environ.get("SUBREG_EVAL_LANE_MIN", "64"))   # images per lane below which a forward is not split
+
     def __init__(self, params, n_blocks=(1, 1, 2, 2), dtype="bf16", block_size=1):
         self.lib = _lib.load()
         self.params = params
@@ -222,11 +224,46 @@ class HipBackbone:
             self._blk[bi].mask_scale = 1.0
             self._blk[bi].mask_scale_dev = None
 
+    def mask_params(self, H, W):
+        """(seed, drop probability) of every block's free-running keep mask for the NEXT forward's counters (self.nbt as that forward
+        sees it): dropout's rate (:299), DropBlock's gamma (:294-296) or, for block_size > 1, the complement of the seeds' rate."""
+        out, h = [], H
+        for bi, (_name, _cin, _cout, stride, _ds, db) in enumerate(self.blocks):
+            h = h // stride
+            seed = int(torch.randint(0, 2 ** 62, (1,)))
+            if not db:
+                out.append((seed, DROP_RATE))
+            else:
+                gamma = float(dropblock_gamma(self.nbt[bi], h, self.block_size))
+                out.append((seed, gamma if self.block_size == 1 else 1.0 - gamma))
+        return out
+
+    def set_mask_params(self, H, W):
+        """Device-resident mask parameters (graph replay, train.GraphedStep): refresh them for the forward that follows."""
+        n = len(self.blocks)
+        if getattr(self, "_mask_params_dev", None) is None:
+            self._mask_params_dev = torch.zeros(2 * n, dtype=torch.int64, device=self.device)     # n records of 16 bytes
+        vals = (_lib.MaskParam * n)()
+        for i, (seed, p) in enumerate(self.mask_params(H, W)):
+            vals[i].seed, vals[i].p_drop = seed, min(max(p, 0.0), 0.999999)
+        _lib.check(self.lib.subreg_mask_params_set(_lib.ptr(self._mask_params_dev), n, C.cast(vals, C.c_void_p), _lib.stream_ptr()),
+                   "mask_params_set")
+
     def _prepare_masks(self, B, H, W, masks):
         """Keep masks of every block output (dropout :299 / DropBlock :311-325), uploaded as NHWC u8."""
         self._keep = []
         s = _lib.stream_ptr()
         h, w = H, W
+        # device-resident seeds / probabilities (self.use_mask_params, set by train.GraphedStep around its capture): the launches
+        # below then read them when they RUN, so a replayed graph draws fresh masks
+        pdev = getattr(self, "_mask_params_dev", None) if (getattr(self, "use_mask_params", False) and masks is None) else None
+
+        def random_keep(dst, n, bi, p, count):
+            if pdev is not None:
+                _lib.check(self.lib.subreg_random_keep_mask_dev(_lib.ptr(dst), n, pdev.data_ptr() + 16 * bi, count, s), "random_keep_mask_dev")
+            else:
+                _lib.check(self.lib.subreg_random_keep_mask(_lib.ptr(dst), n, int(torch.randint(0, 2 ** 62, (1,))), p, count, s),
+                           "random_keep_mask")
         # DropBlock's count_ones and the rescale factor numel / count_ones stay on the device (one counter and one float per
         # block), as in the reference (:318-323): reading them back cost two host synchronisations per training step
         counts = torch.zeros(len(self.blocks), dtype=torch.int32, device=self.device)
@@ -248,8 +285,7 @@ class HipBackbone:
             if not db:
                 scale = float(np.float32(1.0) / np.float32(1.0 - DROP_RATE))
                 if masks is None:
-                    _lib.check(self.lib.subreg_random_keep_mask(_lib.ptr(keep), n, int(torch.randint(0, 2 ** 62, (1,))),
-                                                                DROP_RATE, None, s), "random_keep_mask")
+                    random_keep(keep, n, bi, DROP_RATE, None)
                 else:
                     m = torch.from_numpy(masks.dropout_keep((B, cout, h, w), DROP_RATE)).to(self.device)
                     _lib.check(self.lib.subreg_mask_nchw_to_nhwc(_lib.ptr(m), _lib.ptr(keep), B, cout, h, w, 0, s), "mask")
@@ -258,8 +294,7 @@ class HipBackbone:
                 gamma = dropblock_gamma(self.nbt[bi], h, bs)
                 shape = (B, cout, h - (bs - 1), w - (bs - 1))
                 if masks is None and bs == 1:
-                    _lib.check(self.lib.subreg_random_keep_mask(_lib.ptr(keep), n, int(torch.randint(0, 2 ** 62, (1,))),
-                                                                float(gamma), _lib.ptr(counts[bi:]), s), "random_keep_mask")
+                    random_keep(keep, n, bi, float(gamma), _lib.ptr(counts[bi:]))
                     scale = device_scale(bi, n)
                 elif bs == 1:                                   # injected element mask (block_size 1)
                     bm = 1.0 - masks.bernoulli(shape, gamma)
@@ -274,8 +309,7 @@ class HipBackbone:
                         sample = torch.from_numpy(np.ascontiguousarray(masks.bernoulli(shape, gamma) != 0).astype(np.uint8)).to(self.device)
                     else:
                         sample = torch.empty(ns, dtype=torch.uint8, device=self.device)
-                        _lib.check(self.lib.subreg_random_keep_mask(_lib.ptr(sample), ns, int(torch.randint(0, 2 ** 62, (1,))),
-                                                                    float(1.0 - gamma), None, s), "random_keep_mask")   # 1 with probability gamma
+                        random_keep(sample, ns, bi, float(1.0 - gamma), None)   # 1 with probability gamma
                     _lib.check(self.lib.subreg_dropblock_mask(_lib.ptr(sample), _lib.ptr(keep), B, cout, h, w, bs, _lib.ptr(counts[bi:]), s),
                                "dropblock_mask")
                     scale = device_scale(bi, n)
@@ -291,6 +325,7 @@ class HipBackbone:
 
     # ------------------------------------------------------------------ forward
     GRAPH_EVAL = os.environ.get("SUBREG_GRAPH_EVAL", "1") != "0"      # forward_graphed(): replay cached hipGraphs (0: always eager)
+    GRAPH_CACHE = 6                                                   # shapes kept (least recently used goes first)
 
     def forward_graphed(self, x):
         """Eval-mode forward for callers that run the SAME shape again and again over a backbone that does not change (the
@@ -304,25 +339,47 @@ class HipBackbone:
             return self.forward(x)
         self.refresh()
         key = tuple(x.shape)
-        ent = self._graphs.get(key)
         tokens = (self._fold_token, self._ws_token)
-        if ent is not None and ent["graph"] is not None and ent["tokens"] != tokens:
-            ent = None                                            # weights re-packed or workspaces moved since the capture
+        # every captured entry whose weights were re-packed or whose workspaces moved since its capture goes, whatever its shape (each
+        # keeps a copy of its input and features alive: ~95 MB at 1125 images).  A replay may still be in flight on the caller's or
+        # a lane's stream: synchronise before a graph is destroyed, as IncrementalRunner does before graph.reset().
+        stale = [k for k, e in self._graphs.items() if e["graph"] is not None and e["tokens"] != tokens]
+        if stale:
+            torch.cuda.synchronize(self.device)
+            for k in stale:
+                del self._graphs[k]
+        ent = self._graphs.pop(key, None)
         if ent is None:
-            ent = self._graphs[key] = dict(calls=0, graph=None, x=None, feat=None, tokens=None)
+            ent = dict(calls=0, graph=None, x=None, feat=None, tokens=None, eager_only=False)
+            while len(self._graphs) >= self.GRAPH_CACHE:                  # least recently used first (dict order = use order)
+                old_key = next(iter(self._graphs))
+                if self._graphs[old_key]["graph"] is not None:
+                    torch.cuda.synchronize(self.device)
+                del self._graphs[old_key]
+        self._graphs[key] = ent                                           # (re-inserted: most recently used)
         ent["calls"] += 1
+        if ent["eager_only"] or (ent["graph"] is None and ent["calls"] < 2):
+            return self.forward(x, check_params=False)                    # first sight of a shape: eager (sizes the workspaces)
         if ent["graph"] is None:
-            if ent["calls"] < 2:
-                return self.forward(x, check_params=False)        # first sight of a shape: eager (sizes the workspaces)
             ent["x"] = torch.empty_like(x, memory_format=torch.contiguous_format)
             ent["feat"] = torch.empty(x.shape[0], self.out_dim, dtype=torch.float32, device=self.device)
             ent["x"].copy_(x)
             nbt_keep = list(self.nbt)
             torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.forward(ent["x"], out=ent["feat"], check_params=False)
-            self.nbt = nbt_keep                                   # (the capture pass launches nothing)
+            try:
+                g = torch.cuda.CUDAGraph()
+                # thread_local: HIP calls of OTHER host threads (a DataLoader's pin_memory thread) do not invalidate this capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.forward(ent["x"], out=ent["feat"], check_params=False)
+            except Exception as e:                                        # noqa: BLE001 - whatever broke the capture: this shape stays eager
+                import warnings
+                self.nbt = nbt_keep
+                ent.update(graph=None, x=None, feat=None, eager_only=True)
+                torch.cuda.synchronize(self.device)
+                warnings.warn("subreg_hip: eval forward of shape %s could not be captured as a hipGraph (%s: %s); it runs eagerly"
+                              % (key, type(e).__name__, e), RuntimeWarning, stacklevel=2)
+                return self.forward(x, check_params=False)
+            self.nbt = nbt_keep                                           # (the capture pass launches nothing)
             ent["graph"], ent["tokens"] = g, (self._fold_token, self._ws_token)
         else:
             ent["x"].copy_(x)
@@ -354,7 +411,7 @@ class HipBackbone:
         else:                                        # balanced chunks (1125 images -> 3 x 375, not 512 + 512 + 101)
             n_chunks = -(-B // self.MAX_EVAL_CHUNK)
             chunk = -(-B // n_chunks)
-        lanes = 1 if (train or return_stages) else max(1, min(int(self.EVAL_LANES), chunk // 64))
+        lanes = 1 if (train or return_stages) else max(1, min(int(self.EVAL_LANES), chunk // self.EVAL_LANE_MIN))
         if lanes > 1:
             assert not train, "train-mode forwards write BN statistics: lanes carry no stats buffer (desc.stats = None)"
             # eval mode, several lanes: sub-batch i of every chunk goes to lane i (its own stream + workspaces)

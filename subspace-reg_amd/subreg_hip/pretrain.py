@@ -20,7 +20,7 @@ import torch
 
 from . import checkpoint as ck
 from . import functional as HF
-from .train import SGD, Adam
+from .train import SGD, Adam, GraphedStep
 
 
 class AverageMeter(object):
@@ -152,28 +152,52 @@ def train(epoch, train_loader, model, criterion, optimizer, opt, lang_puller=Non
     batch_time, data_time, losses, top1, top5 = (AverageMeter() for _ in range(5))
     dev = next(model.parameters()).device
     counters = torch.zeros(2, dtype=torch.int32, device=dev)
+    # One process, one GPU: the whole step (forward, loss + accuracy counters, backward, optimiser step) is ONE hipGraph per batch
+    # shape and learning rate (train.GraphedStep; opt.hip_graph = False keeps the eager launches).  The stepper lives on the
+    # optimiser, so the graphs survive from epoch to epoch.
+    stepper = None
+    if world == 1 and grad_sync is None and getattr(opt, "hip_graph", True):
+        stepper = getattr(optimizer, "_subreg_graphed_step", None)
+        if stepper is None or stepper.model is not model:
+            def loss_fn(input, target, _model=model, _opt=opt, _lp=lang_puller):
+                output = _model(input)
+                stepper.counters.zero_()
+                loss = HF.cross_entropy(output, target, stepper.counters, 5)
+                if getattr(_opt, "label_pull", None) is not None and _lp is not None:   # :232-236
+                    loss = loss + _lp.loss1(_opt.label_pull, _lp(_model.classifier.weight), _model.classifier.weight)
+                return loss
+            stepper = optimizer._subreg_graphed_step = GraphedStep(model, optimizer, loss_fn)
+            stepper.counters = counters
     end = time.time()
     for idx, (input, target, *_rest) in enumerate(train_loader):
         data_time.update(time.time() - end)
         n_global = input.shape[0]
         input, target = shard_batch(input.float(), target, rank, world)
         input, target = input.to(dev), target.to(dev).long()
-        output = model(input)
-        loss, acc1, acc5 = _batch_metrics(output, target, counters)
-        if getattr(opt, "label_pull", None) is not None and lang_puller is not None:       # :232-236
-            loss = loss + lang_puller.loss1(opt.label_pull, lang_puller(model.classifier.weight), model.classifier.weight)
-        losses.update(loss.item(), input.size(0))
-        top1.update(acc1, input.size(0))
-        top5.update(acc5, input.size(0))
-        optimizer.zero_grad()
-        if world > 1:
-            # SUM over ranks of d(local mean * n_local / n_global) = d(global mean): DataParallel's gradient, no division after
-            (loss * (float(input.shape[0]) / float(n_global))).backward()
+        if stepper is not None:
+            loss = stepper(input, target)
+            c, n = stepper.counters.tolist(), float(target.shape[0])
+            acc1, acc5 = 100.0 * c[0] / n, 100.0 * c[1] / n
+            losses.update(loss.item(), input.size(0))
+            top1.update(acc1, input.size(0))
+            top5.update(acc5, input.size(0))
         else:
-            loss.backward()
-        if grad_sync is not None:
-            grad_sync.finish(optimizer.param_groups[0]["params"])
-        optimizer.step()
+            output = model(input)
+            loss, acc1, acc5 = _batch_metrics(output, target, counters)
+            if getattr(opt, "label_pull", None) is not None and lang_puller is not None:       # :232-236
+                loss = loss + lang_puller.loss1(opt.label_pull, lang_puller(model.classifier.weight), model.classifier.weight)
+            losses.update(loss.item(), input.size(0))
+            top1.update(acc1, input.size(0))
+            top5.update(acc5, input.size(0))
+            optimizer.zero_grad()
+            if world > 1:
+                # SUM over ranks of d(local mean * n_local / n_global) = d(global mean): DataParallel's gradient, no division after
+                (loss * (float(input.shape[0]) / float(n_global))).backward()
+            else:
+                loss.backward()
+            if grad_sync is not None:
+                grad_sync.finish(optimizer.param_groups[0]["params"])
+            optimizer.step()
         batch_time.update(time.time() - end)
         end = time.time()
         if idx % opt.print_freq == 0:

@@ -358,6 +358,10 @@ class SGD:
         hb._bind_pointers()
         _lib.check(lib.subreg_sgd_pack_train(C.byref(hb._desc), C.byref(stash.desc), _lib.ptr(base), _lib.ptr(stash.flat_grads), _lib.ptr(mom),
                                              self.lr, self.momentum, self.weight_decay, int(first), _lib.stream_ptr()), "sgd_pack_train")
+        # the raw forward copies are shared by every stash of this backbone, the dX copies are per stash: only THIS stash's are
+        # current now (tensor._version does not see the library's raw-pointer update, so the others must be told)
+        for other in hb.__dict__.get("_train_stashes", []):
+            other.opt_packed = None
         stash.opt_packed = conv_weight_versions(hb)
         done = {i for i, _p in conv}
         return [it for it in items if it[0] not in done]
@@ -440,3 +444,121 @@ class Adam:
             g = p.grad.contiguous().float()
             _lib.check(lib.subreg_adam(_lib.ptr(p.data), _lib.ptr(g), _lib.ptr(st[0]), _lib.ptr(st[1]), p.numel(), self.lr,
                                        self.betas[0], self.betas[1], self.eps, self.weight_decay, st[2], _lib.stream_ptr()), "adam")
+
+
+class GraphedStep:
+    """One pretraining step - forward, loss, zero_grad, backward, optimiser step (train_supervised.py:229-244) - captured as ONE
+    hipGraph per (input shapes, learning rate) and replayed: ~220 kernel launches on two streams become one graph launch (the eager
+    step's host enqueue is 2.7 ms of a 3.9 ms step at batch 64, profiles/r05_train_step.txt).
+
+        step = GraphedStep(model, optimizer, lambda x, y: criterion(model(x), y))
+        loss = step(x, y)            # a 0-dim tensor owned by the graph: read it (.item()) before the next call
+
+    `loss_fn(*inputs)` runs the model and returns the loss (or a tuple whose first element is the loss: the rest - logits,
+    accuracy counters - is returned with it; all are graph-owned).  What a replay does beside the graph launch: copy the inputs into
+    the graph's buffers, advance the host-side forward counters, and hand the masks' seeds and DropBlock's step-dependent gamma
+    (resnet_language.py:294-296) to the device (HipBackbone.set_mask_params: the captured mask kernels read them when they run).
+
+    The first `warmup` calls of a key run eagerly (they size the stash, create the optimiser's state and caches, and put the
+    fused optimiser step on its steady-state path); the next one captures.  Anything that fails to capture falls back to the
+    eager step for that key, with a RuntimeWarning - the eager step runs the same kernels.
+    A data-parallel run (HipBackbone.grad_stage_hook set) and injected mask sources stay eager.
+    """
+
+    def __init__(self, model, optimizer, loss_fn, warmup=2, max_graphs=4):
+        self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
+        self.warmup, self.max_graphs = max(int(warmup), 2), max_graphs
+        self.entries = {}                      # key -> dict(calls, graph, inputs, outputs, failed)
+        self.replays = 0
+
+    def _key(self, inputs):
+        groups = tuple((g["lr"],) for g in self.opt.param_groups)
+        hyper = (getattr(self.opt, "momentum", None), getattr(self.opt, "weight_decay", None), self.model.training)
+        return tuple((tuple(t.shape), t.dtype) for t in inputs) + groups + hyper
+
+    def _eager(self, inputs):
+        out = self.loss_fn(*inputs)
+        loss = out[0] if isinstance(out, tuple) else out
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        # The results are handed out DETACHED, so this step's autograd graph dies here.  A caller that keeps an eager step's loss
+        # (`loss = step(x, y)`) would otherwise keep its AccumulateGrad nodes alive; the next call's capture re-uses them, they
+        # belong to the stream of the eager forward (the default stream), the engine pulls that stream into the capture and
+        # hipStreamEndCapture crashes (measured: tools/graph_probe.py, PROBE_HOLD=1 - the reason torch's own recipe warms up on a
+        # side stream).  After backward() nothing can use the graph anyway.
+        if isinstance(out, tuple):
+            return tuple(t.detach() if isinstance(t, torch.Tensor) else t for t in out)
+        return out.detach()
+
+    def __call__(self, *inputs):
+        hb = self.model.hip_backbone()
+        key = self._key(inputs)
+        ent = self.entries.get(key)
+        if ent is None:
+            if len(self.entries) >= self.max_graphs:                     # a new learning rate / shape: the oldest entry goes
+                torch.cuda.synchronize()
+                self.entries.pop(next(iter(self.entries)))
+            ent = self.entries[key] = dict(calls=0, graph=None, inputs=None, outputs=None, failed=False)
+        ent["calls"] += 1
+        eager_only = (ent["failed"] or getattr(hb, "grad_stage_hook", None) is not None or self.model.mask_source is not None
+                      or not torch.is_grad_enabled())
+        if eager_only or (ent["graph"] is None and ent["calls"] <= self.warmup):
+            return self._eager(inputs)
+        x = inputs[0]
+        H, W = int(x.shape[2]), int(x.shape[3])
+        if ent["graph"] is None:
+            self._capture(ent, hb, inputs, H, W)
+            if ent["failed"]:
+                return self._eager(inputs)
+        # ---- replay
+        for dst, src in zip(ent["inputs"], inputs):
+            dst.copy_(src, non_blocking=True)
+        stash = ent["stash"]
+        from . import _lib
+        if stash.opt_packed is None or stash.opt_packed != conv_weight_versions(hb):
+            # somebody else moved the weights since this graph's last step (an eager step of another batch shape, a checkpoint
+            # load): the captured forward reads the packed copies as they are, so rebuild them first
+            hb._bind_pointers()
+            _lib.check(hb.lib.subreg_backbone_pack_train(C.byref(hb._desc), C.byref(stash.desc), _lib.stream_ptr()), "backbone_pack_train")
+        if self.model.training:
+            for i in range(len(hb.nbt)):
+                hb.nbt[i] += 1
+            hb.set_mask_params(H, W)
+        ent["graph"].replay()
+        self.replays += 1
+        hb._fold_versions = None                                           # running statistics and weights moved
+        for other in hb.__dict__.get("_train_stashes", []):
+            other.opt_packed = None
+        stash.opt_packed = conv_weight_versions(hb)                        # (what the captured optimiser step establishes)
+        return ent["outputs"]
+
+    def _capture(self, ent, hb, inputs, H, W):
+        import warnings
+        ent["inputs"] = [torch.empty_like(t, memory_format=torch.contiguous_format) for t in inputs]
+        for dst, src in zip(ent["inputs"], inputs):
+            dst.copy_(src)
+        nbt_keep = list(hb.nbt)
+        training = self.model.training
+        hb.use_mask_params = True
+        try:
+            if training:
+                # (creates the device records; the replay that follows the capture draws this step's seeds itself, from the same
+                # host generator state an eager step would have seen)
+                rng = torch.get_rng_state()
+                hb.set_mask_params(H, W)
+                torch.set_rng_state(rng)
+            torch.cuda.synchronize()
+            self.opt.zero_grad()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                out = self._eager(ent["inputs"])
+            ent["graph"], ent["outputs"], ent["stash"] = g, out, hb._train_stash
+        except Exception as e:                                            # noqa: BLE001 - any capture failure: run eagerly instead
+            ent["failed"], ent["graph"] = True, None
+            torch.cuda.synchronize()
+            warnings.warn("subreg_hip: the training step could not be captured as a hipGraph (%s: %s); running it eagerly"
+                          % (type(e).__name__, e), RuntimeWarning, stacklevel=3)
+        finally:
+            hb.use_mask_params = False
+            hb.nbt = nbt_keep                                             # (the capture pass launched nothing)

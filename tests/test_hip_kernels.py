@@ -663,6 +663,36 @@ def test_graphed_eval_forward_equals_eager_and_follows_weight_updates():
     for rep in range(3):
         assert torch.equal(hb.forward_graphed(big), want_big)
         assert torch.equal(hb.forward_graphed(xs[0]), want2)
+    # the cache is bounded (least recently used shape goes) and holds no entry captured under older weights / workspaces
+    for b in range(1, hb.GRAPH_CACHE + 4):
+        xb = _t(syn.make_images(20 + b, b, 84))
+        for rep in range(2):
+            hb.forward_graphed(xb)
+    assert len(hb._graphs) <= hb.GRAPH_CACHE
+    tokens = (hb._fold_token, hb._ws_token)
+    assert all(e["graph"] is None or e["tokens"] == tokens for e in hb._graphs.values())
+    # a capture that fails leaves the shape on the eager path (no retry every call), with a warning, and the right result
+    import warnings
+    x7 = _t(syn.make_images(77, 7, 84))
+    want7 = hb.forward(x7).clone()
+    hb.forward_graphed(x7)
+    real_forward, hit = hb.forward, []
+
+    def failing_forward(x, *a, out=None, **k):
+        if out is not None:                                # (the call inside the capture)
+            hit.append(1)
+            raise RuntimeError("injected capture failure")
+        return real_forward(x, *a, out=out, **k)
+    hb.forward = failing_forward
+    try:
+        with warnings.catch_warnings(record=True) as wl:
+            warnings.simplefilter("always")
+            assert torch.equal(hb.forward_graphed(x7), want7)
+            assert torch.equal(hb.forward_graphed(x7), want7)
+        assert len(hit) == 1 and any("could not be captured" in str(w.message) for w in wl)
+        assert hb._graphs[tuple(x7.shape)]["eager_only"]
+    finally:
+        hb.forward = real_forward
 
 
 def test_workspace_capacity_is_not_monotone_in_batch():

@@ -618,9 +618,10 @@ def _hip_stash_as_oracle_input(net, B, hw):
 
 # (84, 64): the batch bench.py's pretraining leg times (configs.py:124).  B = 128 (its second timed batch) runs the same kernel
 # selection as 64 and costs 9 minutes of NumPy oracle on the GPU box's host: not in the suite (SUBREG_TEST_B128=1 adds it).
+@pytest.mark.parametrize("replay", [False, True], ids=["eager", "graph_replay"])
 @pytest.mark.parametrize("case", [(32, 0), (84, 0), (84, 64)] + ([(84, 128)] if os.environ.get("SUBREG_TEST_B128") == "1" else []),
                          ids=["hw32_B8", "hw84_B6", "hw84_B64"] + (["hw84_B128"] if os.environ.get("SUBREG_TEST_B128") == "1" else []))
-def test_bf16_backward_from_its_own_forward_stash(case):
+def test_bf16_backward_from_its_own_forward_stash(case, replay):
     """bf16 is the dtype of BASELINE.json configs[2] / [4]: pin its BACKWARD kernels tightly.  The bf16 forward's own stash
     (raw conv outputs, activations, batch statistics, block outputs, keep masks - exactly what the HIP backward reads) goes into
     the oracle's backward (oracle/backward_ref.py::backward_from_stash, pinned on CPU against train_step and the reference's
@@ -640,8 +641,20 @@ def test_bf16_backward_from_its_own_forward_stash(case):
     x = torch.from_numpy(x_np).cuda()
     y = torch.from_numpy(labels).cuda()
     net.train()
-    loss = torch.nn.CrossEntropyLoss()(net(x), y)
-    loss.backward()
+    if replay:
+        # the step as ONE replayed hipGraph (train.GraphedStep): the stash and the gradients the THIRD call - a replay - leaves behind.
+        # Free-running device masks (an injected mask source keeps the step eager) and an optimiser that moves nothing (lr = 0,
+        # no decay), so the parameters the oracle reads are the ones the replayed forward used.
+        from subreg_hip.train import SGD, GraphedStep
+        net.mask_source = None
+        crit = torch.nn.CrossEntropyLoss()
+        stepper = GraphedStep(net, SGD(net.parameters(), lr=0.0, momentum=0.0, weight_decay=0.0), lambda a, b: crit(net(a), b))
+        for _ in range(4):
+            loss = stepper(x, y)
+        assert stepper.replays == 2
+    else:
+        loss = torch.nn.CrossEntropyLoss()(net(x), y)
+        loss.backward()
     torch.cuda.synchronize()
     stash = _hip_stash_as_oracle_input(net, B, hw)
     sd = {k: v.detach().float().cpu().numpy() for k, v in net.state_dict().items() if v.dtype.is_floating_point}
@@ -655,6 +668,95 @@ def test_bf16_backward_from_its_own_forward_stash(case):
         worst = max(worst, (name, l2), key=lambda t: t[1])
         assert l2 < 5e-2, ("bf16 backward vs the oracle on the same stash", name, l2)
     print("worst tensor:", worst)
+
+
+def _plain_net(dtype, dropblock=False, seed=71):
+    from subreg_hip.resnet_language import create_model
+    from test_hip_loop import make_opt
+    net = create_model("resnet18", 60, make_opt(hip_dtype=dtype, no_dropblock=not dropblock))
+    sd = syn.make_state_dict(seed)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    return net.cuda()
+
+
+@pytest.mark.parametrize("case", [("f32", 32, 8, False), ("bf16", 32, 8, True), ("bf16", 84, 64, False)],
+                         ids=["f32_hw32_B8", "bf16_hw32_B8_dropblock5", "bf16_hw84_B64"])
+def test_graphed_step_replays_the_eager_step_bit_for_bit(case):
+    """train.GraphedStep (the pretraining driver's step as ONE replayed hipGraph, train_supervised.py:229-244): six steps - two eager
+    warm-up calls, the capture + first replay, three more replays - against six eager steps from the same start, the same batches
+    and the same host generator state per step (the masks' seeds are drawn from it in the same order by both).  Dropout / DropBlock
+    masks (fresh every replay, DropBlock's gamma moving with the forward counter), batch statistics, running statistics, the two
+    backward streams, the fused SGD + re-pack: every parameter, buffer and loss must be IDENTICAL, so every parity statement about
+    the eager step (reference goldens, stash-fed oracle backward) holds for the replayed one."""
+    from subreg_hip.train import SGD, GraphedStep
+    dtype, hw, B, dropblock = case
+    crit = torch.nn.CrossEntropyLoss()
+    xs = [torch.from_numpy(syn.make_images(300 + i, B, hw)).cuda() for i in range(3)]
+    ys = [torch.from_numpy(np.random.RandomState(400 + i).randint(0, 60, B)).cuda() for i in range(3)]
+    results = []
+    for graphed in (False, True):
+        net = _plain_net(dtype, dropblock).train()
+        opt = SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+        stepper = GraphedStep(net, opt, lambda a, b, _n=net: crit(_n(a), b)) if graphed else None
+        losses = []
+        for i in range(6):
+            torch.manual_seed(1000 + i)
+            if i == 4:
+                opt.lr = 0.02                          # a learning-rate change: a second graph (two eager calls, then its capture)
+            if graphed:
+                loss = stepper(xs[i % 3], ys[i % 3])
+            else:
+                loss = crit(net(xs[i % 3]), ys[i % 3])
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            losses.append(float(loss.item()))
+        torch.cuda.synchronize()
+        if graphed:
+            assert stepper.replays == 2 and not any(e["failed"] for e in stepper.entries.values()), (stepper.replays, stepper.entries)
+        sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        results.append((losses, sd, list(net.hip_backbone().nbt)))
+    (la, sa, na), (lb, sb, nb) = results
+    assert la == lb, (la, lb)
+    assert na == nb
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), ("state after six steps", k, float((sa[k].float() - sb[k].float()).abs().max()))
+
+
+def test_graphed_step_interleaved_with_another_batch_shape_repacks_its_weights():
+    """A stash's dX weight copies are per stash; the raw forward copies are shared.  Steps of ANOTHER batch shape between two steps of
+    a shape (the short last batch of an epoch) move the weights under the first shape's stash: its next step - eager or replayed -
+    must rebuild them (train.SGD._fused_conv_step tells the other stashes; GraphedStep re-packs before the replay).  Compared
+    with a run whose stashes are dropped before every step (everything re-packed from the parameters)."""
+    from subreg_hip.train import SGD, GraphedStep
+    crit = torch.nn.CrossEntropyLoss()
+    shapes = [8, 8, 8, 5, 8, 5, 8, 8]
+    xs = {b: torch.from_numpy(syn.make_images(500 + b, b, 32)).cuda() for b in (5, 8)}
+    ys = {b: torch.from_numpy(np.random.RandomState(600 + b).randint(0, 60, b)).cuda() for b in (5, 8)}
+    finals = []
+    for mode in ("fresh", "eager", "graphed"):
+        net = _plain_net("f32").train()
+        opt = SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+        stepper = GraphedStep(net, opt, lambda a, b, _n=net: crit(_n(a), b)) if mode == "graphed" else None
+        for i, b in enumerate(shapes):
+            torch.manual_seed(2000 + i)
+            if mode == "fresh":
+                for st in net.hip_backbone().__dict__.get("_train_stashes", []):
+                    st.opt_packed = None
+            if stepper is not None:
+                stepper(xs[b], ys[b])
+            else:
+                loss = crit(net(xs[b]), ys[b])
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+        torch.cuda.synchronize()
+        if stepper is not None:
+            assert stepper.replays >= 3
+        finals.append({k: v.detach().clone() for k, v in net.state_dict().items()})
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), ("eager, interleaved shapes", k)
+        assert torch.equal(finals[0][k], finals[2][k]), ("graphed, interleaved shapes", k)
 
 
 def test_adam_step_matches_torch_optim_adam():

@@ -54,6 +54,7 @@ def test_struct_layouts_match_c():
     # sizes computed by hand from include/subreg_hip.h on LP64
     assert ctypes.sizeof(_lib.ConvDesc) == 9 * 8 + 5 * 4 + 4
     assert ctypes.sizeof(_lib.LoopState) == 20
+    assert ctypes.sizeof(_lib.MaskParam) == 16 and _lib.MaskParam.p_drop.offset == 8     # subreg_mask_param
     assert ctypes.sizeof(_lib.BlockDesc) == 4 * ctypes.sizeof(_lib.ConvDesc) + 8 + 8 + 8 + 8 + 8 + 8     # ... + mask_scale_dev
     assert _lib.StepDesc.weight.offset == 32 and _lib.StepDesc.n_base.offset == 72
     # offsetof(subreg_step_desc, exp_avg_sq / bias / bias_base), sizeof: gcc on include/subreg_hip.h

@@ -14,7 +14,7 @@ import torch         # noqa: E402
 
 from subreg_hip import synthetic as syn                 # noqa: E402
 from subreg_hip.resnet_language import create_model     # noqa: E402
-from subreg_hip.train import SGD                        # noqa: E402
+from subreg_hip.train import SGD, GraphedStep           # noqa: E402
 from types import SimpleNamespace                       # noqa: E402
 
 
@@ -24,10 +24,13 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--host-time", action="store_true", help="also print the host-side enqueue time of a step")
+    ap.add_argument("--graph", action="store_true", help="run the step as one replayed hipGraph (train.GraphedStep)")
+    ap.add_argument("--dropblock", action="store_true", help="DropBlock with block_size 5 (no --no_dropblock)")
+    ap.add_argument("--randomize-bn", action="store_true", help="random BatchNorm parameters / running statistics")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    net = create_model("resnet18", 60, SimpleNamespace(no_dropblock=True, linear_bias=False, hip_dtype=a.dtype))
-    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in syn.make_state_dict(1, randomize_bn=False).items()})
+    net = create_model("resnet18", 60, SimpleNamespace(no_dropblock=not a.dropblock, linear_bias=False, hip_dtype=a.dtype))
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in syn.make_state_dict(1, randomize_bn=a.randomize_bn).items()})
     net = net.to(dev).train()
     opt = SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
     crit = torch.nn.CrossEntropyLoss()
@@ -41,9 +44,17 @@ def main():
         loss.backward()
         opt.step()
         return loss
-    for _ in range(3):
+    if a.graph:
+        graphed = GraphedStep(net, opt, lambda xx, yy: crit(net(xx), yy))
+        eager = step
+
+        def step():                                                        # noqa: F811
+            return graphed(x, y)
+    for _ in range(5):
         step()
     torch.cuda.synchronize()
+    if a.graph:
+        print("graph replays so far: %d" % graphed.replays)
     if a.host_time:
         # host enqueue time of one step: the device is idle and its queues empty when the step's calls start, so what is timed
         # is Python + launch overhead alone (the step is host-bound wherever this exceeds the device time)
