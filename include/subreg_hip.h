@@ -47,6 +47,7 @@ extern "C" {
  * (conv64_resident.hip::conv64_fused_first_kernel / conv64_wide_fused_kernel). */
 #define SUBREG_CONV_KERNEL_GENERAL 256
 #define SUBREG_CONV_KERNEL_WIDE 512
+#define SUBREG_CONV_KERNEL_WIDE_ALT 1024  /* with _WIDE: the OTHER MFMA shape of conv_wide.hip than its default for the problem (16x16x32 by default): parity tests, A/B runs */
 
 /* flags of subreg_backbone_forward */
 #define SUBREG_FWD_TRAIN 1 /* BN batch statistics + running-stat update + keep masks (net.train(), eval/language_eval.py:211) */

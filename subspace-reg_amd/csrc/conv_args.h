@@ -28,7 +28,9 @@ struct ConvArgs {
 // conv_wide.hip: eval-mode bf16 3x3 convolutions with Cout % 160 == 0 (scale folded into the weights, optional fused shortcut
 // GEMM, optional 2x2 max-pool) on 512-row x 160-channel tiles, one 4-wave workgroup per CU.  SUBREG_EUNSUPPORTED when the
 // problem is outside that set (the caller then takes the general kernel).
-int conv_wide(const ConvArgs& a, bool pool, hipStream_t stream);
+// tr: MFMA tile edge of the 256-row tiling (16: conv_wide16_kernel, 32: conv_wide_kernel<2>); 0 = the default for the problem
+int conv_wide(const ConvArgs& a, bool pool, hipStream_t stream, int tr = 0);
+int conv_wide_default_tr(bool pool);
 // does conv_wide take this problem, and should the dispatcher prefer it (measured rule)?
 bool conv_wide_supported(const ConvArgs& a, bool pool);
 bool conv_wide_preferred(const ConvArgs& a, bool pool);

@@ -309,19 +309,31 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WK * 64, MINW) void conv_fwd_kern
     constexpr int NAP = (MI * TAPS + 1) / 2;
     unsigned apk[NAP];
     {
+        // Branch-free on purpose (round 6): written with && / ?: hipcc turned every entry into a divergent branch (exec save, branch,
+        // restore) and this table into ~60 % of a prologue that two or three waves per SIMD have to issue before their first MFMA.
+        // Validity per row offset dy and column offset dx once per MFMA row tile (unsigned compares), entries as selects.
 #pragma unroll
         for (int k = 0; k < NAP; ++k) apk[k] = 0;
+        const unsigned zad = (unsigned)(AROWS * ROWB + 16 * lh);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = m0 + (wave_m * MI + i) * TR + lr;
-            const bool mv = m < g.M;
+            const unsigned mv = m < g.M ? 1u : 0u;
             const Pix px = row_to_pixel<POOL>(g, mv ? m : 0);
+            unsigned okh[3], okw[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                okh[d] = mv & ((unsigned)(px.h + d - 1) < (unsigned)g.H ? 1u : 0u);
+                okw[d] = (unsigned)(px.w + d - 1) < (unsigned)g.W ? 1u : 0u;
+            }
+            const int base = px.p - plo;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
                 const int dy = TAPS == 9 ? t / 3 - 1 : 0, dx = TAPS == 9 ? t % 3 - 1 : 0;
-                const bool ok = mv && tap_valid(g, px.h, px.w, dy, dx);
-                const int row = px.p + dy * g.W + dx - plo;
-                const unsigned ad = ok ? row * ROWB + 16 * (lh ^ swz_tr<SLOTS, TR>(row)) : AROWS * ROWB + 16 * lh;
+                const int row = base + dy * g.W + dx;
+                const unsigned adv = (unsigned)row * ROWB + 16u * ((unsigned)lh ^ (unsigned)swz_tr<SLOTS, TR>(row));
+                const unsigned mask = 0u - (okh[dy + 1] & okw[dx + 1]);
+                const unsigned ad = ((adv & mask) | (zad & ~mask)) & 0xffffu;
                 apk[(i * TAPS + t) >> 1] |= ad << (16 * ((i * TAPS + t) & 1));
             }
         }
@@ -1196,7 +1208,8 @@ static int conv_fwd_impl(const void* x, const void* w, void* y, const float* sca
         if (wide && !(flags & SUBREG_CONV_KERNEL_GENERAL)) {
             const bool force = flags & SUBREG_CONV_KERNEL_WIDE;
             if (force || conv_wide_preferred(a, pool)) {
-                const int rc = conv_wide(a, pool, s);
+                const int dtr = conv_wide_default_tr(pool);
+                const int rc = conv_wide(a, pool, s, (flags & SUBREG_CONV_KERNEL_WIDE_ALT) ? 48 - dtr : dtr);
                 if (rc != SUBREG_EUNSUPPORTED || force) return rc;
             }
         } else if (flags & SUBREG_CONV_KERNEL_WIDE) {

@@ -35,6 +35,10 @@
 #include "conv_index.h"
 #include "subreg_common.h"
 
+#ifndef SUBREG_W16_AHEAD
+#define SUBREG_W16_AHEAD 2       // conv_wide16_kernel: B fragments read 2 or 3 groups of four MFMAs ahead of their use (see `group`); 3 measured
+                                 // equal on the un-pooled layers and 7 % slower on the pooled ones (profiles/r06_wide16_ahead.txt)
+#endif
 #ifndef SUBREG_WIDE_DIAG
 #define SUBREG_WIDE_DIAG 0       // 1 = no in-loop staging, 2 = no LDS reads / MFMAs (wrong results: timing only);
                                  // 3 = per-wave s_memtime stamps into a.stats (tools/diag_conv.py --kernel wide);
@@ -173,8 +177,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv_wide_kernel(const Conv
     const int lr = lane & 31, lh = lane >> 5;
     const ConvGeom g = a.g;
     constexpr bool STAMPS = SUBREG_WIDE_DIAG == 3;
+    constexpr bool ENDS = STAMPS || SUBREG_WIDE_DIAG == 8;   // 8: loop begin / end and the clock only
     unsigned long long t_begin = 0, t_loop = 0, t_wait = 0, t_bar = 0, r_begin = 0;
-    if (STAMPS) { t_begin = __builtin_amdgcn_s_memtime(); r_begin = __builtin_amdgcn_s_memrealtime(); }
+    if (ENDS) { t_begin = __builtin_amdgcn_s_memtime(); r_begin = __builtin_amdgcn_s_memrealtime(); }
     // XCD-aware tile order: each of the 8 XCDs owns a contiguous tile range, n-tile fastest (conv_fwd.hip)
     const int ntn = a.Cout / TN;
     int vtile;
@@ -247,19 +252,29 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv_wide_kernel(const Conv
     constexpr int NAP = (MI * TAPS + 1) / 2;
     unsigned apk[NAP];
     {
+        // branch-free (see conv_wide16_kernel: with && / ?: every entry became a divergent branch, the prologue 2.5 x the instructions)
 #pragma unroll
         for (int k = 0; k < NAP; ++k) apk[k] = 0;
+        const unsigned zad = (unsigned)(AROWS * ROWB + 16 * lh);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = m0 + (wave_m * MI + i) * 32 + lr;
-            const bool mv = m < g.M;
+            const unsigned mv = m < g.M ? 1u : 0u;
             const Pix px = row_to_pixel<POOL>(g, mv ? m : 0);
+            unsigned okh[3], okw[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                okh[d] = mv & ((unsigned)(px.h + d - 1) < (unsigned)g.H ? 1u : 0u);
+                okw[d] = (unsigned)(px.w + d - 1) < (unsigned)g.W ? 1u : 0u;
+            }
+            const int base = px.p - plo;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
                 const int dy = t / 3 - 1, dx = t % 3 - 1;
-                const bool ok = mv && tap_valid(g, px.h, px.w, dy, dx);
-                const int row = px.p + dy * g.W + dx - plo;
-                const unsigned ad = ok ? row * ROWB + 16 * (lh ^ swz<SLOTS>(row)) : AROWS * ROWB + 16 * lh;
+                const int row = base + dy * g.W + dx;
+                const unsigned adv = (unsigned)row * ROWB + 16u * ((unsigned)lh ^ (unsigned)swz<SLOTS>(row));
+                const unsigned mask = 0u - (okh[dy + 1] & okw[dx + 1]);
+                const unsigned ad = ((adv & mask) | (zad & ~mask)) & 0xffffu;
                 apk[(i * TAPS + t) >> 1] |= ad << (16 * ((i * TAPS + t) & 1));
             }
         }
@@ -363,7 +378,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv_wide_kernel(const Conv
         __builtin_amdgcn_sched_barrier(0);
         if (STAMPS) { const unsigned long long q2 = __builtin_amdgcn_s_memtime(); t_wait += q1 - q0; t_bar += q2 - q1; }
     };
-    if (STAMPS) t_loop = __builtin_amdgcn_s_memtime();
+    if (ENDS) t_loop = __builtin_amdgcn_s_memtime();
 
     // ---- phase 0: the convolution chunks, nine steps each (unrolled: tap, ring slot and fragment addresses are compile-time)
     const unsigned wl0 = lds_base + (unsigned)wid * 1024u;                // LDS offset of weight piece `wid` within a ring slot
@@ -470,7 +485,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv_wide_kernel(const Conv
         unsigned long long t0;
         __device__ ~EpilogueStamp() { if (dst) *dst = (float)(__builtin_amdgcn_s_memtime() - t0); }
     } epi_stamp{nullptr, 0};
-    if (STAMPS && a.stats && lane == 0) {
+    if (ENDS && a.stats && lane == 0) {
         const unsigned long long n = __builtin_amdgcn_s_memtime(), rn = __builtin_amdgcn_s_memrealtime();
         float* d = a.stats + ((size_t)blockIdx.x * NW + wid) * 8;
         d[0] = (float)(t_loop - t_begin); d[1] = (float)(n - t_loop); d[2] = 0.f; d[3] = (float)(n - t_loop) - (float)t_wait - (float)t_bar;
@@ -627,9 +642,10 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lh = lane >> 4;             // row (column) within an MFMA tile, 8-channel k-slot (A, B) / row quad (C)
     const ConvGeom g = a.g;
-    constexpr bool STAMPS = SUBREG_WIDE_DIAG == 3;
+    constexpr bool STAMPS = SUBREG_WIDE_DIAG == 3;           // per-MID stamps (they drain the LDS queue at every MID: this kernel's reads run through it)
+    constexpr bool ENDS = STAMPS || SUBREG_WIDE_DIAG == 8;   // 8: loop begin / end and the clock only
     unsigned long long t_begin = 0, t_loop = 0, t_wait = 0, t_bar = 0, r_begin = 0;
-    if (STAMPS) { t_begin = __builtin_amdgcn_s_memtime(); r_begin = __builtin_amdgcn_s_memrealtime(); }
+    if (ENDS) { t_begin = __builtin_amdgcn_s_memtime(); r_begin = __builtin_amdgcn_s_memrealtime(); }
     const int ntn = a.Cout / TN;
     int vtile;
     {
@@ -666,8 +682,15 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
         row = row < prow ? row : prow - 1;
         dma16(src, uoff + (unsigned)row * xrow + swzo, lds_base + A_BASE + buf * ABUF + q * 1024);
     };
-    // per-lane source offset of this wave's weight piece `wid`; pieces wid + 4, wid + 8 are 4096, 8192 bytes further (64 rows each)
-    const unsigned wvoff0 = (unsigned)(n0 + wid * RPP + prl) * ROWB + swzo;
+    // per-lane source offset of this wave's weight piece `wid`: (n0 + 16 wid) rows (scalar, wsoff) + this lane's row and swizzled slot,
+    // made where it is used from prl and swzo (one v_lshl_add: the register budget of this kernel is counted in single registers);
+    // pieces wid + 4, wid + 8 are 4096, 8192 bytes further (64 rows each)
+    const unsigned wsoff = (unsigned)(n0 + wid * RPP) * ROWB;
+    auto wlane = [&]() -> unsigned {
+        unsigned p = (unsigned)prl;
+        asm volatile("" : "+v"(p));                                        // (opaque: not hoisted into a loop-invariant register)
+        return p * ROWB + swzo;
+    };
     const int s2w = __builtin_amdgcn_readfirstlane(wid < 2 ? 1 : 0);
     const unsigned s2m = (unsigned)__builtin_amdgcn_readfirstlane(wid < 2 ? -1 : 0);
     const unsigned long long s2mask = ((unsigned long long)s2m << 32) | s2m;
@@ -676,7 +699,7 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < WPW; ++k) {
             const int i = wid + NW * k;
-            if (i < WPT) dma16(wsrc, wvoff0 + rfl(soff + (unsigned)k * 4096u), lds_base + slot * BTAP + i * 1024);
+            if (i < WPT) dma16(wsrc, wlane() + rfl(wsoff + soff + (unsigned)k * 4096u), lds_base + slot * BTAP + i * 1024);
         }
     };
     const int nch0 = a.Cin / 32, nch1 = a.x2 ? a.Cin2 / 32 : 0;
@@ -689,19 +712,31 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
     constexpr int NAP = (NA * TAPS + 1) / 2;
     unsigned apk[NAP];
     {
+        // Branch-free on purpose: written with && / ?: hipcc turns every entry into a divergent branch (exec save, branch, restore: 103
+        // exec saves and 68 branches in this prologue, ~1400 instructions for two waves per SIMD to issue = 11 k cycles per tile).
+        // Validity per row offset dy and column offset dx once per fragment (unsigned compares: one per bound pair), entries as selects.
 #pragma unroll
         for (int k = 0; k < NAP; ++k) apk[k] = 0;
+        const unsigned zad = (unsigned)(AROWS * ROWB + 16 * lh);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int m = m0 + wid * 64 + i * TR + lr;
-            const bool mv = m < g.M;
+            const unsigned mv = m < g.M ? 1u : 0u;
             const Pix px = row_to_pixel<POOL>(g, mv ? m : 0);
+            unsigned okh[3], okw[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                okh[d] = mv & ((unsigned)(px.h + d - 1) < (unsigned)g.H ? 1u : 0u);
+                okw[d] = (unsigned)(px.w + d - 1) < (unsigned)g.W ? 1u : 0u;
+            }
+            const int base = px.p - plo;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
                 const int dy = t / 3 - 1, dx = t % 3 - 1;
-                const bool ok = mv && tap_valid(g, px.h, px.w, dy, dx);
-                const int row = px.p + dy * g.W + dx - plo;
-                const unsigned ad = ok ? row * ROWB + 16 * (lh ^ swz_tr<SLOTS, TR>(row)) : AROWS * ROWB + 16 * lh;
+                const int row = base + dy * g.W + dx;
+                const unsigned adv = (unsigned)row * ROWB + 16u * ((unsigned)lh ^ (unsigned)swz_tr<SLOTS, TR>(row));
+                const unsigned mask = 0u - (okh[dy + 1] & okw[dx + 1]);               // all ones where the tap is inside the image
+                const unsigned ad = ((adv & mask) | (zad & ~mask)) & 0xffffu;
                 apk[(i * TAPS + t) >> 1] |= ad << (16 * ((i * TAPS + t) & 1));
             }
         }
@@ -764,14 +799,25 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto group = [&](auto g_tag, auto ro_tag, int boff, auto&& dma) {
+    // B reads of the B-major section (SUBREG_W16_AHEAD): 2 = b_{G+2} in front of group G (128 cycles ahead); 3 = the ring's fourth slot
+    // used too: b4 b5 in front of G2, then b_{G+3} (192 cycles ahead), the next step's b'_0 in front of G7, b'_1 in front of the last pair
+    auto group = [&](auto g_tag, auto ro_tag, auto next_tag, int boff, int n_boff, auto&& dma) {
         constexpr int G = decltype(g_tag)::value, RO = decltype(ro_tag)::value;
+        constexpr bool NEXT = decltype(next_tag)::value;
         if (SUBREG_WIDE_DIAG != 1) dma(g_tag);
         if constexpr (SUBREG_WIDE_DIAG != 2) {
-            ring[(G + 2 + RO) & 3] = rd_b(G + 2, boff);
+            if constexpr (SUBREG_W16_AHEAD == 2) {
+                ring[(G + 2 + RO) & 3] = rd_b(G + 2, boff);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            } else {
+                constexpr int NRD = G == 2 ? 2 : (G <= 6 ? 1 : (NEXT ? 1 : 0));
+                if constexpr (G == 2) { ring[(4 + RO) & 3] = rd_b(4, boff); ring[(5 + RO) & 3] = rd_b(5, boff); }
+                else if constexpr (G <= 6) ring[(G + 3 + RO) & 3] = rd_b(G + 3, boff);
+                else if constexpr (NEXT) ring[(2 + RO) & 3] = rd_b(0, n_boff);          // G = 7: b'_0 into the slot of b6
+                if constexpr (NRD > 0) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+            }
 #pragma unroll
             for (int i = 0; i < NA; ++i) mma_ab(fa[i], ring[(G + RO) & 3], acc[i][G]);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, NA, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -782,20 +828,19 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
         if (SUBREG_WIDE_DIAG != 1) dma(IC<8>{});
         if constexpr (SUBREG_WIDE_DIAG != 2) {
             if constexpr (NEXT) {
-                ring[(2 + RO) & 3] = rd_b(0, n_boff);
+                if constexpr (SUBREG_W16_AHEAD == 2) ring[(2 + RO) & 3] = rd_b(0, n_boff);
                 ring[(3 + RO) & 3] = rd_b(1, n_boff);
+                __builtin_amdgcn_sched_group_barrier(0x100, SUBREG_W16_AHEAD == 2 ? 2 : 1, 0);
             }
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 mma_ab(fa[i], ring[(0 + RO) & 3], acc[i][8]);             // b8: slot (8 + RO) % 4
                 mma_ab(fa[i], ring[(1 + RO) & 3], acc[i][9]);
-                if constexpr (NEXT) fa[i] = rd_a(i, n_aoff, NTAP);
-            }
-            if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if constexpr (NEXT) {
+                    fa[i] = rd_a(i, n_aoff, NTAP);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -818,7 +863,7 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if (STAMPS) { const unsigned long long q2 = __builtin_amdgcn_s_memtime(); t_wait += q1 - q0; t_bar += q2 - q1; }
     };
-    if (STAMPS) t_loop = __builtin_amdgcn_s_memtime();
+    if (ENDS) t_loop = __builtin_amdgcn_s_memtime();
 
     // ---- phase 0: the convolution chunks, nine steps each
     const unsigned wl0 = lds_base + (unsigned)wid * 1024u;
@@ -835,9 +880,13 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
         unsigned cw = (unsigned)c * wtile;
         asm volatile("" : "+s"(cw));
         const int lim = prow - 1 - (apieces - 1) * RPP;
-        const unsigned pv = __umul24((unsigned)prl, pxrow) + swzo;
+        // per-lane part of a patch piece's source offset: row prl of the piece + swizzled slot, made where it is used (see wlane)
+        auto plane = [&]() -> unsigned {
+            unsigned p = (unsigned)prl;
+            asm volatile("" : "+v"(p));
+            return __umul24(p, pxrow) + swzo;
+        };
         const unsigned gs = (unsigned)RPP * pxrow;
-        const unsigned l2 = vsel(s2mask, wvoff0, pv);                     // (S2 as a weight piece: piece wid + 8, the 8192 goes into the scalar part)
         auto step = [&](auto tap_tag) {
             constexpr int TAP = decltype(tap_tag)::value;
             constexpr int SL = TAP % NWB, RO = 2 * (TAP & 1);            // (a chunk starts with b_0, b_1 in slots 0, 1)
@@ -845,9 +894,9 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
             constexpr int NT = SAME ? TAP + 1 : -1;
             const int boff = SL * BTAP, nboff = ((TAP + 1) % NWB) * BTAP, n_aoff = SAME ? aoff : naoff;
             pair0(IC<RO>{}, boff);
-            group(IC<2>{}, IC<RO>{}, boff, no_dma);
-            group(IC<3>{}, IC<RO>{}, boff, no_dma);
-            group(IC<4>{}, IC<RO>{}, boff, no_dma);
+            group(IC<2>{}, IC<RO>{}, std::true_type{}, boff, nboff, no_dma);
+            group(IC<3>{}, IC<RO>{}, std::true_type{}, boff, nboff, no_dma);
+            group(IC<4>{}, IC<RO>{}, std::true_type{}, boff, nboff, no_dma);
             mid_sync(false, (TAP >= 1 && TAP - 1 <= PLAST) ? 1 : 0);
             constexpr int WSL = (TAP + 2) % NWB;
             const char* wsrc = a.w;
@@ -867,15 +916,15 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
                 if constexpr (gq == 0) {                                  // S2
                     int q = q0 + p2;
                     q = q < apieces - 2 ? q : apieces - 2;
-                    const unsigned so = ssel(s2w, woff + 8192u, puoff + (unsigned)q * gs);
+                    const unsigned so = ssel(s2w, wsoff + woff + 8192u, puoff + (unsigned)q * gs);   // (weight piece wid + 8 | patch piece q)
                     const unsigned la = ssel(s2w, wl0 + WSL * BTAP + 8 * 1024, plds + (unsigned)q * 1024u);
-                    dma16(ssel_ptr(s2w, wsrc, psrc), l2 + so, la);
+                    dma16(ssel_ptr(s2w, wsrc, psrc), vsel(s2mask, wlane(), plane()) + so, la);
                 } else if constexpr (gq == 1 || gq == 2) {                // W0, W1
-                    dma16(wsrc, wvoff0 + rfl(woff + (unsigned)(gq - 1) * 4096u), wl0 + WSL * BTAP + (gq - 1) * 4096);
+                    dma16(wsrc, wlane() + rfl(wsoff + woff + (unsigned)(gq - 1) * 4096u), wl0 + WSL * BTAP + (gq - 1) * 4096);
                 } else if constexpr (gq == 3 && TAP < PLAST) {            // S3: a regular patch piece
                     int q = q0 + p3;
                     q = q < apieces - 2 ? q : apieces - 2;
-                    dma16(psrc, pv + rfl(puoff + (unsigned)q * gs), plds + (unsigned)q * 1024u);
+                    dma16(psrc, plane() + rfl(puoff + (unsigned)q * gs), plds + (unsigned)q * 1024u);
                 } else if constexpr (gq == 3 && TAP == PLAST) {           // S3: the last patch piece
                     // (tail rows clamped to the patch's last row; made here, once per chunk, instead of held in a register)
                     int prl_o = prl;
@@ -884,9 +933,9 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
                     dma16(psrc, pv_last + rfl(puoff + (unsigned)(apieces - 1) * gs), plds + (unsigned)(apieces - 1) * 1024u);
                 }
             };
-            group(IC<5>{}, IC<RO>{}, boff, dma);
-            group(IC<6>{}, IC<RO>{}, boff, dma);
-            group(IC<7>{}, IC<RO>{}, boff, dma);
+            group(IC<5>{}, IC<RO>{}, std::true_type{}, boff, nboff, dma);
+            group(IC<6>{}, IC<RO>{}, std::true_type{}, boff, nboff, dma);
+            group(IC<7>{}, IC<RO>{}, std::true_type{}, boff, nboff, dma);
             pair8(IC<RO>{}, std::true_type{}, n_aoff, IC<NT>{}, nboff, dma);
         };
         step(IC<0>{});
@@ -909,17 +958,17 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
         const int boff = (s % NWB) * BTAP, nboff = ((s + 1) % NWB) * BTAP;
         const bool more = d + 1 < nch1;
         pair0(IC<0>{}, boff);
-        group(IC<2>{}, IC<0>{}, boff, no_dma);
-        group(IC<3>{}, IC<0>{}, boff, no_dma);
-        group(IC<4>{}, IC<0>{}, boff, no_dma);
+        group(IC<2>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
+        group(IC<3>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
+        group(IC<4>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
         mid_sync(true);                                                   // (the patch buffer written below is the one step s-1 read)
         if (SUBREG_WIDE_DIAG != 1) {
             if (d + 2 < nch1) stage_weights(a.w2, (unsigned)(d + 2) * wtile, (s + 2) % NWB);
             if (more) for (int q = wid; q < apieces; q += NW) patch_piece(a.x2, porg1 + (unsigned)(d + 1) * (32 * ELEM), xrow1, q, (nch0 + d + 1) & 1);
         }
-        group(IC<5>{}, IC<0>{}, boff, no_dma);
-        group(IC<6>{}, IC<0>{}, boff, no_dma);
-        group(IC<7>{}, IC<0>{}, boff, no_dma);
+        group(IC<5>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
+        group(IC<6>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
+        group(IC<7>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
         pair8(IC<0>{}, std::false_type{}, 0, IC<0>{}, 0, no_dma);
         if (more) {
             mid_sync(false);
@@ -936,7 +985,7 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
         unsigned long long t0;
         __device__ ~EpilogueStamp() { if (dst) *dst = (float)(__builtin_amdgcn_s_memtime() - t0); }
     } epi_stamp{nullptr, 0};
-    if (STAMPS && a.stats && lane == 0) {
+    if (ENDS && a.stats && lane == 0) {
         const unsigned long long n = __builtin_amdgcn_s_memtime(), rn = __builtin_amdgcn_s_memrealtime();
         float* d = a.stats + ((size_t)blockIdx.x * NW + wid) * 8;
         d[0] = (float)(t_loop - t_begin); d[1] = (float)(n - t_loop); d[2] = 0.f; d[3] = (float)(n - t_loop) - (float)t_wait - (float)t_bar;
@@ -1078,8 +1127,9 @@ int launch_wide16(const ConvArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
     return launch_status();
 }
-// MFMA shape of the 256-row tiling (SUBREG_WIDE_TR: 16 = conv_wide16_kernel, 32 = conv_wide_kernel<2>)
-int wide_tr() { static const int v = [] { const char* e = getenv("SUBREG_WIDE_TR"); return e && *e ? atoi(e) : 16; }(); return v == 32 ? 32 : 16; }
+// MFMA shape of the 256-row tiling.  Default: 16x16x32 (conv_wide16_kernel); SUBREG_WIDE_TR=32 selects conv_wide_kernel<2> (measurements),
+// SUBREG_CONV_KERNEL_WIDE_ALT in a call's flags the other one than the default (parity tests).
+int wide_tr_env() { static const int v = [] { const char* e = getenv("SUBREG_WIDE_TR"); return e && *e ? atoi(e) : 0; }(); return v == 16 || v == 32 ? v : 0; }
 
 // Two tilings of the same kernel body (SUBREG_WIDE_MI picks; measurements):
 //   MI = 3: 96 x 160 wave tiles, 384 x 160 tiles, ONE workgroup per CU (a wave owns its SIMD's 512 registers)
@@ -1117,15 +1167,29 @@ bool conv_wide_preferred(const ConvArgs& a, bool pool) {
     if (!conv_wide_supported(a, pool)) return false;
     if (mode == 1) return true;
     if (wide_mi() != 2) return false;                                  // (the rule was measured for the 256-row variant)
-    if (a.g.M < 200000) return false;                                  // (not measured below ~115 images of 42x42)
-    if (a.g.W >= 42) return a.Cin >= 160 || a.g.M >= 800000;
-    if (pool && a.g.W == 21) return a.g.M >= 100000;
-    return false;
+    if (conv_wide_default_tr(pool) == 32) {
+        // the 32x32x16 form (round 5, profiles/r05_wide2_vs_general.txt): the 42x42 maps and the pooled 21x21 conv
+        if (a.g.M < 200000) return false;
+        if (a.g.W >= 42) return a.Cin >= 160 || a.g.M >= 800000;
+        if (pool && a.g.W == 21) return a.g.M >= 100000;
+        return false;
+    }
+    // 16x16x32 form (profiles/r06_wide16_vs_general.txt: both kernels per layer at 250 ... 1125 images, one box, interleaved).  It wins
+    // wherever the 256-row tiles fill the chip: -5 ... -13 % on layer 2 (conv1, K = 576, from ~350 images), -2 ... -9 % on layer 3.0 and
+    // layer 4.0 from ~450 images; on layer 3.1 (10x10, 320 channels: 548 tiles at 700 images for 512 slots) the general kernel's
+    // 128-row tiles win at every batch; the 5x5 maps only from ~1000 images (-7 %).
+    if (a.g.W >= 42) return a.Cin >= 160 ? a.g.M >= 200000 : a.g.M >= 600000;
+    if (a.g.W >= 21) return a.g.M >= (pool ? 100000 : 200000);
+    if (a.g.W >= 10) return a.Cout >= 640 && a.g.M >= 50000;
+    return a.g.M >= 24000;
 }
 
-int conv_wide(const ConvArgs& a, bool pool, hipStream_t stream) {
+int conv_wide_default_tr(bool pool) { (void)pool; return wide_tr_env() ? wide_tr_env() : 16; }
+
+int conv_wide(const ConvArgs& a, bool pool, hipStream_t stream, int tr) {
     if (!conv_wide_supported(a, pool)) return SUBREG_EUNSUPPORTED;
-    if (wide_mi() == 2 && wide_tr() == 16) return pool ? launch_wide16<true, AR_POOL2>(a, stream) : launch_wide16<false, AR_LIN2>(a, stream);
+    if (tr == 0) tr = conv_wide_default_tr(pool);
+    if (wide_mi() == 2 && tr == 16) return pool ? launch_wide16<true, AR_POOL2>(a, stream) : launch_wide16<false, AR_LIN2>(a, stream);
     if (wide_mi() == 2) return pool ? launch_wide<2, 4, 1, true, AR_POOL2, 2>(a, stream) : launch_wide<2, 4, 1, false, AR_LIN2, 2>(a, stream);
     return pool ? launch_wide<3, 4, 1, true, AR_POOL3, 1>(a, stream) : launch_wide<3, 4, 1, false, AR_LIN3, 1>(a, stream);
 }

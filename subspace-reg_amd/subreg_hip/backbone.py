@@ -55,7 +55,9 @@ class HipBackbone:
         self._fold_versions = None
         self._fold_token = 0           # bumped whenever the packed / folded weights are rebuilt (invalidates cached graphs)
         self._ws_token = 0             # ... whenever a workspace is re-allocated
-        self._graphs = {}              # (B, H, W) -> dict(calls, graph, x, feat, tokens): forward_graphed()
+        self._graphs = {}              # ((B, 3, H, W), buffer set) -> dict(calls, graph, x, feat, tokens): forward_graphed()
+        self._spec_pending, self._spec_next, self._spec_last, self._spec_streams = [], {}, None, []   # input-sequence prefetch
+        self.prefetch_hits = 0
         self._cap = (0, 0, 0)          # allocated (workspace bytes, stats floats, im2col elements)
         self._ws_ok = set()            # (B, H, W) known to fit the allocation
         self._lanes = []               # extra eval lanes: dict(desc, ws, col, cap, stream, ok)
@@ -207,6 +209,7 @@ class HipBackbone:
             torch.cuda.synchronize(self.device)
         self._lanes, self._ws_ok, self._cap, self._keep = [], set(), (0, 0, 0), []
         self._graphs = {}
+        self._spec_pending, self._spec_next, self._spec_last = [], {}, None
         self._ws_token += 1
         self._ws = self._col = self._stats = None
         self._train_stash = None
@@ -325,20 +328,70 @@ class HipBackbone:
 
     # ------------------------------------------------------------------ forward
     GRAPH_EVAL = os.environ.get("SUBREG_GRAPH_EVAL", "1") != "0"      # forward_graphed(): replay cached hipGraphs (0: always eager)
-    GRAPH_CACHE = 6                                                   # shapes kept (least recently used goes first)
+    GRAPH_CACHE = 12                                                  # (shape, buffer set) entries kept (least recently used goes first)
+    EVAL_PREFETCH = int(os.environ.get("SUBREG_EVAL_PREFETCH", "2"))  # forward_graphed(): forwards started ahead of their call (0: none)
+
+    def _graph_entry(self, key):
+        """Cache entry of (shape, buffer set); the least recently used entry goes when the cache is full."""
+        ent = self._graphs.pop(key, None)
+        if ent is None:
+            ent = dict(calls=0, graph=None, x=None, feat=None, tokens=None, eager_only=False)
+            while len(self._graphs) >= self.GRAPH_CACHE:                  # least recently used first (dict order = use order)
+                old_key = next(iter(self._graphs))
+                if self._graphs[old_key]["graph"] is not None:
+                    torch.cuda.synchronize(self.device)                   # (a replay may still be in flight)
+                del self._graphs[old_key]
+        self._graphs[key] = ent                                           # (re-inserted: most recently used)
+        return ent
+
+    def _capture_entry(self, ent, key, x, lane_base):
+        """Capture the eval forward of x's shape on workspace set lane_base into ent; False (and ent stays eager-only) on failure."""
+        ent["x"] = torch.empty_like(x, memory_format=torch.contiguous_format)
+        ent["feat"] = torch.empty(x.shape[0], self.out_dim, dtype=torch.float32, device=self.device)
+        ent["x"].copy_(x)
+        nbt_keep = list(self.nbt)
+        torch.cuda.synchronize(self.device)
+        try:
+            g = torch.cuda.CUDAGraph()
+            # thread_local: HIP calls of OTHER host threads (a DataLoader's pin_memory thread) do not invalidate this capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self.forward(ent["x"], out=ent["feat"], check_params=False, lane_base=lane_base)
+        except Exception as e:                                            # noqa: BLE001 - whatever broke the capture: this shape stays eager
+            import warnings
+            self.nbt = nbt_keep
+            ent.update(graph=None, x=None, feat=None, eager_only=True)
+            torch.cuda.synchronize(self.device)
+            warnings.warn("subreg_hip: eval forward of shape %s could not be captured as a hipGraph (%s: %s); it runs eagerly"
+                          % (key, type(e).__name__, e), RuntimeWarning, stacklevel=3)
+            return False
+        self.nbt = nbt_keep                                               # (the capture pass launches nothing)
+        ent["graph"], ent["tokens"] = g, (self._fold_token, self._ws_token)
+        return True
 
     def forward_graphed(self, x):
-        """Eval-mode forward for callers that run the SAME shape again and again over a backbone that does not change (the
+        """Eval-mode forward for callers that run the SAME shapes again and again over a backbone that does not change (the
         reference's own loop over the drop-in module, eval/language_eval.py:242-326: one support forward and one forward per
-        query set and epoch, 125 images each): the launch sequence (~25 kernels on one or two lanes) is captured into a hipGraph
-        the second time a shape is seen and replayed from then on - copy the input into the graph's buffer, replay, copy the
-        features out.  Every replay executes all 22 convolutions; only the host-side enqueue is saved.  The cache is dropped
-        whenever the weights are re-packed (refresh() sees tensor._version / data_ptr changes) or a workspace moves."""
+        query set and epoch, 125 images each).
+
+        1. The launch sequence (~25 kernels on one or two lanes) is captured into a hipGraph the second time a shape is seen and
+           replayed from then on - copy the input into the graph's buffer, replay, copy the features out.
+        2. Input-sequence prefetch (EVAL_PREFETCH forwards deep).  That loop reads every result on the host before it asks for the
+           next forward (`.item()`, `.cpu()`: language_eval.py:36-43), so its nine 125-image forwards per epoch run one after another
+           with the GPU idle in between, each at the fill of a 125-image batch.  The calls repeat epoch after epoch with the SAME
+           tensor objects in the same order: the backbone remembers which tensor followed which, and when a call arrives it starts
+           the forwards of the next EVAL_PREFETCH tensors of that chain on side streams with workspace sets of their own.  A later
+           call is served from such a forward only if it passes THE SAME tensor object at the SAME `_version` under the same
+           weights (anything else - another tensor, an in-place edit, re-packed weights - drops the predictions and runs the
+           forward now), so every result is the forward of exactly what was passed; nothing is cached across calls: each call is
+           one execution of all 22 convolutions.  What changes is when they run: two forwards ahead overlap each other and the
+           host's round trips, like the two lanes of a 250-image forward.
+        The caches are dropped whenever the weights are re-packed (refresh() sees tensor._version / data_ptr changes) or a workspace
+        moves."""
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3
         if not self.GRAPH_EVAL:
             return self.forward(x)
         self.refresh()
-        key = tuple(x.shape)
+        shape = tuple(x.shape)
         tokens = (self._fold_token, self._ws_token)
         # every captured entry whose weights were re-packed or whose workspaces moved since its capture goes, whatever its shape (each
         # keeps a copy of its input and features alive: ~95 MB at 1125 images).  A replay may still be in flight on the caller's or
@@ -348,50 +401,86 @@ class HipBackbone:
             torch.cuda.synchronize(self.device)
             for k in stale:
                 del self._graphs[k]
-        ent = self._graphs.pop(key, None)
-        if ent is None:
-            ent = dict(calls=0, graph=None, x=None, feat=None, tokens=None, eager_only=False)
-            while len(self._graphs) >= self.GRAPH_CACHE:                  # least recently used first (dict order = use order)
-                old_key = next(iter(self._graphs))
-                if self._graphs[old_key]["graph"] is not None:
-                    torch.cuda.synchronize(self.device)
-                del self._graphs[old_key]
-        self._graphs[key] = ent                                           # (re-inserted: most recently used)
-        ent["calls"] += 1
-        if ent["eager_only"] or (ent["graph"] is None and ent["calls"] < 2):
-            return self.forward(x, check_params=False)                    # first sight of a shape: eager (sizes the workspaces)
-        if ent["graph"] is None:
-            ent["x"] = torch.empty_like(x, memory_format=torch.contiguous_format)
-            ent["feat"] = torch.empty(x.shape[0], self.out_dim, dtype=torch.float32, device=self.device)
-            ent["x"].copy_(x)
-            nbt_keep = list(self.nbt)
-            torch.cuda.synchronize(self.device)
-            try:
-                g = torch.cuda.CUDAGraph()
-                # thread_local: HIP calls of OTHER host threads (a DataLoader's pin_memory thread) do not invalidate this capture
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self.forward(ent["x"], out=ent["feat"], check_params=False)
-            except Exception as e:                                        # noqa: BLE001 - whatever broke the capture: this shape stays eager
-                import warnings
-                self.nbt = nbt_keep
-                ent.update(graph=None, x=None, feat=None, eager_only=True)
-                torch.cuda.synchronize(self.device)
-                warnings.warn("subreg_hip: eval forward of shape %s could not be captured as a hipGraph (%s: %s); it runs eagerly"
-                              % (key, type(e).__name__, e), RuntimeWarning, stacklevel=2)
-                return self.forward(x, check_params=False)
-            self.nbt = nbt_keep                                           # (the capture pass launches nothing)
-            ent["graph"], ent["tokens"] = g, (self._fold_token, self._ws_token)
-        else:
-            ent["x"].copy_(x)
-        ent["graph"].replay()
+            self._spec_pending = []
+        cur = torch.cuda.current_stream()
+        feat = None
+        pend = self._spec_pending
+        if pend:
+            p = pend[0]
+            if p["x"] is x and p["version"] == x._version and p["tokens"] == tokens:
+                pend.pop(0)
+                cur.wait_event(p["done"])                                 # that forward is complete before the copy below reads its output
+                feat = p["ent"]["feat"].clone()
+                self.prefetch_hits += 1
+            else:                                                         # not what was predicted: every prediction goes
+                self._spec_pending = pend = []
+        if feat is None:
+            ent = self._graph_entry((shape, 0))
+            ent["calls"] += 1
+            if ent["eager_only"] or (ent["graph"] is None and ent["calls"] < 2):
+                feat = self.forward(x, check_params=False)                # first sight of a shape: eager (sizes the workspaces)
+                self.nbt = [n - 1 for n in self.nbt]                      # (counted below, like every call)
+            elif ent["graph"] is None and not self._capture_entry(ent, shape, x, 0):
+                feat = self.forward(x, check_params=False)
+                self.nbt = [n - 1 for n in self.nbt]
+            else:
+                if ent["x"].data_ptr() != x.data_ptr():
+                    ent["x"].copy_(x)
+                ent["graph"].replay()
+                feat = ent["feat"].clone()
         for i in range(len(self.nbt)):
             self.nbt[i] += 1
-        return ent["feat"].clone()
+        if self.EVAL_PREFETCH > 0:
+            self._prefetch(x, tokens, cur)
+        return feat
 
-    def forward(self, x, train=False, masks=None, return_stages=False, out=None, check_params=True):
+    def _prefetch(self, x, tokens, cur):
+        """Remember that x followed the previous call's tensor; start the forwards of the tensors that followed x last time."""
+        hist = self._spec_next
+        if self._spec_last is not None and self._spec_last is not x:
+            hist.pop(id(self._spec_last), None)
+            hist[id(self._spec_last)] = (self._spec_last, x)              # (strong references: an id is only compared while its tensor lives)
+            while len(hist) > 64:
+                hist.pop(next(iter(hist)))
+        self._spec_last = x
+        pend = self._spec_pending
+        t = pend[-1]["x"] if pend else x
+        seen = {id(x)} | {id(p["x"]) for p in pend}
+        while len(pend) < self.EVAL_PREFETCH:
+            nxt = hist.get(id(t))
+            if nxt is None or nxt[0] is not t or id(nxt[1]) in seen:
+                return
+            nx = nxt[1]
+            base = self._graphs.get((tuple(nx.shape), 0))
+            if base is None or base["graph"] is None or not nx.is_cuda or nx.dtype != torch.float32:
+                return                                                    # (only shapes whose own graph exists: seen at least twice)
+            used = {p["set"] for p in pend}
+            sset = next(s for s in range(1, self.EVAL_PREFETCH + 2) if s not in used)
+            while len(self._spec_streams) <= sset:
+                self._spec_streams.append(torch.cuda.Stream(device=self.device))
+            st = self._spec_streams[sset]
+            key = (tuple(nx.shape), sset)
+            ent = self._graph_entry(key)
+            if ent["eager_only"]:
+                return
+            if ent["graph"] is None and not self._capture_entry(ent, key, nx, sset * max(1, int(self.EVAL_LANES))):
+                return
+            st.wait_stream(cur)                                           # behind the packed weights and the last copy out of this set's buffer
+            with torch.cuda.stream(st):
+                ent["x"].copy_(nx)
+                ent["graph"].replay()
+                done = torch.cuda.Event()
+                done.record(st)
+            pend.append(dict(x=nx, version=nx._version, tokens=tokens, ent=ent, set=sset, done=done))
+            seen.add(id(nx))
+            t = nx
+
+    def forward(self, x, train=False, masks=None, return_stages=False, out=None, check_params=True, lane_base=0):
         """x: [B,3,H,W] fp32 CUDA (NCHW like the reference) -> feat [B,out_dim] fp32.
         check_params=False skips the (host-side) scan for changed weights/BN tensors when the caller knows
-        nothing changed since the last forward (the fused loop's eval epochs)."""
+        nothing changed since the last forward (the fused loop's eval epochs).
+        lane_base > 0 (eval mode only): run on the workspace sets lane_base, lane_base + 1, ... instead of 0, 1, ... - a forward that
+        may overlap another one of this backbone (forward_graphed's prefetch); its first lane runs on the CURRENT stream."""
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3
         x = x.contiguous()
         B, _, H, W = x.shape
@@ -412,14 +501,17 @@ class HipBackbone:
             n_chunks = -(-B // self.MAX_EVAL_CHUNK)
             chunk = -(-B // n_chunks)
         lanes = 1 if (train or return_stages) else max(1, min(int(self.EVAL_LANES), chunk // self.EVAL_LANE_MIN))
-        if lanes > 1:
+        assert lane_base == 0 or not (train or return_stages), "workspace sets other than 0 serve eval-mode forwards only"
+        if lanes > 1 or lane_base > 0:
             assert not train, "train-mode forwards write BN statistics: lanes carry no stats buffer (desc.stats = None)"
-            # eval mode, several lanes: sub-batch i of every chunk goes to lane i (its own stream + workspaces)
+            # eval mode, several lanes: sub-batch i of every chunk goes to lane lane_base + i (its own workspaces; lane 0 of the set runs
+            # on the current stream, the others on streams of their own)
             sub = -(-chunk // lanes)
-            self._ensure_workspace(sub, H, W, need_col=False)
             cur = torch.cuda.current_stream()
-            extra = [self._lane(i, sub, H, W) for i in range(1, lanes)]
-            for ln in extra:
+            if lane_base == 0:
+                self._ensure_workspace(sub, H, W, need_col=False)
+            sets = [None if lane_base + i == 0 else self._lane(lane_base + i, sub, H, W) for i in range(lanes)]
+            for ln in sets[1:]:
                 ln["stream"].wait_stream(cur)                       # fork: x (and anything queued before) is ready
             for b0 in range(0, B, chunk):
                 nb = min(chunk, B - b0)
@@ -427,12 +519,12 @@ class HipBackbone:
                     lo, hi = b0 + min(i * sub, nb), b0 + min((i + 1) * sub, nb)
                     if hi <= lo:
                         continue
-                    desc = self._desc if i == 0 else extra[i - 1]["desc"]
-                    with torch.cuda.stream(cur if i == 0 else extra[i - 1]["stream"]):
+                    desc = self._desc if sets[i] is None else sets[i]["desc"]
+                    with torch.cuda.stream(cur if i == 0 else sets[i]["stream"]):
                         _lib.check(self.lib.subreg_backbone_forward(C.byref(desc), _lib.ptr(x[lo:hi]), hi - lo, H, W,
                                                                     _lib.ptr(feat[lo:hi]), None, 0, _lib.stream_ptr()),
                                    "backbone_forward")
-            for ln in extra:
+            for ln in sets[1:]:
                 cur.wait_stream(ln["stream"])                       # join
             return feat
         self._ensure_workspace(chunk, H, W, need_col=train)

@@ -477,16 +477,42 @@ class GraphedStep:
         return tuple((tuple(t.shape), t.dtype) for t in inputs) + groups + hyper
 
     def _eager(self, inputs):
-        out = self.loss_fn(*inputs)
-        loss = out[0] if isinstance(out, tuple) else out
-        self.opt.zero_grad()
-        loss.backward()
+        """One step.  How the gradients are taken is dictated by what a capture survives (tools/graph_probe.py, PROBE_HOLD=1):
+        a leaf's AccumulateGrad node is shared with every older autograd graph that is still alive (a loss the caller kept from an
+        eager step) and belongs to the stream of the forward that created it - the default stream.  A gradient that reaches such a
+        node inside a capture makes the engine synchronise the capturing stream with the default stream, which pulls the default
+        stream into the capture, and hipStreamEndCapture takes the process down (the reason torch's own recipe warms up on a side
+        stream - which does not help against graphs the CALLER holds).  So:
+          * parameters whose gradients travel through autograd (the classifier; anything but the backbone) are replaced, for the
+            duration of the step, by fresh leaf Parameters over the SAME storage: their gradient edges are new;
+          * the gradients are taken with torch.autograd.grad (no AccumulateGrad nodes run) and assigned to the real parameters;
+          * the backbone's gradients do not travel through autograd at all (BackboneTrainFn.backward assigns the views of its flat
+            buffer to `.grad` and returns None: allow_unused);
+          * the results are handed out detached, so this step's graph dies here."""
+        opt_params = [p for g in self.opt.param_groups for p in g["params"] if p.requires_grad]
+        wanted = {id(p) for p in opt_params}
+        backbone = {id(p) for n, p in self.model.named_parameters() if not n.startswith("classifier")}
+        swaps = []
+        for mod in self.model.modules():
+            for name, p in list(mod._parameters.items()):
+                if p is not None and id(p) in wanted and id(p) not in backbone:
+                    alias = torch.nn.Parameter(p.detach(), requires_grad=True)
+                    mod._parameters[name] = alias
+                    swaps.append((mod, name, p, alias))
+        try:
+            out = self.loss_fn(*inputs)
+            loss = out[0] if isinstance(out, tuple) else out
+            self.opt.zero_grad()
+            alias_of = {id(p): a for _m, _n, p, a in swaps}
+            leaves = [alias_of.get(id(p), p) for p in opt_params]
+            grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+        finally:
+            for mod, name, p, _alias in swaps:
+                mod._parameters[name] = p
+        for p, g in zip(opt_params, grads):
+            if g is not None:
+                p.grad = g
         self.opt.step()
-        # The results are handed out DETACHED, so this step's autograd graph dies here.  A caller that keeps an eager step's loss
-        # (`loss = step(x, y)`) would otherwise keep its AccumulateGrad nodes alive; the next call's capture re-uses them, they
-        # belong to the stream of the eager forward (the default stream), the engine pulls that stream into the capture and
-        # hipStreamEndCapture crashes (measured: tools/graph_probe.py, PROBE_HOLD=1 - the reason torch's own recipe warms up on a
-        # side stream).  After backward() nothing can use the graph anyway.
         if isinstance(out, tuple):
             return tuple(t.detach() if isinstance(t, torch.Tensor) else t for t in out)
         return out.detach()

@@ -81,9 +81,9 @@ def _round_bf16(a):
 
 
 # Kernel selection of subreg_conv_fwd for the wide layers (Cout % 160 == 0, bf16, eval mode): "auto" = the dispatcher's measured rule,
-# "general" = conv_fwd.hip forced, "wide" = the one-wave-per-SIMD kernel of conv_wide.hip forced.  The parity tests below run over
-# all three.
-KERNELS = ["auto", "general", "wide"]
+# "general" = conv_fwd.hip forced, "wide" = conv_wide.hip forced in its default MFMA shape (16x16x32: conv_wide16_kernel),
+# "wide_alt" = conv_wide.hip in the other shape (32x32x16: conv_wide_kernel).  The parity tests below run over all four.
+KERNELS = ["auto", "general", "wide", "wide_alt"]
 
 
 def _kernel_flag(kernel, dtype, Cout, k=3):
@@ -91,7 +91,9 @@ def _kernel_flag(kernel, dtype, Cout, k=3):
         return 0
     if dtype != "bf16" or Cout % 160 != 0 or k != 3:
         pytest.skip("one kernel only for this problem")
-    return _lib.CONV_KERNEL_GENERAL if kernel == "general" else _lib.CONV_KERNEL_WIDE
+    if kernel == "general":
+        return _lib.CONV_KERNEL_GENERAL
+    return _lib.CONV_KERNEL_WIDE | (_lib.CONV_KERNEL_WIDE_ALT if kernel == "wide_alt" else 0)
 
 
 CONV_CASES = [
@@ -651,7 +653,23 @@ def test_graphed_eval_forward_equals_eager_and_follows_weight_updates():
         for x, w in zip(xs, want):
             got = hb.forward_graphed(x)
             assert torch.equal(got, w), (rep, (got - w).abs().max().item())
-    assert hb._graphs[tuple(xs[0].shape)]["graph"] is not None
+    assert hb._graphs[(tuple(xs[0].shape), 0)]["graph"] is not None
+    # input-sequence prefetch: the same three tensors in the same order - the later rounds are served by forwards started ahead of their
+    # call (same results, asserted above); an in-place edit of a predicted tensor (its _version moves) drops the prediction
+    if hb.EVAL_PREFETCH > 0:
+        assert hb.prefetch_hits >= 2, hb.prefetch_hits
+        hits = hb.prefetch_hits
+        hb.forward_graphed(xs[0])                          # (starts the forwards of xs[1], xs[2] as they were)
+        with torch.no_grad():
+            xs[1].mul_(0.5)
+        want_half = hb.forward(xs[1]).clone()
+        assert not torch.equal(want_half, want[1])
+        assert torch.equal(hb.forward_graphed(xs[1]), want_half) and hb.prefetch_hits == hits
+        assert torch.equal(hb.forward_graphed(xs[2]), want[2])
+        want[1] = want_half
+        for x, w in zip(xs, want):                         # and the chain is learnt again
+            assert torch.equal(hb.forward_graphed(x), w)
+        torch.cuda.synchronize()
     with torch.no_grad():
         params["layer2.0.conv2.weight"].mul_(1.25)         # in-place update: version bump -> re-pack -> cached graph dropped
     want2 = hb.forward(xs[0]).clone()
@@ -690,7 +708,7 @@ def test_graphed_eval_forward_equals_eager_and_follows_weight_updates():
             assert torch.equal(hb.forward_graphed(x7), want7)
             assert torch.equal(hb.forward_graphed(x7), want7)
         assert len(hit) == 1 and any("could not be captured" in str(w.message) for w in wl)
-        assert hb._graphs[tuple(x7.shape)]["eager_only"]
+        assert hb._graphs[(tuple(x7.shape), 0)]["eager_only"]
     finally:
         hb.forward = real_forward
 

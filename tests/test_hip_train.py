@@ -679,48 +679,77 @@ def _plain_net(dtype, dropblock=False, seed=71):
     return net.cuda()
 
 
-@pytest.mark.parametrize("case", [("f32", 32, 8, False), ("bf16", 32, 8, True), ("bf16", 84, 64, False)],
-                         ids=["f32_hw32_B8", "bf16_hw32_B8_dropblock5", "bf16_hw84_B64"])
-def test_graphed_step_replays_the_eager_step_bit_for_bit(case):
-    """train.GraphedStep (the pretraining driver's step as ONE replayed hipGraph, train_supervised.py:229-244): six steps - two eager
-    warm-up calls, the capture + first replay, three more replays - against six eager steps from the same start, the same batches
-    and the same host generator state per step (the masks' seeds are drawn from it in the same order by both).  Dropout / DropBlock
-    masks (fresh every replay, DropBlock's gamma moving with the forward counter), batch statistics, running statistics, the two
-    backward streams, the fused SGD + re-pack: every parameter, buffer and loss must be IDENTICAL, so every parity statement about
-    the eager step (reference goldens, stash-fed oracle backward) holds for the replayed one."""
+@pytest.mark.parametrize("case", [("f32", 32, 8, False), ("bf16", 84, 6, True), ("bf16", 84, 64, False)],
+                         ids=["f32_hw32_B8", "bf16_hw84_B6_dropblock5", "bf16_hw84_B64"])
+def test_graphed_step_replay_equals_the_eager_step_from_the_same_state(case):
+    """train.GraphedStep (the pretraining driver's step as ONE replayed hipGraph, train_supervised.py:229-244).  After two eager
+    warm-up calls and the capture, the state (parameters, buffers, momentum, forward counters) is saved, ONE step is made by replay,
+    the state is restored and the SAME step (same batch, same host generator state: the masks' seeds are drawn from it in the same
+    order by both) is made eagerly.  The loss, every BatchNorm parameter / statistic / momentum and the classifier must be IDENTICAL -
+    fresh dropout / DropBlock masks with DropBlock's gamma at the forward counter's value, batch statistics, the two backward
+    streams, the fused SGD + re-pack all behave as in the eager step; the conv weights, some of whose dW kernels accumulate with
+    float atomics (every f32 dW, the bf16 1x1 shortcut and first-layer dW: csrc/backward.hip), agree to that run-to-run noise
+    (1e-5 of the tensor; a missed re-pack or a stale mask would be 1e-2).  So every parity statement about the eager step (reference goldens, stash-fed oracle
+    backward) holds for the replayed one."""
     from subreg_hip.train import SGD, GraphedStep
     dtype, hw, B, dropblock = case
     crit = torch.nn.CrossEntropyLoss()
-    xs = [torch.from_numpy(syn.make_images(300 + i, B, hw)).cuda() for i in range(3)]
-    ys = [torch.from_numpy(np.random.RandomState(400 + i).randint(0, 60, B)).cuda() for i in range(3)]
-    results = []
-    for graphed in (False, True):
-        net = _plain_net(dtype, dropblock).train()
-        opt = SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
-        stepper = GraphedStep(net, opt, lambda a, b, _n=net: crit(_n(a), b)) if graphed else None
-        losses = []
-        for i in range(6):
-            torch.manual_seed(1000 + i)
-            if i == 4:
-                opt.lr = 0.02                          # a learning-rate change: a second graph (two eager calls, then its capture)
-            if graphed:
-                loss = stepper(xs[i % 3], ys[i % 3])
-            else:
-                loss = crit(net(xs[i % 3]), ys[i % 3])
-                opt.zero_grad()
-                loss.backward()
-                opt.step()
-            losses.append(float(loss.item()))
-        torch.cuda.synchronize()
-        if graphed:
-            assert stepper.replays == 2 and not any(e["failed"] for e in stepper.entries.values()), (stepper.replays, stepper.entries)
-        sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
-        results.append((losses, sd, list(net.hip_backbone().nbt)))
-    (la, sa, na), (lb, sb, nb) = results
-    assert la == lb, (la, lb)
-    assert na == nb
-    for k in sa:
-        assert torch.equal(sa[k], sb[k]), ("state after six steps", k, float((sa[k].float() - sb[k].float()).abs().max()))
+    xs = [torch.from_numpy(syn.make_images(300 + i, B, hw)).cuda() for i in range(4)]
+    ys = [torch.from_numpy(np.random.RandomState(400 + i).randint(0, 60, B)).cuda() for i in range(4)]
+    net = _plain_net(dtype, dropblock).train()
+    hb = net.hip_backbone()
+    opt = SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+    stepper = GraphedStep(net, opt, lambda a, b: crit(net(a), b))
+    for i in range(3):
+        torch.manual_seed(1000 + i)
+        stepper(xs[i], ys[i])
+    torch.cuda.synchronize()
+    assert stepper.replays == 1 and not any(e["failed"] for e in stepper.entries.values())
+
+    def snapshot():
+        return ({k: v.detach().clone() for k, v in net.state_dict().items()}, [b.clone() for b in opt.bufs], list(hb.nbt))
+    saved = snapshot()
+    torch.manual_seed(1003)
+    loss_g = float(stepper(xs[3], ys[3]).item())
+    assert stepper.replays == 2
+    after_g = snapshot()
+    with torch.no_grad():                                                  # back to the saved state, in place
+        sd = net.state_dict()
+        for k, v in saved[0].items():
+            sd[k].copy_(v)
+        for b, v in zip(opt.bufs, saved[1]):
+            b.copy_(v)
+    hb.nbt = list(saved[2])
+    torch.manual_seed(1003)
+    loss = crit(net(xs[3]), ys[3])
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    after_e = snapshot()
+    assert loss_g == float(loss.item()), (loss_g, float(loss.item()))
+    assert after_g[2] == after_e[2]
+    worst = 0.0
+    for (k, g), e in list(zip(after_g[0].items(), after_e[0].values())) + [(("momentum %d" % i, g), e) for i, (g, e) in enumerate(zip(after_g[1], after_e[1]))]:
+        # conv weights / their momentum: some dW kernels accumulate with float atomics (every f32 one, the bf16 1x1 and K = 32 first-layer
+        # ones, the fallback for shapes the streaming kernel does not take) - those agree to their run-to-run noise, the rest exactly
+        atomics = g.dim() == 4
+        if atomics:
+            rel = float((g.double() - e.double()).norm() / max(float(e.double().norm()), 1e-30))
+            worst = max(worst, rel)
+            assert rel < 1e-5, ("replayed vs eager step (atomic dW)", k, rel)
+        else:
+            assert torch.equal(g, e), ("replayed vs eager step", k, float((g.double() - e.double()).abs().max()))
+    print("atomic-dW tensors: worst relative difference %.2e" % worst)
+    # a learning-rate change makes a second graph (two eager calls, then its capture); the first stays cached.  `loss` - the eager
+    # step's, with its autograd graph and the leaves' AccumulateGrad nodes of the DEFAULT stream - is still alive here on purpose:
+    # a capture that went through loss.backward() re-used those nodes and crashed in hipStreamEndCapture (GraphedStep._eager)
+    assert loss.grad_fn is not None
+    opt.lr = 0.02
+    for i in range(3):
+        stepper(xs[i], ys[i])
+    torch.cuda.synchronize()
+    assert len(stepper.entries) == 2 and stepper.replays == 3 and not any(e["failed"] for e in stepper.entries.values())
 
 
 def test_graphed_step_interleaved_with_another_batch_shape_repacks_its_weights():
@@ -754,9 +783,16 @@ def test_graphed_step_interleaved_with_another_batch_shape_repacks_its_weights()
         if stepper is not None:
             assert stepper.replays >= 3
         finals.append({k: v.detach().clone() for k, v in net.state_dict().items()})
+    # (f32 dW accumulates with float atomics: runs differ in the last bits and eight steps amplify that - a stale dX weight copy, the
+    # bug this guards against, is a one-step-old weight: ~lr x gradient = 1e-2 of the tensor)
     for k in finals[0]:
-        assert torch.equal(finals[0][k], finals[1][k]), ("eager, interleaved shapes", k)
-        assert torch.equal(finals[0][k], finals[2][k]), ("graphed, interleaved shapes", k)
+        if not finals[0][k].dtype.is_floating_point:
+            assert torch.equal(finals[0][k], finals[1][k]) and torch.equal(finals[0][k], finals[2][k]), k
+            continue
+        ref = finals[0][k].double()
+        for tag, other in (("eager", finals[1][k]), ("graphed", finals[2][k])):
+            rel = float((other.double() - ref).norm() / max(float(ref.norm()), 1e-30))
+            assert rel < 2e-4, (tag + ", interleaved shapes", k, rel)
 
 
 def test_adam_step_matches_torch_optim_adam():
