@@ -254,7 +254,7 @@ def sweep_model_wall(args, model, sweep_leg):
     return out
 
 
-def route_a(args, net, opt, meta, dev, n_epochs=8):
+def route_a(args, net, opt, meta, dev, n_epochs=16):
     """Throughput of drop-in route A: the reference's UNCHANGED loop statements (language_eval.py:242-326)
     over the drop-in modules - nn.Module forward through the HIP backbone, torch autograd for CE + regloss + LangPuller,
     torch.optim.SGD, one forward per query set - at the shape of the LAST session (125 support images, 8 query sets of 125,
@@ -292,7 +292,7 @@ def route_a(args, net, opt, meta, dev, n_epochs=8):
                 out = net(qx)
                 accs.append((out.argmax(1) == qy).float().sum().item())
         return lv, accs
-    for _ in range(2):
+    for _ in range(4):             # (the module's per-shape graphs and its input-sequence prefetch are in place after three epochs)
         epoch()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -530,6 +530,7 @@ def main():
                     help="also run the S-seed x 8-session sweep (configs[3]) after the timed region; 0 = skip")
     ap.add_argument("--sweep-deadline", type=int, default=900, help="seconds after which the sweep leg is abandoned")
     ap.add_argument("--sweep-only", action="store_true", help="(internal) run only the one-rank sweep leg and print {\"sweep\": ...}")
+    ap.add_argument("--route-a-only", action="store_true", help="(measurements) run only the route-A leg and print {\"route_a\": ...}")
     ap.add_argument("--pretrain-only", action="store_true", help="(internal) run only the pretraining-step leg and print {\"pretrain\": ...}")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the pretraining-step, route-A and sweep-model legs")
     ap.add_argument("--reuse-features", action="store_true",
@@ -586,6 +587,10 @@ def main():
     net, opt = make_net(args, seed, dev)
     meta, base = make_run_inputs(seed, dev, args.base_batch)
     eps = args.epochs_per_sync or args.epochs
+    if args.route_a_only:
+        assert world == 1
+        print(json.dumps({"route_a": route_a(args, net, opt, meta, dev, n_epochs=16)}), flush=True)
+        return
 
     def new_runner(profile):
         # fresh run state: base classifier rows, BN stats keep evolving across runs (synthetic, values do not matter)

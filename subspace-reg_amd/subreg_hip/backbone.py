@@ -187,13 +187,15 @@ class HipBackbone:
             ncol = self._col_elems(B, H, W, False)                   # lanes run eval-mode forwards only
             cb, cc = ln["cap"]
             if nbytes > cb:
-                self._ws_token += 1
+                if cb > 0:
+                    self._ws_token += 1                # (a lane's FIRST workspaces move nothing a cached graph points at)
                 cb = nbytes
                 ln["ws"] = [torch.empty(cb, dtype=torch.uint8, device=self.device) for _ in range(4)]
                 for k in range(4):
                     ln["desc"].ws[k] = ln["ws"][k].data_ptr()
             if ncol > cc:
-                self._ws_token += 1
+                if cc > 0:
+                    self._ws_token += 1
                 cc = ncol
                 ln["col"] = torch.empty(cc, dtype=self.tdtype, device=self.device)
                 ln["desc"].col = ln["col"].data_ptr()

@@ -658,8 +658,8 @@ def test_graphed_eval_forward_equals_eager_and_follows_weight_updates():
     # call (same results, asserted above); an in-place edit of a predicted tensor (its _version moves) drops the prediction
     if hb.EVAL_PREFETCH > 0:
         assert hb.prefetch_hits >= 2, hb.prefetch_hits
-        hits = hb.prefetch_hits
         hb.forward_graphed(xs[0])                          # (starts the forwards of xs[1], xs[2] as they were)
+        hits = hb.prefetch_hits
         with torch.no_grad():
             xs[1].mul_(0.5)
         want_half = hb.forward(xs[1]).clone()
@@ -691,7 +691,7 @@ def test_graphed_eval_forward_equals_eager_and_follows_weight_updates():
     assert all(e["graph"] is None or e["tokens"] == tokens for e in hb._graphs.values())
     # a capture that fails leaves the shape on the eager path (no retry every call), with a warning, and the right result
     import warnings
-    x7 = _t(syn.make_images(77, 7, 84))
+    x7 = _t(syn.make_images(77, hb.GRAPH_CACHE + 9, 84))       # (a batch size the loop above has not captured)
     want7 = hb.forward(x7).clone()
     hb.forward_graphed(x7)
     real_forward, hit = hb.forward, []

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV: per kernel (short name) and, for the conv kernels, per launch geometry
 (= per layer shape).  Usage: prof_summary.py <kernel_trace.csv> [--top N] [--conv] [--images N] [--timeline N]
-(--timeline N: the last N launches in start order with duration, gap to the previous kernel's end and grid)"""
+(--timeline N: the last N launches in start order with duration, gap to the previous kernel's end and grid;
+--busy: the union of all kernel intervals beside the sum of their durations)"""
 import csv
 import re
 import sys
@@ -74,6 +75,20 @@ def main():
     print("total kernel time %.1f ms" % (total * 1e-3))
     for n, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:top]:
         print("%-64s calls %6d  total %9.1f us  avg %9.1f us  %5.1f%%" % (n[:64], c, t, t / c, 100 * t / total))
+    if "--busy" in sys.argv:
+        # union of the busy intervals of the whole trace (kernels of concurrent lanes / streams overlap: the sum of their durations
+        # exceeds the wall time, the union cannot) - what a two-lane trace is compared with the bench line's own wall time by
+        iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(path)))
+        cur_s, cur_e, union = iv[0][0], iv[0][1], 0
+        for a, b in iv[1:]:
+            if a > cur_e:
+                union += cur_e - cur_s
+                cur_s, cur_e = a, b
+            else:
+                cur_e = max(cur_e, b)
+        union += cur_e - cur_s
+        print("busy (union of all kernel intervals) %.1f ms of a %.1f ms trace span; sum of kernel durations %.1f ms (overlap factor %.3f)"
+              % (union * 1e-6, (iv[-1][1] - iv[0][0]) * 1e-6, total * 1e-3, total * 1e3 / max(union, 1)))
     if "--images" in sys.argv:
         # roofline.frac of bench.py from the trace alone: the forward's kernels (conv family + avgpool) over the images forwarded
         # in the traced process (warm-up included).  Only meaningful for a ONE-lane run (SUBREG_EVAL_LANES=1): two lanes overlap.

@@ -1,16 +1,4 @@
 mkdir -p gpurun_out/r06
-python -m pytest tests -x -q -m gpu > gpurun_out/r06/t_all.log 2>&1; grep -v "amdgpu.ids" gpurun_out/r06/t_all.log | tail -15
-L=$PWD/subspace-reg_amd/subreg_hip
-O=gpurun_out/r06/wide16_vs_general.txt; : > $O
-for B in 250 375 500 700 1000 1125; do
-  for rep in 1 2; do
-    for k in general wide; do
-      echo "== batch $B kernel $k round $rep" >> $O
-      python tools/bench_conv.py --batch $B --kernel $k 2>&1 | grep "^L[234]" >> $O
-    done
-  done
-done
-echo "== loop ends stamps (wide, 16x16x32)" >> $O
-SUBREG_LIB=$L/libsubreg_wd8.so python tools/diag_conv.py --batch 700 --kernel wide 2>&1 | grep -v amdgpu.ids >> $O
-tail -14 $O
-for d in 0 1 2 3; do SUBREG_EVAL_PREFETCH=$d python tools/bench_prefetch.py 125 2>&1 | grep prefetch; done | tee gpurun_out/r06/prefetch.txt
+python -m pytest tests -x -q -m gpu > gpurun_out/r06/t_all.log 2>&1; grep -v "amdgpu.ids" gpurun_out/r06/t_all.log | tail -6
+for d in 0 2 0 2; do echo "SUBREG_EVAL_PREFETCH=$d"; SUBREG_EVAL_PREFETCH=$d python bench.py --route-a-only 2>/dev/null | cut -c1-200; done | tee gpurun_out/r06/route_a_prefetch.txt
+python bench.py --no-cpu-baseline 2> gpurun_out/r06/bench_b.err | tee gpurun_out/r06/bench_b.json | cut -c1-900
