@@ -302,7 +302,10 @@ def route_a(args, net, opt, meta, dev, n_epochs=16):
     dt = (time.perf_counter() - t0) / n_epochs
     with torch.no_grad():
         net.classifier.weight = torch.nn.Parameter(net.classifier.weight.detach()[:60].clone())
+    hb = net.hip_backbone()
     return {"epochs_per_s": 1.0 / dt, "ms_per_epoch": dt * 1e3, "images_per_epoch": 1125,
+            "prefetch": {"depth": int(hb.EVAL_PREFETCH), "forwards_served_from_a_prefetch": int(hb.prefetch_hits),
+                         "forwards": 9 * (n_epochs + 4), "cached_graphs": len(hb._graphs)},
             "shape": "session 8 of 8: 125 support + 8 x 125 query images, 9 backbone forwards, torch autograd + SGD on classifier.weight [100, 640]"}
 
 

@@ -29,6 +29,7 @@
 // (2x2 max over four registers); both leave through a per-wave LDS slab as whole 16-byte vectors.
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "conv_args.h"
@@ -1093,14 +1094,29 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
 // ---------------------------------------------------------------------------- host side
 namespace {
 
+// largest patch (pixel rows) any m-tile of the problem stages.  The walk over the m-tiles is O(M / TM) host work (~8 k patch_range calls at
+// 1125 images of 42x42) and the dispatcher asks twice per launch: the last answers are kept per (B, H, W, pool, TM).
 template <bool POOL>
 int worst_patch_rows_w(const ConvGeom& g, int TM) {
+    struct Entry { int B, H, W, TM, pool, worst; };
+    static std::mutex mu;
+    static Entry cache[16];
+    static int n_cached = 0, next_slot = 0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (int i = 0; i < n_cached; ++i)
+            if (cache[i].B == g.B && cache[i].H == g.H && cache[i].W == g.W && cache[i].TM == TM && cache[i].pool == (POOL ? 1 : 0)) return cache[i].worst;
+    }
     int worst = 0;
     for (int m0 = 0; m0 < g.M; m0 += TM) {
         int lo, hi;
         patch_range<POOL>(g, m0, TM, &lo, &hi);
         if (hi - lo > worst) worst = hi - lo;
     }
+    std::lock_guard<std::mutex> lk(mu);
+    cache[next_slot] = Entry{g.B, g.H, g.W, TM, POOL ? 1 : 0, worst};
+    next_slot = (next_slot + 1) % 16;
+    if (n_cached < 16) ++n_cached;
     return worst;
 }
 

@@ -436,6 +436,49 @@ class HipBackbone:
             self._prefetch(x, tokens, cur)
         return feat
 
+    def _parallel_streams(self, n):
+        """n streams whose kernels really run beside each other's and beside the current stream's.  HIP deals streams onto a few hardware
+        queues in creation order (and by priority), and two streams on one queue execute one after the other: in a process that had made
+        other streams before, the two prefetch streams shared a queue and depth 2 ran like depth 1 (11.0 instead of 7.9 ms per nine
+        forwards, profiles/r06_prefetch_queues.txt: which stream counts collide depends on the priority, none is safe).  So the
+        streams are CHOSEN by measurement, once: a spin kernel on two candidates at a time - those that finish together in one
+        spin's time run in parallel."""
+        dev, cur = self.device, torch.cuda.current_stream()
+        cands = [torch.cuda.Stream(device=dev, priority=-(i % 2)) for i in range(10)]
+        if os.environ.get("SUBREG_PREFETCH_CALIBRATE", "1") == "0":
+            return cands[:n]
+        spin = 2_000_000                                               # ticks of torch.cuda._sleep (~1 ms); only ratios are used
+
+        def timed(streams):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0.record(cur)
+            for st in streams:
+                if st is not cur:
+                    st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(spin)
+            for st in streams:
+                if st is not cur:
+                    cur.wait_stream(st)
+            e1.record(cur)
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1)
+        try:
+            timed([cur])
+            one = min(timed([cur]), timed([cur]))
+            free = [c for c in cands if min(timed([c, cur]), timed([c, cur])) < 1.3 * one]     # beside the caller's stream
+            chosen = []
+            for c in free:                                                                    # and beside each other
+                if all(min(timed([c, o]), timed([c, o])) < 1.3 * one for o in chosen):
+                    chosen.append(c)
+                    if len(chosen) == n:
+                        break
+            self.prefetch_streams_calibrated = len(chosen)
+            return chosen + [c for c in cands if c not in chosen][:n - len(chosen)]
+        except Exception:                                              # noqa: BLE001 - no spin kernel on this build: creation order it is
+            return cands[:n]
+
     def _prefetch(self, x, tokens, cur):
         """Remember that x followed the previous call's tensor; start the forwards of the tensors that followed x last time."""
         hist = self._spec_next
@@ -458,8 +501,8 @@ class HipBackbone:
                 return                                                    # (only shapes whose own graph exists: seen at least twice)
             used = {p["set"] for p in pend}
             sset = next(s for s in range(1, self.EVAL_PREFETCH + 2) if s not in used)
-            while len(self._spec_streams) <= sset:
-                self._spec_streams.append(torch.cuda.Stream(device=self.device))
+            if len(self._spec_streams) <= sset:
+                self._spec_streams = [None] + self._parallel_streams(self.EVAL_PREFETCH + 1)
             st = self._spec_streams[sset]
             key = (tuple(nx.shape), sset)
             ent = self._graph_entry(key)

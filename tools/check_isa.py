@@ -43,6 +43,20 @@ def main():
         print("check_isa: no device .s files in %s (build with -save-temps=obj)" % d)
         return 1
     rc = 0
+    # every kernel source named on the command line (the Makefile passes csrc/*.hip) must have its ISA here, and that ISA must be
+    # at least as new as the source: a build directory from before -save-temps, or an incremental rebuild of one file, must not pass
+    # on the strength of the files that happen to exist
+    for src in sys.argv[2:]:
+        stem = os.path.splitext(os.path.basename(src))[0]
+        isa = os.path.join(d, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+        if not os.path.exists(isa):
+            rc = 1
+            print("check_isa: no ISA for %s in %s (object built without -save-temps=obj?)" % (src, d))
+        elif os.path.getmtime(isa) + 1.0 < os.path.getmtime(src):
+            rc = 1
+            print("check_isa: %s is older than %s" % (isa, src))
+    if rc:
+        return rc
     for f in files:
         bad = check(f)
         if bad:

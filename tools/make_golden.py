@@ -588,7 +588,7 @@ def gen_train_step(cases=((84, 6), (32, 8)), fname="train_step.npz"):
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["blocks", "backbone", "reg", "train", "train64", "loop32", "adam", "bias", "semantic", "episodes", "loop84"]
+    what = sys.argv[1:] or ["blocks", "backbone", "reg", "train", "train64", "loop32", "adam", "bias", "semantic", "episodes", "loop84", "freeze_opts"]
     if "blocks" in what:
         gen_blocks()
     if "backbone" in what:

@@ -1,4 +1,3 @@
-mkdir -p gpurun_out/r06
-python -m pytest tests -x -q -m gpu > gpurun_out/r06/t_all.log 2>&1; grep -v "amdgpu.ids" gpurun_out/r06/t_all.log | tail -6
-for d in 0 2 0 2; do echo "SUBREG_EVAL_PREFETCH=$d"; SUBREG_EVAL_PREFETCH=$d python bench.py --route-a-only 2>/dev/null | cut -c1-200; done | tee gpurun_out/r06/route_a_prefetch.txt
-python bench.py --no-cpu-baseline 2> gpurun_out/r06/bench_b.err | tee gpurun_out/r06/bench_b.json | cut -c1-900
+for n in 0 1 2 3 5 7 9 12; do python tools/bench_prefetch.py 125 $n 2>&1 | grep "prefetch depth"; done | tee gpurun_out/r06/prefetch_queues2.txt
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline --sweep-seeds 0 2>/dev/null | python3 -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(j.get('route_a')))"
+python -m pytest tests/test_hip_kernels.py -x -q -k "graphed_eval" 2>&1 | tail -2
