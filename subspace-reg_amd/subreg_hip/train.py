@@ -128,7 +128,11 @@ class TrainStash:
         # buffers live as long as this stash.
         self.side_stream, self._events = None, []
         if os.environ.get("SUBREG_TRAIN_ONE_STREAM", "0") != "1":
-            self.side_stream = torch.cuda.Stream(device=dev)
+            # (a stream whose kernels really run beside the caller's: HIP deals streams onto a few hardware queues in creation order, and two
+            # streams on one queue execute one after the other - HipBackbone._parallel_streams picks by measurement, once per backbone)
+            if getattr(hb, "_train_side_stream", None) is None:
+                hb._train_side_stream = hb._parallel_streams(1)[0]
+            self.side_stream = hb._train_side_stream
             self.desc.side_stream = self.side_stream.cuda_stream
             for i in range(len(self.desc.events)):
                 e = C.c_void_p()
