@@ -48,6 +48,8 @@ extern "C" {
 #define SUBREG_CONV_KERNEL_GENERAL 256
 #define SUBREG_CONV_KERNEL_WIDE 512
 #define SUBREG_CONV_KERNEL_WIDE_ALT 1024  /* with _WIDE: the OTHER MFMA shape of conv_wide.hip than its default for the problem (16x16x32 by default): parity tests, A/B runs */
+#define SUBREG_CONV_KERNEL_WIDE_128 2048  /* with _WIDE: the 128-row tiling of conv_wide16_kernel (SUBREG_EUNSUPPORTED where its patch does not fit) */
+#define SUBREG_CONV_KERNEL_WIDE_256 4096  /* with _WIDE: the 256-row tiling */
 
 /* flags of subreg_backbone_forward */
 #define SUBREG_FWD_TRAIN 1 /* BN batch statistics + running-stat update + keep masks (net.train(), eval/language_eval.py:211) */

@@ -29,7 +29,8 @@ struct ConvArgs {
 // GEMM, optional 2x2 max-pool) on 512-row x 160-channel tiles, one 4-wave workgroup per CU.  SUBREG_EUNSUPPORTED when the
 // problem is outside that set (the caller then takes the general kernel).
 // tr: MFMA tile edge of the 256-row tiling (16: conv_wide16_kernel, 32: conv_wide_kernel<2>); 0 = the default for the problem
-int conv_wide(const ConvArgs& a, bool pool, hipStream_t stream, int tr = 0);
+// rows: tile height of the 16x16x32 form (256, or 128 where the problem's patch fits); 0 = the measured default for the problem
+int conv_wide(const ConvArgs& a, bool pool, hipStream_t stream, int tr = 0, int rows = 0);
 int conv_wide_default_tr(bool pool);
 // does conv_wide take this problem, and should the dispatcher prefer it (measured rule)?
 bool conv_wide_supported(const ConvArgs& a, bool pool);

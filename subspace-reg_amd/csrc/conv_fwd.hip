@@ -1209,7 +1209,8 @@ static int conv_fwd_impl(const void* x, const void* w, void* y, const float* sca
             const bool force = flags & SUBREG_CONV_KERNEL_WIDE;
             if (force || conv_wide_preferred(a, pool)) {
                 const int dtr = conv_wide_default_tr(pool);
-                const int rc = conv_wide(a, pool, s, (flags & SUBREG_CONV_KERNEL_WIDE_ALT) ? 48 - dtr : dtr);
+                const int rows = (flags & SUBREG_CONV_KERNEL_WIDE_128) ? 128 : (flags & SUBREG_CONV_KERNEL_WIDE_256) ? 256 : 0;
+                const int rc = conv_wide(a, pool, s, (flags & SUBREG_CONV_KERNEL_WIDE_ALT) ? 48 - dtr : dtr, rows);
                 if (rc != SUBREG_EUNSUPPORTED || force) return rc;
             }
         } else if (flags & SUBREG_CONV_KERNEL_WIDE) {

@@ -622,10 +622,17 @@ __device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x4& acc
 }
 }  // namespace
 
-template <bool POOL, int AROWS>
-__global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
+// NA = 4: the 256-row tiling described above.  NA = 2 (round 6, second half): the SAME kernel on 128 x 160 tiles (32 x 160 per wave, 80
+// accumulator registers, three workgroups per CU where the patch is small: the 10x10 / 5x5 maps) - what the general kernel's 128-row /
+// 16x16x32 tiles do, under this file's loop (unconditional DMA slots, reads running ahead through the steps, one barrier per step).
+// Its step is B-major all the way (20 MFMAs = 10 groups of two): with 80 accumulators there are registers for the A fragments
+// double-buffered a step ahead and a B ring of five read FOUR groups (128 cycles) ahead - 10 groups per step and five slots: b_g always
+// sits in slot g % 5, in every step.
+template <int NA, bool POOL, int AROWS, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv_wide16_kernel(const ConvArgs a) {
     constexpr bool SWAPC = !POOL;
-    constexpr int NW = 4, NA = 4, NB = 10, TM = 256, TN = 160, TR = 16;
+    constexpr int NW = 4, NB = 10, RW = NA * 16, TM = NW * RW, TN = 160, TR = 16;    // RW rows per wave
+    static_assert(NA == 4 || NA == 2, "step schedules below");
     constexpr int ROWB = 64, RPP = 16, SLOTS = 4, ELEM = 2, TAPS = 9, CENTER = 4;
     constexpr int BTAP = TN * ROWB, NWB = 3;
     constexpr int ABUF = (AROWS + 1) * ROWB;
@@ -721,7 +728,7 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
         const unsigned zad = (unsigned)(AROWS * ROWB + 16 * lh);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int m = m0 + wid * 64 + i * TR + lr;
+            const int m = m0 + wid * RW + i * TR + lr;
             const unsigned mv = m < g.M ? 1u : 0u;
             const Pix px = row_to_pixel<POOL>(g, mv ? m : 0);
             unsigned okh[3], okw[3];
@@ -776,7 +783,8 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
     };
     auto rd_b = [&](int j, int boff) -> uint4 { return *reinterpret_cast<const uint4*>(smem + boff + j * (TR * ROWB) + baddr0); };
 
-    uint4 fa[NA], ring[4];
+    uint4 fa[NA], ring[4];          // NA = 4
+    uint4 fa2[2][2], ring5[5];      // NA = 2: A sets of two steps, B ring of five
     // One step on the fragments in registers (RO = 0 or 2: b_j of this step sits in ring slot (j + RO) % 4):
     //   P0   a0b0 a0b1 a1b0 a1b1 | a2b0 a2b1 a3b0 a3b1      reads: b2 in front, b3 in the middle
     //   G2 .. G7   a0..a3 x b_G                             reads: b_{G+2} in front of each           (MID between G4 and G5)
@@ -846,12 +854,37 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    // NA = 2: group G of a step on A set CUR: DMA slot, reads (b_{G+4}: G <= 5 this step's, G >= 6 the next step's b'_{G-6}; G = 5, 6: a'_0, a'_1 of
+    // the next step into the other A set), two MFMAs
+    auto sgroup = [&](auto g_tag, auto cur_tag, auto next_tag, int boff, int n_aoff, auto ntap_tag, int n_boff, auto&& dma) {
+        constexpr int G = decltype(g_tag)::value, CUR = decltype(cur_tag)::value, NTAP = decltype(ntap_tag)::value;
+        constexpr bool NEXT = decltype(next_tag)::value;
+        if (SUBREG_WIDE_DIAG != 1) dma(g_tag);
+        if constexpr (SUBREG_WIDE_DIAG != 2) {
+            constexpr int NRD = ((G <= 5 || NEXT) ? 1 : 0) + ((NEXT && (G == 5 || G == 6)) ? 1 : 0);
+            if constexpr (G <= 5) ring5[(G + 4) % 5] = rd_b(G + 4, boff);
+            else if constexpr (NEXT) ring5[(G + 4) % 5] = rd_b(G - 6, n_boff);
+            if constexpr (NEXT && (G == 5 || G == 6)) fa2[CUR ^ 1][G - 5] = rd_a(G - 5, n_aoff, NTAP);
+            mma_ab(fa2[CUR][0], ring5[G % 5], acc[0][G]);
+            mma_ab(fa2[CUR][1], ring5[G % 5], acc[1][G]);
+            if constexpr (NRD > 0) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto no_dma = [](auto) {};
-    // the first step's fragments: a_0 .. a_3, b_0, b_1
+    // the first step's fragments: a_0 .. a_3, b_0, b_1 (NA = 2: a_0, a_1, b_0 .. b_3)
+    if constexpr (NA == 4) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) fa[i] = rd_a(i, A_BASE, 0);
-    ring[0] = rd_b(0, 0);
-    ring[1] = rd_b(1, 0);
+        for (int i = 0; i < NA; ++i) fa[i] = rd_a(i, A_BASE, 0);
+        ring[0] = rd_b(0, 0);
+        ring[1] = rd_b(1, 0);
+    } else {
+        fa2[0][0] = rd_a(0, A_BASE, 0);
+        fa2[0][1] = rd_a(1, A_BASE, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ring5[j] = rd_b(j, 0);
+    }
 
     auto mid_sync = [&](bool drain_lds, int do_wait = 0) {
         unsigned long long q0 = 0, q1 = 0;
@@ -894,10 +927,19 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
             constexpr bool SAME = TAP < 8;
             constexpr int NT = SAME ? TAP + 1 : -1;
             const int boff = SL * BTAP, nboff = ((TAP + 1) % NWB) * BTAP, n_aoff = SAME ? aoff : naoff;
-            pair0(IC<RO>{}, boff);
-            group(IC<2>{}, IC<RO>{}, std::true_type{}, boff, nboff, no_dma);
-            group(IC<3>{}, IC<RO>{}, std::true_type{}, boff, nboff, no_dma);
-            group(IC<4>{}, IC<RO>{}, std::true_type{}, boff, nboff, no_dma);
+            constexpr int CUR = TAP & 1;                                  // (NA = 2: a chunk starts on A set 0)
+            if constexpr (NA == 4) {
+                pair0(IC<RO>{}, boff);
+                group(IC<2>{}, IC<RO>{}, std::true_type{}, boff, nboff, no_dma);
+                group(IC<3>{}, IC<RO>{}, std::true_type{}, boff, nboff, no_dma);
+                group(IC<4>{}, IC<RO>{}, std::true_type{}, boff, nboff, no_dma);
+            } else {
+                sgroup(IC<0>{}, IC<CUR>{}, std::true_type{}, boff, n_aoff, IC<NT>{}, nboff, no_dma);
+                sgroup(IC<1>{}, IC<CUR>{}, std::true_type{}, boff, n_aoff, IC<NT>{}, nboff, no_dma);
+                sgroup(IC<2>{}, IC<CUR>{}, std::true_type{}, boff, n_aoff, IC<NT>{}, nboff, no_dma);
+                sgroup(IC<3>{}, IC<CUR>{}, std::true_type{}, boff, n_aoff, IC<NT>{}, nboff, no_dma);
+                sgroup(IC<4>{}, IC<CUR>{}, std::true_type{}, boff, n_aoff, IC<NT>{}, nboff, no_dma);
+            }
             mid_sync(false, (TAP >= 1 && TAP - 1 <= PLAST) ? 1 : 0);
             constexpr int WSL = (TAP + 2) % NWB;
             const char* wsrc = a.w;
@@ -934,10 +976,18 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
                     dma16(psrc, pv_last + rfl(puoff + (unsigned)(apieces - 1) * gs), plds + (unsigned)(apieces - 1) * 1024u);
                 }
             };
-            group(IC<5>{}, IC<RO>{}, std::true_type{}, boff, nboff, dma);
-            group(IC<6>{}, IC<RO>{}, std::true_type{}, boff, nboff, dma);
-            group(IC<7>{}, IC<RO>{}, std::true_type{}, boff, nboff, dma);
-            pair8(IC<RO>{}, std::true_type{}, n_aoff, IC<NT>{}, nboff, dma);
+            if constexpr (NA == 4) {
+                group(IC<5>{}, IC<RO>{}, std::true_type{}, boff, nboff, dma);
+                group(IC<6>{}, IC<RO>{}, std::true_type{}, boff, nboff, dma);
+                group(IC<7>{}, IC<RO>{}, std::true_type{}, boff, nboff, dma);
+                pair8(IC<RO>{}, std::true_type{}, n_aoff, IC<NT>{}, nboff, dma);
+            } else {
+                sgroup(IC<5>{}, IC<CUR>{}, std::true_type{}, boff, n_aoff, IC<NT>{}, nboff, dma);
+                sgroup(IC<6>{}, IC<CUR>{}, std::true_type{}, boff, n_aoff, IC<NT>{}, nboff, dma);
+                sgroup(IC<7>{}, IC<CUR>{}, std::true_type{}, boff, n_aoff, IC<NT>{}, nboff, dma);
+                sgroup(IC<8>{}, IC<CUR>{}, std::true_type{}, boff, n_aoff, IC<NT>{}, nboff, dma);
+                sgroup(IC<9>{}, IC<CUR>{}, std::true_type{}, boff, n_aoff, IC<NT>{}, nboff, no_dma);
+            }
         };
         step(IC<0>{});
         step(IC<1>{});
@@ -948,8 +998,13 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
         step(IC<6>{});
         step(IC<7>{});
         step(IC<8>{});
-        ring[0] = ring[2];                                                // step 8 (RO = 0) left b'_0, b'_1 in slots 2, 3: the next chunk
-        ring[1] = ring[3];                                                // (or the first shortcut step) starts with RO = 0 again (8 moves per 360 MFMAs)
+        if constexpr (NA == 4) {
+            ring[0] = ring[2];                                            // step 8 (RO = 0) left b'_0, b'_1 in slots 2, 3: the next chunk
+            ring[1] = ring[3];                                            // (or the first shortcut step) starts with RO = 0 again (8 moves per 360 MFMAs)
+        } else {
+            fa2[0][0] = fa2[1][0];                                        // step 8 ran on A set 0 and read the next step's into set 1
+            fa2[0][1] = fa2[1][1];
+        }
     }
     // ---- phase 1: the fused shortcut GEMM's chunks, ONE step each (centre tap, RO = 0); the next chunk's patch is staged
     //      at MID and waited for at the end of the step, where the next step's first fragments are read (not pipelined deeper)
@@ -958,25 +1013,48 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
         const int naoff = A_BASE + ((nch0 + d + 1) & 1) * ABUF;
         const int boff = (s % NWB) * BTAP, nboff = ((s + 1) % NWB) * BTAP;
         const bool more = d + 1 < nch1;
-        pair0(IC<0>{}, boff);
-        group(IC<2>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
-        group(IC<3>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
-        group(IC<4>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
+        if constexpr (NA == 4) {
+            pair0(IC<0>{}, boff);
+            group(IC<2>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
+            group(IC<3>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
+            group(IC<4>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
+        } else {
+            sgroup(IC<0>{}, IC<0>{}, std::false_type{}, boff, 0, IC<0>{}, 0, no_dma);
+            sgroup(IC<1>{}, IC<0>{}, std::false_type{}, boff, 0, IC<0>{}, 0, no_dma);
+            sgroup(IC<2>{}, IC<0>{}, std::false_type{}, boff, 0, IC<0>{}, 0, no_dma);
+            sgroup(IC<3>{}, IC<0>{}, std::false_type{}, boff, 0, IC<0>{}, 0, no_dma);
+            sgroup(IC<4>{}, IC<0>{}, std::false_type{}, boff, 0, IC<0>{}, 0, no_dma);
+        }
         mid_sync(true);                                                   // (the patch buffer written below is the one step s-1 read)
         if (SUBREG_WIDE_DIAG != 1) {
             if (d + 2 < nch1) stage_weights(a.w2, (unsigned)(d + 2) * wtile, (s + 2) % NWB);
             if (more) for (int q = wid; q < apieces; q += NW) patch_piece(a.x2, porg1 + (unsigned)(d + 1) * (32 * ELEM), xrow1, q, (nch0 + d + 1) & 1);
         }
-        group(IC<5>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
-        group(IC<6>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
-        group(IC<7>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
-        pair8(IC<0>{}, std::false_type{}, 0, IC<0>{}, 0, no_dma);
+        if constexpr (NA == 4) {
+            group(IC<5>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
+            group(IC<6>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
+            group(IC<7>{}, IC<0>{}, std::false_type{}, boff, 0, no_dma);
+            pair8(IC<0>{}, std::false_type{}, 0, IC<0>{}, 0, no_dma);
+        } else {
+            sgroup(IC<5>{}, IC<0>{}, std::false_type{}, boff, 0, IC<0>{}, 0, no_dma);
+            sgroup(IC<6>{}, IC<0>{}, std::false_type{}, boff, 0, IC<0>{}, 0, no_dma);
+            sgroup(IC<7>{}, IC<0>{}, std::false_type{}, boff, 0, IC<0>{}, 0, no_dma);
+            sgroup(IC<8>{}, IC<0>{}, std::false_type{}, boff, 0, IC<0>{}, 0, no_dma);
+            sgroup(IC<9>{}, IC<0>{}, std::false_type{}, boff, 0, IC<0>{}, 0, no_dma);
+        }
         if (more) {
             mid_sync(false);
+            if constexpr (NA == 4) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) fa[i] = rd_a(i, naoff, CENTER);
-            ring[0] = rd_b(0, nboff);
-            ring[1] = rd_b(1, nboff);
+                for (int i = 0; i < NA; ++i) fa[i] = rd_a(i, naoff, CENTER);
+                ring[0] = rd_b(0, nboff);
+                ring[1] = rd_b(1, nboff);
+            } else {
+                fa2[0][0] = rd_a(0, naoff, CENTER);
+                fa2[0][1] = rd_a(1, naoff, CENTER);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ring5[j] = rd_b(j, nboff);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1026,7 +1104,7 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < NB; ++j)
                         *reinterpret_cast<uint2*>(wbase + ii * TR * RS + j * TR * ELEM) = lrelu_pack(acc[2 * ib + ii][j]);
-                const int mrow0 = m0 + wid * 64 + ib * 32;
+                const int mrow0 = m0 + wid * RW + ib * 32;
                 char* const ybase = a.y + ((size_t)mrow0 * a.Cout + n0) * ELEM;
 #pragma unroll
                 for (int v0 = 0; v0 < NV; v0 += 64) {
@@ -1039,7 +1117,7 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
         } else {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int m = m0 + wid * 64 + i * TR + lr;
+                const int m = m0 + wid * RW + i * TR + lr;
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     const int n = n0 + j * TR + 4 * lh;
@@ -1050,7 +1128,7 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
     } else {
         // pixel-major: column = lane % 16 (channel of tile j), registers 0..3 = rows 4 lh + {0..3} of A tile i = ONE 2x2 window
         if (full) {
-            constexpr int NV = 16 * VPR;
+            constexpr int NV = 4 * NA * VPR;                  // 4 NA pooled rows per wave
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const float sh = s_shift[j * TR + lr];
@@ -1062,14 +1140,16 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
                     *reinterpret_cast<T*>(slab + (4 * i + lh) * RS + (j * TR + lr) * ELEM) = (T)best;
                 }
             }
-            const int win0 = (m0 + wid * 64) >> 2;                        // first pooled pixel of this wave
+            const int win0 = (m0 + wid * RW) >> 2;                        // first pooled pixel of this wave
             char* const ybase = a.y + ((size_t)win0 * a.Cout + n0) * ELEM;
 #pragma unroll
             for (int v0 = 0; v0 < NV; v0 += 64) {
                 const int v = v0 + lane;
-                const int row = v / VPR, c16 = v % VPR;
-                const uint4 val = *reinterpret_cast<const uint4*>(slab + row * RS + c16 * 16);
-                *reinterpret_cast<uint4*>(ybase + (size_t)row * a.Cout * ELEM + c16 * 16) = val;
+                if (NV % 64 == 0 || v < NV) {
+                    const int row = v / VPR, c16 = v % VPR;
+                    const uint4 val = *reinterpret_cast<const uint4*>(slab + row * RS + c16 * 16);
+                    *reinterpret_cast<uint4*>(ybase + (size_t)row * a.Cout * ELEM + c16 * 16) = val;
+                }
             }
         } else {
 #pragma unroll
@@ -1078,7 +1158,7 @@ __global__ __launch_bounds__(256, 2) void conv_wide16_kernel(const ConvArgs a) {
                 const float sh = s_shift[j * TR + lr];
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
-                    const int m = m0 + wid * 64 + i * TR + 4 * lh;
+                    const int m = m0 + wid * RW + i * TR + 4 * lh;
                     if (m < g.M) {
                         const f32x4& cfr = acc[i][j];
                         float best = fmaxf(fmaxf(cfr[0], cfr[1]), fmaxf(cfr[2], cfr[3])) + sh;
@@ -1132,17 +1212,20 @@ int launch_wide(const ConvArgs& a, hipStream_t stream) {
     return launch_status();
 }
 
-template <bool POOL, int AROWS>
+template <int NA, bool POOL, int AROWS, int MINW>
 int launch_wide16(const ConvArgs& a, hipStream_t stream) {
-    constexpr int TM = 256, TN = 160;
+    constexpr int TM = 64 * NA, TN = 160;
     const size_t lds = 3 * (size_t)TN * 64 + 2 * (size_t)(AROWS + 1) * 64 + TN * sizeof(float);
-    auto kern = conv_wide16_kernel<POOL, AROWS>;
+    auto kern = conv_wide16_kernel<NA, POOL, AROWS, MINW>;
     static std::atomic<unsigned long long> lds_set{0};
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set)) return rc;
     dim3 grid(((a.g.M + TM - 1) / TM) * (a.Cout / TN));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
     return launch_status();
 }
+// patch rows of the 128-row tiling of conv_wide16_kernel: 160 (the 10x10 / 5x5 maps: 52 KB of LDS, three workgroups per CU) or 224
+// (21x21 / 42x42 un-pooled, 21x21 / 10x10 pooled: 60 KB, two)
+constexpr int AR_S1 = 160, AR_S2 = 224;
 // MFMA shape of the 256-row tiling.  Default: 16x16x32 (conv_wide16_kernel); SUBREG_WIDE_TR=32 selects conv_wide_kernel<2> (measurements),
 // SUBREG_CONV_KERNEL_WIDE_ALT in a call's flags the other one than the default (parity tests).
 int wide_tr_env() { static const int v = [] { const char* e = getenv("SUBREG_WIDE_TR"); return e && *e ? atoi(e) : 0; }(); return v == 16 || v == 32 ? v : 0; }
@@ -1202,12 +1285,50 @@ bool conv_wide_preferred(const ConvArgs& a, bool pool) {
 
 int conv_wide_default_tr(bool pool) { (void)pool; return wide_tr_env() ? wide_tr_env() : 16; }
 
-int conv_wide(const ConvArgs& a, bool pool, hipStream_t stream, int tr) {
+// measured rule of the 128-row tiling against the 256-row one (filled in from profiles/r06_wide16s.txt)
+bool wide16s_preferred(const ConvArgs& a, bool pool);
+
+// worst patch of the 128-row tiling, or 0 when it does not take the problem
+int wide16s_arows(const ConvArgs& a, bool pool) {
+    if (!conv_wide_supported(a, pool)) return 0;                       // (the argument checks are shared)
+    const int worst = pool ? worst_patch_rows_w<true>(a.g, 128) : worst_patch_rows_w<false>(a.g, 128);
+    return worst <= AR_S1 ? AR_S1 : (worst <= AR_S2 ? AR_S2 : 0);
+}
+
+// Tile height of the 16x16x32 form for this problem: 128 where the 128-row tiling is the faster one (profiles/r06_wide16s.txt), else 256.
+int conv_wide_default_rows(const ConvArgs& a, bool pool) {
+    static const int env = [] { const char* e = getenv("SUBREG_WIDE_ROWS"); return e && *e ? atoi(e) : 0; }();
+    const int ar = wide16s_arows(a, pool);
+    if (env == 128) return ar ? 128 : 256;
+    if (env == 256 || !ar) return 256;
+    return wide16s_preferred(a, pool) ? 128 : 256;
+}
+
+int conv_wide(const ConvArgs& a, bool pool, hipStream_t stream, int tr, int rows) {
     if (!conv_wide_supported(a, pool)) return SUBREG_EUNSUPPORTED;
     if (tr == 0) tr = conv_wide_default_tr(pool);
-    if (wide_mi() == 2 && tr == 16) return pool ? launch_wide16<true, AR_POOL2>(a, stream) : launch_wide16<false, AR_LIN2>(a, stream);
+    if (wide_mi() == 2 && tr == 16) {
+        if (rows == 0) rows = conv_wide_default_rows(a, pool);
+        if (rows == 128) {
+            const int ar = wide16s_arows(a, pool);
+            if (ar == AR_S1) return pool ? launch_wide16<2, true, AR_S1, 3>(a, stream) : launch_wide16<2, false, AR_S1, 3>(a, stream);
+            if (ar == AR_S2) return pool ? launch_wide16<2, true, AR_S2, 2>(a, stream) : launch_wide16<2, false, AR_S2, 2>(a, stream);
+            return SUBREG_EUNSUPPORTED;
+        }
+        return pool ? launch_wide16<4, true, AR_POOL2, 2>(a, stream) : launch_wide16<4, false, AR_LIN2, 2>(a, stream);
+    }
     if (wide_mi() == 2) return pool ? launch_wide<2, 4, 1, true, AR_POOL2, 2>(a, stream) : launch_wide<2, 4, 1, false, AR_LIN2, 2>(a, stream);
     return pool ? launch_wide<3, 4, 1, true, AR_POOL3, 1>(a, stream) : launch_wide<3, 4, 1, false, AR_LIN3, 1>(a, stream);
+}
+
+bool wide16s_preferred(const ConvArgs& a, bool pool) {
+    // Measured (profiles/r06_wide16s.txt: general | 256-row | 128-row per layer at 125 ... 1000 images, one box, interleaved): the 128-row
+    // tiling of this file's loop runs its steps at 94-98 % matrix-pipe duty on the 10x10 / 5x5 maps (stamps in the same file) and
+    // still ends within +-3 % of the general kernel's 128-row tiles there (0.98-1.03 at 375-700 images; slower at 125-250 and 1000) and
+    // 5-20 % behind on the larger maps (two workgroups per CU): what those layers lose is rounds of tiles, not loop cycles.  Never
+    // selected; SUBREG_WIDE_ROWS=128 / SUBREG_CONV_KERNEL_WIDE_128 run it (parity tests, measurements).
+    (void)a; (void)pool;
+    return false;
 }
 
 }  // namespace subreg

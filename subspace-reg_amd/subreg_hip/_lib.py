@@ -16,6 +16,7 @@ F32, BF16 = 0, 1
 CONV_LRELU, CONV_POOL2, CONV_RAW_STATS = 1, 2, 4
 CONV_KERNEL_GENERAL, CONV_KERNEL_WIDE = 256, 512   # kernel selection of subreg_conv_fwd (Cout % 160 == 0): conv_fwd.hip / conv_wide.hip
 CONV_KERNEL_WIDE_ALT = 1024                        # with _WIDE: the other MFMA shape of conv_wide.hip than its default for the problem
+CONV_KERNEL_WIDE_128, CONV_KERNEL_WIDE_256 = 2048, 4096   # with _WIDE: the 128- / 256-row tiling of conv_wide16_kernel
 FWD_TRAIN = 1
 ABI_VERSION = 14
 MAX_QUERY_SETS = 32                          # SUBREG_MAX_QUERY_SETS

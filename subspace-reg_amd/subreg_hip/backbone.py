@@ -485,7 +485,7 @@ class HipBackbone:
         if self._spec_last is not None and self._spec_last is not x:
             hist.pop(id(self._spec_last), None)
             hist[id(self._spec_last)] = (self._spec_last, x)              # (strong references: an id is only compared while its tensor lives)
-            while len(hist) > 64:
+            while len(hist) > 16:                                        # (each entry keeps two caller tensors alive: ~10 MB per 125 images)
                 hist.pop(next(iter(hist)))
         self._spec_last = x
         pend = self._spec_pending

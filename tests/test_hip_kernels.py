@@ -82,8 +82,9 @@ def _round_bf16(a):
 
 # Kernel selection of subreg_conv_fwd for the wide layers (Cout % 160 == 0, bf16, eval mode): "auto" = the dispatcher's measured rule,
 # "general" = conv_fwd.hip forced, "wide" = conv_wide.hip forced in its default MFMA shape (16x16x32: conv_wide16_kernel),
-# "wide_alt" = conv_wide.hip in the other shape (32x32x16: conv_wide_kernel).  The parity tests below run over all four.
-KERNELS = ["auto", "general", "wide", "wide_alt"]
+# "wide_alt" = conv_wide.hip in the other shape (32x32x16: conv_wide_kernel), "wide128" / "wide256" = conv_wide16_kernel's 128- / 256-row tiling
+# forced (128 rows: skipped where the patch does not fit).  The parity tests below run over all four.
+KERNELS = ["auto", "general", "wide", "wide_alt", "wide128", "wide256"]
 
 
 def _kernel_flag(kernel, dtype, Cout, k=3):
@@ -93,7 +94,15 @@ def _kernel_flag(kernel, dtype, Cout, k=3):
         pytest.skip("one kernel only for this problem")
     if kernel == "general":
         return _lib.CONV_KERNEL_GENERAL
-    return _lib.CONV_KERNEL_WIDE | (_lib.CONV_KERNEL_WIDE_ALT if kernel == "wide_alt" else 0)
+    return _lib.CONV_KERNEL_WIDE | {"wide": 0, "wide_alt": _lib.CONV_KERNEL_WIDE_ALT, "wide128": _lib.CONV_KERNEL_WIDE_128,
+                                    "wide256": _lib.CONV_KERNEL_WIDE_256}[kernel]
+
+
+def _check_conv(rc, kernel, what):
+    """_lib.check, except that the 128-row tiling of conv_wide16_kernel may refuse a problem whose patch does not fit its LDS"""
+    if kernel == "wide128" and rc == -2:
+        pytest.skip("the 128-row tiling does not take this problem (patch rows)")
+    _lib.check(rc, what)
 
 
 CONV_CASES = [
@@ -326,9 +335,9 @@ def test_conv_folded_scale_and_fused_shortcut(case, dtype, kernel):
     else:
         w2d = _pack_w(w2, dtype, fold=sc2)
     flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0) | _kernel_flag(kernel, dtype, Cout)
-    _lib.check(lib.subreg_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), None, _lib.ptr(shd), None, None, _lib.ptr(x2d),
-                                   _lib.ptr(w2d), c2, B, H, W, Cin, Cout, 3, flags, _lib.dtype_code(dtype), _lib.stream_ptr()),
-               "conv_fwd(fused)")
+    _check_conv(lib.subreg_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), None, _lib.ptr(shd), None, None, _lib.ptr(x2d),
+                                    _lib.ptr(w2d), c2, B, H, W, Cin, Cout, 3, flags, _lib.dtype_code(dtype), _lib.stream_ptr()),
+                kernel, "conv_fwd(fused)")
     got = _nchw_host(y, B, Cout, Ho, Wo, dtype)
     a, r = _tol(dtype, np.abs(want).max())
     _cmp("fused conv3", got, rr._nchw(want), a, r)
@@ -484,9 +493,9 @@ def test_conv_fwd_production_tiles(case, dtype, kernel):
     y = torch.full((B * Ho * Wo, Cout), float("nan"), dtype=td, device=_dev())
     shd = _t(shift)
     flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0) | _kernel_flag(kernel, dtype, Cout, k)
-    _lib.check(lib.subreg_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), None, _lib.ptr(shd), None, None, _lib.ptr(x2d),
-                                   _lib.ptr(w2d), (Cout if Cin2 == 0 else max(Cin2, 0)), B, H, W, Cin, Cout, k, flags,
-                                   _lib.dtype_code(dtype), _lib.stream_ptr()), "conv_fwd(big)")
+    _check_conv(lib.subreg_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), None, _lib.ptr(shd), None, None, _lib.ptr(x2d),
+                                    _lib.ptr(w2d), (Cout if Cin2 == 0 else max(Cin2, 0)), B, H, W, Cin, Cout, k, flags,
+                                    _lib.dtype_code(dtype), _lib.stream_ptr()), kernel, "conv_fwd(big)")
     torch.cuda.synchronize()
     assert not torch.isnan(y.float()).any().item(), "an output row was never written"
     rows = torch.from_numpy((pb * Ho + ph) * Wo + pw).to(_dev())

@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--im2col", action="store_true", help="layer 1 over the K = 32 im2col buffer (the round-2 route) + pack_input")
     ap.add_argument("--unfused", action="store_true", help="conv1 (from the image) and conv2 of layer 1 as two launches")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "general", "wide", "wide_alt"],
+    ap.add_argument("--kernel", default="auto", choices=["auto", "general", "wide", "wide_alt", "wide128", "wide256"],
                     help="wide layers (Cout % 160 == 0): the dispatcher's rule, conv_fwd.hip forced, conv_wide.hip forced")
     ap.add_argument("--data", default="normal", choices=["normal", "zeros", "narrow", "half"],
                     help="operand values of the general layers (power experiment): N(0, 1) activations and N(0, 1/K) weights; all zeros; "
@@ -138,11 +138,16 @@ def main():
         flags = _lib.CONV_LRELU | (_lib.CONV_POOL2 if pool else 0)
         if Cout % 160 == 0 and a.dtype == "bf16":
             flags |= {"auto": 0, "general": _lib.CONV_KERNEL_GENERAL, "wide": _lib.CONV_KERNEL_WIDE,
-                      "wide_alt": _lib.CONV_KERNEL_WIDE | _lib.CONV_KERNEL_WIDE_ALT}[a.kernel]
+                      "wide_alt": _lib.CONV_KERNEL_WIDE | _lib.CONV_KERNEL_WIDE_ALT, "wide128": _lib.CONV_KERNEL_WIDE | _lib.CONV_KERNEL_WIDE_128,
+                      "wide256": _lib.CONV_KERNEL_WIDE | _lib.CONV_KERNEL_WIDE_256}[a.kernel]
 
         def run():
             _lib.check(lib.subreg_conv_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), None, _lib.ptr(shift), None, None,
                                            _lib.ptr(x2), _lib.ptr(w2), c2, B, H, H, Cin, Cout, k, flags, dt, _lib.stream_ptr()))
+        if lib.subreg_conv_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), None, _lib.ptr(shift), None, None, _lib.ptr(x2), _lib.ptr(w2), c2, B, H, H,
+                               Cin, Cout, k, flags, dt, _lib.stream_ptr()) == -2:            # SUBREG_EUNSUPPORTED: a forced kernel that does not take the layer
+            print("%-24s M=%8d K=%5d N=%4d  (the forced kernel does not take this problem)" % (name, npix, Cin * k * k, Cout))
+            continue
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
