@@ -305,7 +305,8 @@ def route_a(args, net, opt, meta, dev, n_epochs=16):
     hb = net.hip_backbone()
     return {"epochs_per_s": 1.0 / dt, "ms_per_epoch": dt * 1e3, "images_per_epoch": 1125,
             "prefetch": {"depth": int(hb.EVAL_PREFETCH), "forwards_served_from_a_prefetch": int(hb.prefetch_hits),
-                         "forwards": 9 * (n_epochs + 4), "cached_graphs": len(hb._graphs)},
+                         "forwards": 9 * (n_epochs + 4), "cached_graphs": len(hb._graphs),
+                         "streams_found_parallel": getattr(hb, "prefetch_streams_calibrated", None)},
             "shape": "session 8 of 8: 125 support + 8 x 125 query images, 9 backbone forwards, torch autograd + SGD on classifier.weight [100, 640]"}
 
 

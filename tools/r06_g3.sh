@@ -1,13 +1,5 @@
 mkdir -p gpurun_out/r06
-O=gpurun_out/r06/wide16s.txt; : > $O
-for B in 125 250 375 500 700 1000; do
-  for rep in 1 2; do
-    for k in general wide256 wide128; do
-      echo "== batch $B kernel $k round $rep" >> $O
-      python tools/bench_conv.py --batch $B --kernel $k 2>&1 | grep "^L[234]" | grep -v "does not take" >> $O
-    done
-  done
-done
-echo "== loop ends stamps, 128-row tiling forced" >> $O
-SUBREG_WIDE_ROWS=128 SUBREG_LIB=$PWD/subspace-reg_amd/subreg_hip/libsubreg_wd8.so python tools/diag_conv.py --batch 700 --kernel wide 2>&1 | grep -v amdgpu.ids >> $O
-tail -3 $O
+for i in 1 2 3; do python bench.py --steps 4 --warmup 1 --no-cpu-baseline --sweep-seeds 0 2>/dev/null | python3 -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(j.get('route_a'))[:420])"; done
+echo "== TN128 experiment (general kernel, L3.1 / L4.x), two rounds"
+for rep in 1 2; do for B in 250 500 700 1000; do for e in 0 1; do echo "-- batch $B SUBREG_TN128=$e"; SUBREG_TN128=$e python tools/bench_conv.py --batch $B --kernel general --only L4 2>&1 | grep "^L4"; done; done; done | tee gpurun_out/r06/tn128.txt
+SUBREG_TN128=1 python -m pytest tests/test_hip_kernels.py -x -q -k "conv" 2>&1 | tail -3
