@@ -1277,10 +1277,36 @@ bool conv_wide_preferred(const ConvArgs& a, bool pool) {
     // wherever the 256-row tiles fill the chip: -5 ... -13 % on layer 2 (conv1, K = 576, from ~350 images), -2 ... -9 % on layer 3.0 and
     // layer 4.0 from ~450 images; on layer 3.1 (10x10, 320 channels: 548 tiles at 700 images for 512 slots) the general kernel's
     // 128-row tiles win at every batch; the 5x5 maps only from ~1000 images (-7 %).
-    if (a.g.W >= 42) return a.Cin >= 160 ? a.g.M >= 200000 : a.g.M >= 600000;
-    if (a.g.W >= 21) return a.g.M >= (pool ? 100000 : 200000);
-    if (a.g.W >= 10) return a.Cout >= 640 && a.g.M >= 50000;
-    return a.g.M >= 24000;
+    // (SUBREG_WIDE_CLASSES: measurement switch - the layer classes that take this kernel whatever their size: A = 42x42 from 64 channels,
+    // B = 42x42 from 160 (un-pooled and pooled), C = 21x21 un-pooled, D = 21x21 pooled, E = 10x10 to 640 channels, F = 10x10 to 320, G = 5x5)
+    static const char* classes = getenv("SUBREG_WIDE_CLASSES");
+    if (classes) {
+        const char c = a.g.W >= 42 ? (a.Cin >= 160 ? 'B' : 'A') : a.g.W >= 21 ? (pool ? 'D' : 'C') : a.g.W >= 10 ? (a.Cout >= 640 ? 'E' : 'F') : 'G';
+        for (const char* p = classes; *p; ++p)
+            if (*p == c) return true;
+        return false;
+    }
+    // (SUBREG_WIDE_SCALE: measurement switch, multiplies the thresholds - the table above is per launch on one stream, the forward runs two
+    // lanes side by side, where a partial round of tiles costs less)
+    static const double sc = [] { const char* e = getenv("SUBREG_WIDE_SCALE"); return e && *e ? atof(e) : 1.0; }();
+    static const int rule = [] { const char* e = getenv("SUBREG_WIDE_RULE"); return e && *e ? atoi(e) : 3; }();
+    const double M = (double)a.g.M;
+    if (rule == 1) {           // the per-launch table alone (one stream, 20 launches back to back)
+        if (a.g.W >= 42) return a.Cin >= 160 ? M >= 200000 * sc : M >= 600000 * sc;
+        if (a.g.W >= 21) return M >= (pool ? 100000 : 200000) * sc;
+        if (a.g.W >= 10) return a.Cout >= 640 && M >= 50000 * sc;
+        return M >= 24000 * sc;
+    }
+    // rules 2 / 3 (3 = default): re-measured where the kernels RUN - in the two-lane forward, one layer class at a time at eight batches
+    // (profiles/r06_forward_classes.txt), then whole rules against each other (r06_forward_rules.txt: rule 2 -0.4 %, rule 3 -0.9 % over
+    // the eight batches, -1.3 % at 1000 / 1125 images).  Beside another lane's kernels a partial round of 256-row tiles costs less than
+    // alone, so layer 3.0's un-pooled convolutions pay from ~190 images per lane, not ~450; and with every other wide layer on this
+    // kernel layers 3.1 / 4.1 pay from 500 images per lane although each alone does not (the gains are not additive: the chip holds a
+    // higher clock the more of the forward runs on the cheaper MFMA shape).
+    if (a.g.W >= 42) return a.Cin >= 160 ? M >= 200000 * sc : M >= 550000 * sc;
+    if (a.g.W >= 21) return M >= (pool ? 120000 : 80000) * sc;
+    if (a.g.W >= 10) return a.Cout >= 640 ? M >= 50000 * sc : (rule >= 3 && M >= 50000 * sc);
+    return rule >= 3 && M >= 12500 * sc;
 }
 
 int conv_wide_default_tr(bool pool) { (void)pool; return wide_tr_env() ? wide_tr_env() : 16; }

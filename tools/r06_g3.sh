@@ -1,5 +1,10 @@
 mkdir -p gpurun_out/r06
-for i in 1 2 3; do python bench.py --steps 4 --warmup 1 --no-cpu-baseline --sweep-seeds 0 2>/dev/null | python3 -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(j.get('route_a'))[:420])"; done
-echo "== TN128 experiment (general kernel, L3.1 / L4.x), two rounds"
-for rep in 1 2; do for B in 250 500 700 1000; do for e in 0 1; do echo "-- batch $B SUBREG_TN128=$e"; SUBREG_TN128=$e python tools/bench_conv.py --batch $B --kernel general --only L4 2>&1 | grep "^L4"; done; done; done | tee gpurun_out/r06/tn128.txt
-SUBREG_TN128=1 python -m pytest tests/test_hip_kernels.py -x -q -k "conv" 2>&1 | tail -3
+O=gpurun_out/r06/bench_ab_same_box.txt; : > $O
+for rep in 1 2 3; do
+  for cfg in "SUBREG_WIDE_TR=32" "SUBREG_WIDE_RULE=1" "SUBREG_WIDE_RULE=3" "SUBREG_WIDE=0"; do
+    echo -n "$cfg  " >> $O
+    env $cfg python bench.py --no-extra-legs --no-cpu-baseline --sweep-seeds 0 2>/dev/null | python3 -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('episodes/s %.4f  balanced %.4f  ms_per_step %.2f  roofline.frac %.4f' % (j['value'], j['episodes_per_s_balanced'], j['ms_per_step'], j['roofline']['frac']))" >> $O
+  done
+done
+cat $O
+python -m pytest tests/test_hip_kernels.py tests/test_hip_loop.py -x -q 2>&1 | tail -3
