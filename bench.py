@@ -348,9 +348,9 @@ def pretrain_leg(args):
                 fn()
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n
-        for _ in range(4):
+        for _ in range(8):
             eager_step()
-        dt_eager = timed(eager_step, 10)
+        dt_eager = min(timed(eager_step, 10), timed(eager_step, 10))
         for _ in range(5):                                             # (warm-up calls, the capture, first replays)
             step()
         dt = timed(step, 20)

@@ -722,6 +722,30 @@ def test_graphed_eval_forward_equals_eager_and_follows_weight_updates():
         hb.forward = real_forward
 
 
+def test_prefetched_two_lane_forwards_equal_the_eager_ones():
+    """forward_graphed's input-sequence prefetch with forwards that are themselves split over two lanes (>= 128 images): a prefetched
+    forward runs on workspace sets of its own (lane_base 2, 3 / 4, 5) while the caller's stream may run another forward of the same
+    backbone on sets 0, 1 - results must be those of the eager forward, whichever path served the call."""
+    from subreg_hip.backbone import HipBackbone
+    sd = syn.make_state_dict(4)
+    params = {k: _t(v) for k, v in sd.items() if v.dtype != np.int64}
+    hb = HipBackbone(params, (1, 1, 2, 2), "bf16")
+    if hb.EVAL_PREFETCH <= 0:
+        pytest.skip("prefetch switched off in this environment")
+    xs = [_t(syn.make_images(40 + i, 130, 84)) for i in range(4)]
+    want = [hb.forward(x).clone() for x in xs]
+    x70 = xs[3][:70].contiguous()
+    want70 = hb.forward(x70).clone()
+    for rep in range(4):
+        for i, x in enumerate(xs):
+            got = hb.forward_graphed(x)
+            assert torch.equal(got, want[i]), (rep, i, (got - want[i]).abs().max().item())
+            if rep == 3 and i == 1:                        # an eager forward of another batch on sets 0, 1 while two prefetches are in flight
+                assert torch.equal(hb.forward(x70), want70)
+    torch.cuda.synchronize()
+    assert hb.prefetch_hits >= 6, hb.prefetch_hits
+
+
 def test_workspace_capacity_is_not_monotone_in_batch():
     """A train-mode forward at B=64 followed by B=55 (84x84, bf16): the smaller batch needs MORE BN-partial floats (layer 2
     switches to 128-row tiles below 56 images).  The workspace must grow, and the result must equal a fresh backbone's."""
