@@ -308,12 +308,13 @@ def route_a(args, net, opt, meta, dev, n_epochs=16):
     hb.EVAL_PREFETCH = 0
     dt_off = timed_epochs()
     hb.EVAL_PREFETCH = depth
+    hb.prefetch_hits = 0
     dt = timed_epochs()
     with torch.no_grad():
         net.classifier.weight = torch.nn.Parameter(net.classifier.weight.detach()[:60].clone())
     return {"epochs_per_s": 1.0 / dt, "ms_per_epoch": dt * 1e3, "images_per_epoch": 1125, "epochs_per_s_without_prefetch": 1.0 / dt_off,
             "prefetch": {"depth": int(hb.EVAL_PREFETCH), "forwards_served_from_a_prefetch": int(hb.prefetch_hits),
-                         "forwards": 9 * 2 * (n_epochs + 4), "cached_graphs": len(hb._graphs),
+                         "forwards": 9 * (n_epochs + 4), "cached_graphs": len(hb._graphs),
                          "streams_found_parallel": getattr(hb, "prefetch_streams_calibrated", None)},
             "shape": "session 8 of 8: 125 support + 8 x 125 query images, 9 backbone forwards, torch autograd + SGD on classifier.weight [100, 640]"}
 

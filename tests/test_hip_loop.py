@@ -211,7 +211,8 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
             want_moved = float(g[k])
             assert want_moved > 0
             many_steps = tag in ("hw32_freeze3_adam", "hw32_freeze5_M")         # (see `loose` below)
-            assert abs(moved - want_moved) <= ((1e-2 if many_steps else 2e-3) if f32 else 0.25) * want_moved, (name, moved, want_moved)
+            # (bf16, measured: within 4.5 % on every pinned tensor of the three cases)
+            assert abs(moved - want_moved) <= ((1e-2 if many_steps else 2e-3) if f32 else 0.08) * want_moved, (name, moved, want_moved)
             want = g["final." + name]
             # f32: element-wise on the update itself (the weights moved by ~1e-5 per element: compare the DIFFERENCE to the start)
             d_got, d_want = (got[:want.shape[0]] - sd0[name][:want.shape[0]]).astype(np.float64), (want - sd0[name][:want.shape[0]]).astype(np.float64)
@@ -221,7 +222,18 @@ def test_fused_loop_against_reference_golden(tag, dtype, tmp_path):
             # LeakyReLU / MaxPool decisions: measured 2.6e-2 / 2.7e-2 on layer1.0.conv1.weight in f32 with every loss within 7e-6
             # of the reference's (the joint two-forward backward itself is pinned at 2e-5 by test_hip_train.py)
             loose = tag in ("hw32_freeze3_adam", "hw32_freeze5_M")
-            assert l2 < ((5e-2 if loose else 1e-2) if f32 else (0.7 if loose else 0.5)), ("backbone update", name, l2)
+            # bf16, measured (the reference run is f32): 0.007-0.30 under SGD, growing from the last layer (its gradient is exact up to
+            # the features' rounding) to the first (every LeakyReLU / MaxPool decision between flips some elements); Adam turns an
+            # element whose gradient is within that noise of zero into +-lr: 0.07-0.57
+            adam = tag == "hw32_freeze3_adam"
+            assert l2 < ((5e-2 if loose else 1e-2) if f32 else (0.65 if adam else 0.4)), ("backbone update", name, l2)
+            # direction of the update against the f32 reference run (round-5 advisor: the L2 gate alone pins little in bf16).
+            # Measured in bf16: >= 0.955 under SGD (0.9994-1.0 on layer 4's tensors), >= 0.829 under Adam (>= 0.978 on layer4.1's)
+            cos = float((d_got * d_want).sum() / max(np.linalg.norm(d_got) * np.linalg.norm(d_want), 1e-30))
+            print("backbone update %s %s (%s): relative L2 %.4f, cosine %.4f, moved %.4g / %.4g" % (tag, name, "f32" if f32 else "bf16", l2, cos, moved, want_moved))
+            last_block = name.startswith("layer4.1.")
+            want_cos = 0.998 if f32 else ((0.96 if last_block else 0.78) if adam else (0.998 if last_block else 0.93))
+            assert cos > want_cos, ("backbone update direction", name, cos, want_cos)
     if f32:
         _cmp("novel avg", novel_avg, g["novel_avg"], 1e-5, 1e-6)
         _cmp("base avg", base_avg, g["base_avg"], 1e-5, 1e-6)
