@@ -693,14 +693,8 @@ def main():
     #                   is reported under "sweep", the parent prints the line regardless;
     #      N ranks   -> it needs this process group, so it runs here under a deadline thread that prints the line without it.
     if world == 1 and not args.no_extra_legs:
-        # route A (the reference's unchanged loop statements over the drop-in modules) and the measured inputs of the sweep model:
-        # in this process (they need the backbone), each wrapped - nothing here can cost the line
-        try:
-            out["route_a"] = route_a(args, net, opt, meta, dev)
-            if 7 in session_seconds:
-                out["route_a"]["fused_loop_epochs_per_s_same_shape"] = args.epochs / (session_seconds[7] - 0.0)
-        except Exception as exc:                                   # noqa: BLE001
-            out["route_a"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        # the feature-reuse figure and the measured inputs of the sweep model: in this process (they need the backbone), each wrapped -
+        # nothing here can cost the line
         # SURVEY.md section 8d "report both": the same 8-session workload with the frozen backbone's (constant) eval-mode features
         # computed ONCE per session and reused by every later epoch - results identical to the headline's recomputation
         # (tests/test_hip_loop.py::test_feature_reuse_is_results_identical; eval/language_eval.py:252,321-326 feed constant inputs
@@ -767,6 +761,14 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         out["pretrain"] = leg_in_child(args, "--pretrain-only", "pretrain", 300)
+        # route A (the reference's unchanged loop statements over the drop-in modules): a child process too - the leg as a user's script
+        # runs it, in a process of its own.  (Inside THIS process, behind the fused-loop run and the streams it created, the same leg
+        # measured 100-106 epochs/s where the fresh process gives 118-123: DESIGN.md section 4.8.)
+        out["route_a"] = leg_in_child(args, "--route-a-only", "route_a", 300)
+        if isinstance(out["route_a"], dict) and "error" not in out["route_a"]:
+            out["route_a"]["process"] = "child of bench.py (fresh process)"
+            if 7 in session_seconds:
+                out["route_a"]["fused_loop_epochs_per_s_same_shape"] = args.epochs / (session_seconds[7] - 0.0)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -1,10 +1,7 @@
 #!/bin/bash
-# smoke + the default bench line on the final tree
 mkdir -p gpurun_out/r06
-python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" 2>&1 | grep -v amdgpu.ids | tail -3
 python3 bench.py 2> gpurun_out/r06/bench_final.err > gpurun_out/r06/bench_final.json
-tail -c 600 gpurun_out/r06/bench_final.err
 python3 -c "
 import json; d=json.loads(open('gpurun_out/r06/bench_final.json').read().strip().splitlines()[-1])
-print(d['value'], d['episodes_per_s_balanced'], d['roofline']['frac'], d['route_a'], d['feature_reuse']['episodes_per_s'], {k:(v['ms_per_step'], v.get('ms_per_step_eager')) for k,v in d['pretrain']['batches'].items()})
+print(d['value'], d['episodes_per_s_balanced'], d['roofline']['frac'], d['route_a'], d['feature_reuse']['episodes_per_s'], {k:(v['ms_per_step'], v.get('ms_per_step_eager')) for k,v in d['pretrain']['batches'].items()}, d['cpu_baseline']['value'])
 "
