@@ -527,8 +527,10 @@ class GraphedStep:
         ent = self.entries.get(key)
         if ent is None:
             if len(self.entries) >= self.max_graphs:                     # a new learning rate / shape: the oldest entry goes
-                torch.cuda.synchronize()
-                self.entries.pop(next(iter(self.entries)))
+                oldest = next(iter(self.entries))
+                if self.entries[oldest]["graph"] is not None:            # (its last replay may still be in flight; an entry that never
+                    torch.cuda.synchronize()                             #  captured - a learning rate that changes every step - costs nothing)
+                self.entries.pop(oldest)
             ent = self.entries[key] = dict(calls=0, graph=None, inputs=None, outputs=None, failed=False)
         ent["calls"] += 1
         eager_only = (ent["failed"] or getattr(hb, "grad_stage_hook", None) is not None or self.model.mask_source is not None
