@@ -152,11 +152,12 @@ def train(epoch, train_loader, model, criterion, optimizer, opt, lang_puller=Non
     batch_time, data_time, losses, top1, top5 = (AverageMeter() for _ in range(5))
     dev = next(model.parameters()).device
     counters = torch.zeros(2, dtype=torch.int32, device=dev)
-    # One process, one GPU: the whole step (forward, loss + accuracy counters, backward, optimiser step) is ONE hipGraph per batch
-    # shape and learning rate (train.GraphedStep; opt.hip_graph = False keeps the eager launches).  The stepper lives on the
-    # optimiser, so the graphs survive from epoch to epoch.
+    # One process, one GPU, opt.hip_graph = True: the whole step (forward, loss + accuracy counters, backward, optimiser step) as ONE
+    # hipGraph per batch shape and learning rate (train.GraphedStep).  Opt-in: the step is bound by the GPU (3.9 ms eager, 4.06 ms
+    # replayed at 64 images, profiles/r06_train_step.txt) - the graph frees 2.5 ms of host time per step, it does not shorten the step.
+    # The stepper lives on the optimiser, so the graphs survive from epoch to epoch.
     stepper = None
-    if world == 1 and grad_sync is None and getattr(opt, "hip_graph", True):
+    if world == 1 and grad_sync is None and getattr(opt, "hip_graph", False):
         stepper = getattr(optimizer, "_subreg_graphed_step", None)
         if stepper is None or stepper.model is not model:
             def loss_fn(input, target, _model=model, _opt=opt, _lp=lang_puller):
