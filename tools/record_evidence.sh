@@ -1,6 +1,7 @@
 #!/bin/bash
 # Re-record the round's measurements on the GPU box (run through gpurun from the repo root):
-#   bash tools/record_evidence.sh [tag]     -> everything under gpurun_out/evidence/
+#   gpurun -- "SUBREG_EVIDENCE_HEAD=$(git rev-parse --short HEAD) bash tools/record_evidence.sh [tag]"     -> everything under gpurun_out/evidence/
+# (the box has no .git: SUBREG_EVIDENCE_HEAD is what profiles/traffic.json records as the commit the HBM traffic was measured on)
 # Then copy what should be judged into profiles/ as <tag>_* (see profiles/README.md).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
